@@ -1,0 +1,294 @@
+/*
+ * krs.h -- C ABI of libkrs_hip.so: the MI355X (gfx950) hot path behind the
+ * keras-rs layer API (embedding gather+pool, its index-scatter gradient,
+ * DotInteraction, FeatureCross).
+ *
+ * The reference (keras-team/keras-rs) has NO FFI of its own: its boundary for
+ * this path is the Keras layer protocol plus the DistributedEmbedding backend
+ * hook set (keras_rs/src/layers/embedding/base_distributed_embedding.py:990-1042).
+ * Every entry point below therefore names the reference *Python* statement(s)
+ * whose arithmetic it replaces; the Python layers in keras_rs_amd/layers call
+ * these through ctypes from inside torch.autograd.Function objects.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types: device pointers are `void*`, the stream is
+ *     a `hipStream_t` passed as `void*` (NULL = the null stream);
+ *   - every function returns 0 on success or a negative krs_status; the text of
+ *     the last failure on the calling thread is krs_last_error();
+ *   - no allocation, no ownership transfer, no hidden state: the caller owns
+ *     inputs, outputs and workspaces (sizes from *_workspace_bytes()); calls are
+ *     asynchronous and ordered by `stream`; safe from any host thread;
+ *   - all matrices are row-major; `ld*` are row strides in ELEMENTS;
+ *   - index work is bit-exact; floating point accumulates in fp32.
+ */
+#ifndef KRS_H_
+#define KRS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KRS_VERSION 100 /* 0.1.0 */
+
+typedef enum krs_status {
+  KRS_OK = 0,
+  KRS_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, bad enum) */
+  KRS_ERR_UNSUPPORTED = -2, /* valid but not implemented for this shape/dtype */
+  KRS_ERR_LAUNCH = -3,      /* HIP launch / runtime failure */
+  KRS_ERR_WORKSPACE = -4    /* workspace too small */
+} krs_status;
+
+typedef enum krs_dtype { KRS_F32 = 0, KRS_BF16 = 1 } krs_dtype;
+typedef enum krs_itype { KRS_I32 = 0, KRS_I64 = 1 } krs_itype;
+
+/* EmbedReduce combiners, embed_reduce.py:10 (SUPPORTED_COMBINERS). */
+typedef enum krs_combiner { KRS_SUM = 0, KRS_MEAN = 1, KRS_SQRTN = 2 } krs_combiner;
+
+/* keras activations FeatureCross(pre_activation=...) that are fused into the
+ * GEMM epilogue; anything else is composed by the host layer. */
+typedef enum krs_activation {
+  KRS_ACT_NONE = 0,
+  KRS_ACT_RELU = 1,
+  KRS_ACT_SIGMOID = 2,
+  KRS_ACT_TANH = 3
+} krs_activation;
+
+/* Bits OR'ed into the optional device-side error word of the embedding calls.
+ * Out-of-range ids are never clamped: the row contributes nothing and the bit
+ * is raised (SURVEY.md section 8c decision on keras ops.take out-of-range). */
+#define KRS_FLAG_ID_OUT_OF_RANGE 1
+#define KRS_FLAG_BAD_OFFSETS 2
+
+/* One embedding table ([vocab, dim] row-major).  Lives in DEVICE memory as an
+ * array indexed by krs_feature.table.  Replaces the `embeddings` variable of
+ * one EmbedReduce sublayer (base_distributed_embedding.py:836-852). */
+typedef struct krs_table {
+  void* weights;    /* [vocab, dim] fp32 or bf16 (table dtype of the call) */
+  float* slot;      /* optimizer slot: Adagrad accumulator [vocab, dim] fp32, or NULL */
+  int64_t row_base; /* global row id of row 0: tables of one call get disjoint
+                       [row_base, row_base+vocab) ranges (sort keys of the backward) */
+  int32_t vocab;
+  float lr;         /* learning rate of this table's fused optimizer */
+} krs_table;
+
+/* One feature = one (ids, table) pair; several features may name one table
+ * (distributed_embedding_test.py:601-652).  DEVICE memory array.
+ * Bags are numbered feature-major: bag = feature * batch + sample. */
+typedef struct krs_feature {
+  int64_t ids_base; /* dense mode (offsets == NULL): index of this feature's first
+                       id in `ids`; bag (f, b) owns ids[ids_base + b*hot .. +hot) */
+  int32_t table;    /* index into the krs_table array */
+  int32_t hot;      /* dense mode: ids per bag (the L of a [batch, L] input) */
+  int32_t combiner; /* krs_combiner */
+  int32_t out_col;  /* first column of this feature's dim-wide slot in an output row */
+} krs_feature;
+
+int krs_version(void);
+const char* krs_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * K1  fused multi-table gather + weighted segment pool (forward)
+ *
+ * Replaces, for ALL features of a DistributedEmbedding in one launch, the
+ * per-feature chain of the reference:
+ *   keras.layers.Embedding.call -> ops.take(table, ids, axis=0)   embed_reduce.py:178
+ *   x * w (w = ones when weights is None)                         embed_reduce.py:224-253
+ *   ops.sum(axis=-2), divide_no_nan by sum(w) / sqrt(sum(w^2))     embed_reduce.py:255-274
+ *   python loop over features                                     base_distributed_embedding.py:910-928
+ *
+ *   out[b*out_ld + feats[f].out_col + c] =
+ *        scale(f,b) * sum_{p in bag(f,b)} w[p] * table_f[ids[p], c]
+ *   scale = 1 (sum) | 1/sum w (mean) | 1/sqrt(sum w^2) (sqrtn); 0 where the
+ *   divisor is 0 (divide_no_nan).  Accumulation is fp32 in ascending p.
+ *
+ * ids      [nnz] int32/int64, feature-major concatenation of all features' ids
+ * offsets  CSR mode: [n_feats*batch + 1] (int32/int64) bag boundaries into ids;
+ *          NULL = dense mode (krs_feature.ids_base / hot describe the bags)
+ * weights  [nnz] fp32 per-id weights or NULL (= all ones)
+ * bag_scale optional [n_feats*batch] fp32: receives scale(f,b) for the backward
+ * err_flag optional device int, OR'ed with KRS_FLAG_* bits
+ * ------------------------------------------------------------------------- */
+int krs_embed_bag_fwd(const krs_table* tables, const krs_feature* feats, int n_feats,
+                      const void* ids, int id_type,
+                      const void* offsets, int off_type,
+                      const float* weights,
+                      int batch, int dim, int table_dtype,
+                      void* out, int out_dtype, int64_t out_ld,
+                      float* bag_scale, int* err_flag, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * K2  index-scatter gradient of K1
+ *
+ * Replaces the autodiff of ops.take/multiply/sum (restated by the reference at
+ * keras_rs/src/layers/embedding/jax/test_utils.py:395-417, accumulated per
+ * table over features :450-468) and, in the fused forms, the per-table
+ * optimizer step of jax/test_utils.py:474-497 (SGD: t -= lr*g;
+ * Adagrad: acc += g*g; t -= lr*g/sqrt(acc), no epsilon).
+ *
+ *   dE_table[r, :] = sum over {p : ids[p] == r, feature(p) uses table}
+ *                       w[p] * scale(bag(p)) * grad[b(p)*grad_ld + out_col + :]
+ *
+ * Step 1 (plan): stable sort of the nnz lookups by global row id
+ * (tables[t].row_base + id).  Within one row the contributions are then
+ * summed in ascending p: the result is deterministic (run-to-run bit-exact).
+ * Step 2 (apply): one pass over the sorted segments that either writes the
+ * dense gradient rows, or applies SGD / Adagrad to the touched rows in place.
+ * ------------------------------------------------------------------------- */
+size_t krs_embed_bag_bwd_workspace_bytes(int64_t nnz);
+
+/* total_rows = max over tables of row_base+vocab (bounds the sort key bits). */
+int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature* feats, int n_feats,
+                           const void* ids, int id_type,
+                           const void* offsets, int off_type,
+                           int batch, int64_t nnz, int64_t total_rows,
+                           void* workspace, size_t workspace_bytes,
+                           int* err_flag, void* stream);
+
+/* Dense parity form: grad_tables[t].weights is the [vocab, dim] fp32 gradient
+ * buffer of table t (krs_table array in device memory, same indexing and
+ * row_base as `tables`).  Rows that are touched are OVERWRITTEN with their sum;
+ * untouched rows are not written (caller zero-fills once). */
+int krs_embed_bag_bwd_dense(const krs_table* grad_tables, int n_tables,
+                            const krs_feature* feats, int n_feats,
+                            const float* weights, const float* bag_scale,
+                            const void* grad, int grad_dtype, int64_t grad_ld,
+                            int batch, int dim, int64_t nnz,
+                            const void* workspace, void* stream);
+
+/* Fused SGD on the touched rows of tables[t].weights (dtype table_dtype). */
+int krs_embed_bag_bwd_fused_sgd(const krs_table* tables, int n_tables,
+                                const krs_feature* feats, int n_feats,
+                                const float* weights, const float* bag_scale,
+                                const void* grad, int grad_dtype, int64_t grad_ld,
+                                int batch, int dim, int table_dtype, int64_t nnz,
+                                const void* workspace, void* stream);
+
+/* Fused Adagrad on the touched rows (tables[t].slot = fp32 accumulator). */
+int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_tables,
+                                    const krs_feature* feats, int n_feats,
+                                    const float* weights, const float* bag_scale,
+                                    const void* grad, int grad_dtype, int64_t grad_ld,
+                                    int batch, int dim, int table_dtype, int64_t nnz,
+                                    const void* workspace, void* stream);
+
+/* Sparse form: unique global rows and their summed gradients.
+ *   unique_rows [nnz] int64 (first *n_unique valid), row_grads [nnz, dim] fp32,
+ *   n_unique device int64. */
+int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats,
+                             const float* weights, const float* bag_scale,
+                             const void* grad, int grad_dtype, int64_t grad_ld,
+                             int batch, int dim, int64_t nnz,
+                             const void* workspace,
+                             int64_t* unique_rows, float* row_grads, int64_t* n_unique,
+                             void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * K3  FeatureCross (DCN-v2 cross layer)
+ *
+ * Replaces FeatureCross.call, feature_cross.py:182-194:
+ *   u = act(h @ kernel + bias)            keras Dense inside the layer (:134-151)
+ *   u = cast(u, compute dtype); u += diag_scale * x   (:189-192)
+ *   y = x0 * u + x                         (:194)
+ * with h = x (full rank) or h = x @ down_kernel (low rank, :185-187).
+ *
+ * krs_gemm: C[M,N] = epilogue(A[M,K] @ B), the MFMA kernel that owns the dense
+ * projection.  B is given K-contiguous ("B transposed", Bt[N,K]) when
+ * b_is_nk != 0, else as the keras kernel layout B[K,N].  Likewise a_is_km != 0
+ * means A is given as At[K,M] (the weight-gradient contractions over the
+ * batch).  Epilogue, applied on the fp32 accumulator v of element (m,n):
+ *      v += bias[n]                (bias != NULL)
+ *      v  = act(v)
+ *      v  = x0[m,n] * (v + diag_scale * x[m,n]) + x[m,n]   (x0 != NULL: cross)
+ *      v += beta * R[m,n]          (R != NULL: residual / gradient accumulate)
+ *   u_out (optional, cross form only) receives act(v)+diag_scale*x, the factor
+ *   the backward needs (dx0 = g * u).
+ * ------------------------------------------------------------------------- */
+typedef struct krs_gemm_epilogue {
+  const float* bias;  /* [N] fp32 or NULL */
+  int32_t act;        /* krs_activation */
+  float diag_scale;
+  const void* x0;     /* [M,N] (dtype of C) or NULL */
+  const void* x;      /* [M,N] (dtype of C), required when x0 != NULL */
+  int64_t ldx;        /* row stride of x0 and x */
+  void* u_out;        /* [M,N] (dtype of C) or NULL */
+  int64_t ldu;
+  const void* r;      /* [M,N] (dtype of C) or NULL */
+  int64_t ldr;
+  float beta;
+} krs_gemm_epilogue;
+
+int krs_gemm(const void* a, int64_t lda, int a_is_km,
+             const void* b, int64_t ldb, int b_is_nk,
+             void* c, int64_t ldc,
+             int64_t m, int64_t n, int64_t k,
+             int in_dtype, int out_dtype,
+             const krs_gemm_epilogue* epilogue,
+             void* workspace, size_t workspace_bytes, void* stream);
+size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
+
+/* Elementwise halves of FeatureCross for the host-composed path (arbitrary
+ * pre_activation callables) and for the backward:
+ *   fwd: y = x0 * (u + diag_scale*x) + x                     feature_cross.py:191-194
+ *   bwd: given g = dL/dy:  du = g * x0 ; dx0 (+)= g * (u+diag*x) ;
+ *        dxd = g + diag_scale * du   (the non-GEMM part of dL/dx)
+ *        dbias[n] = sum_m du[m,n]    (only valid when act is NONE; optional)
+ *   `u` here is the pre-diag factor act(h@K+b). */
+int krs_cross_epilogue_fwd(const void* u, const void* x0, const void* x, void* y,
+                           int64_t m, int64_t n, int64_t ld, float diag_scale,
+                           int dtype, void* stream);
+int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const void* x,
+                           void* du, void* dx0, int dx0_accumulate, void* dxd,
+                           float* dbias,
+                           int64_t m, int64_t n, int64_t ld, float diag_scale,
+                           int dtype, void* stream);
+
+/* Column sum: out[n] = sum_m a[m,n] (fp32 out).  Dense bias gradient. */
+int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
+               float* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * K4  DotInteraction
+ *
+ * Replaces DotInteraction.call, dot_interaction.py:170-203: stack F features
+ * [B,D] -> X[B,F,D]; P = X X^T; then either the row-major strictly/inclusive
+ * lower triangle gather (indices of :118-132) or the masked flatten (:96-116).
+ * feats: HOST array of F device pointers, feature f is [batch, dim] with row
+ * stride ld[f] (views into one concat buffer are fine).
+ *   out [batch, out_cols], out_cols = F*F (skip_gather) | F(F+1)/2 | F(F-1)/2
+ * Backward: dX[b,i,:] = sum_j (G[b,i,j] + G[b,j,i]) X[b,j,:], G = the gradient
+ * scattered back to [F,F] (zero above / on the masked part).
+ * ------------------------------------------------------------------------- */
+int krs_dot_interaction_fwd(const void* const* feats, const int64_t* ld, int n_feats,
+                            int64_t batch, int dim, int dtype,
+                            int self_interaction, int skip_gather,
+                            void* out, int64_t out_ld, void* stream);
+int krs_dot_interaction_bwd(const void* const* feats, const int64_t* ld, int n_feats,
+                            int64_t batch, int dim, int dtype,
+                            int self_interaction, int skip_gather,
+                            const void* grad_out, int64_t grad_ld,
+                            void* const* grad_feats, const int64_t* grad_feat_ld,
+                            void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * K5  MOD bucketise for row-sharded tables
+ *
+ * The reference shards rows MOD-N (sharding_strategy="MOD",
+ * jax/embedding_utils.py:194; layout tensorflow/distributed_embedding.py:316-328):
+ * global row r lives on shard r % n_shards at local row r / n_shards.
+ * Stable counting sort of the nnz ids by destination shard:
+ *   bucket_counts [n_shards] int64: ids per shard
+ *   local_ids     [nnz] int32/int64 (id_type): ids[perm[i]] / n_shards, grouped by shard
+ *   perm          [nnz] int32: source position of each bucketed id
+ * ------------------------------------------------------------------------- */
+size_t krs_mod_bucketize_workspace_bytes(int64_t nnz, int n_shards);
+int krs_mod_bucketize(const void* ids, int id_type, int64_t nnz, int n_shards,
+                      void* local_ids, int32_t* perm, int64_t* bucket_counts,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KRS_H_ */

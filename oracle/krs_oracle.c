@@ -1,0 +1,381 @@
+/*
+ * krs_oracle.c -- CPU restatement of the keras-rs hot path.  TEST INFRASTRUCTURE.
+ *
+ * This file is the parity oracle for libkrs_hip.so.  It is imported only by
+ * tests/, by __graft_entry__.smoke() and by bench.py's `cpu_baseline` leg, and
+ * only as the checker / the timed CPU baseline -- never by the product path
+ * (keras_rs_amd/ fails loudly when its HIP library is missing).
+ *
+ * Each function restates, in plain C on HOST pointers, the arithmetic of the
+ * reference statement(s) cited above it, with the same signature as its
+ * device twin in include/krs.h (the `stream` argument is ignored).
+ *
+ * Pinning: the reference (pure Python on Keras 3) cannot be imported in the
+ * build container (keras/jax/tensorflow are absent), so this oracle is pinned
+ * by the reference's own known-answer tests, transcribed as data in
+ * tests/golden/kat.json (see tests/golden/make_golden.py for file:line of each
+ * vector) and checked by tests/test_oracle_golden.py.  Beyond those KATs parity
+ * is "unpinned" in the sense of SURVEY.md section 8c.
+ *
+ * Build: make -C oracle   (gcc -O2 -fopenmp -shared -fPIC)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/krs.h"
+
+/* ---- bf16 <-> f32 (round to nearest even, NaN kept quiet) ---------------- */
+static inline float bf16_to_f32(uint16_t h) {
+  uint32_t u = ((uint32_t)h) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float ld(const void* p, int dtype, int64_t i) {
+  return dtype == KRS_BF16 ? bf16_to_f32(((const uint16_t*)p)[i]) : ((const float*)p)[i];
+}
+static inline void st(void* p, int dtype, int64_t i, float v) {
+  if (dtype == KRS_BF16)
+    ((uint16_t*)p)[i] = f32_to_bf16(v);
+  else
+    ((float*)p)[i] = v;
+}
+static inline int64_t ldi(const void* p, int itype, int64_t i) {
+  return itype == KRS_I64 ? ((const int64_t*)p)[i] : (int64_t)((const int32_t*)p)[i];
+}
+
+int krs_oracle_version(void) { return KRS_VERSION; }
+
+/* bag (f, b) -> [start, end) in ids */
+static inline void bag_range(const krs_feature* feats, int f, int64_t b, int batch,
+                             const void* offsets, int off_type, int64_t* s, int64_t* e) {
+  if (offsets) {
+    int64_t bag = (int64_t)f * batch + b;
+    *s = ldi(offsets, off_type, bag);
+    *e = ldi(offsets, off_type, bag + 1);
+  } else {
+    *s = feats[f].ids_base + b * (int64_t)feats[f].hot;
+    *e = *s + feats[f].hot;
+  }
+}
+
+/* divide_no_nan reciprocal form: 0 where the divisor is 0.
+ * keras ops.divide_no_nan as used at embed_reduce.py:267-274. */
+static inline float bag_scale_of(int combiner, float sw, float sw2) {
+  if (combiner == KRS_MEAN) return sw == 0.0f ? 0.0f : 1.0f / sw;
+  if (combiner == KRS_SQRTN) {
+    float d = sqrtf(sw2);
+    return d == 0.0f ? 0.0f : 1.0f / d;
+  }
+  return 1.0f;
+}
+
+/*
+ * K1.  EmbedReduce.call for every feature of a DistributedEmbedding:
+ *   gather      keras.layers.Embedding.call == ops.take(table, ids, axis=0)   embed_reduce.py:178
+ *   weights     ones when None                                                embed_reduce.py:224-231
+ *   x * w       embed_reduce.py:253
+ *   sum(axis=-2) and the mean / sqrtn divisors (divide_no_nan)                embed_reduce.py:261-274
+ *   per-feature loop                                     base_distributed_embedding.py:910-928
+ * The numpy restatement the reference tests use is
+ * keras_rs/src/layers/embedding/test_utils.py:245-267 (weights @ table[ids]).
+ * fp32 accumulation in ascending position, then one division.
+ */
+int krs_oracle_embed_bag_fwd(const krs_table* tables, const krs_feature* feats, int n_feats,
+                             const void* ids, int id_type, const void* offsets, int off_type,
+                             const float* weights, int batch, int dim, int table_dtype,
+                             void* out, int out_dtype, int64_t out_ld, float* bag_scale,
+                             int* err_flag, void* stream) {
+  (void)stream;
+  if (!tables || !feats || !out || n_feats < 0 || batch < 0 || dim <= 0) return KRS_ERR_INVALID;
+  int flags = 0;
+#pragma omp parallel for collapse(2) schedule(static) reduction(| : flags)
+  for (int f = 0; f < n_feats; ++f) {
+    for (int64_t b = 0; b < batch; ++b) {
+      const krs_table* tb = &tables[feats[f].table];
+      int64_t s, e;
+      bag_range(feats, f, b, batch, offsets, off_type, &s, &e);
+      float acc[dim];
+      for (int c = 0; c < dim; ++c) acc[c] = 0.0f;
+      float sw = 0.0f, sw2 = 0.0f;
+      for (int64_t p = s; p < e; ++p) {
+        float w = weights ? weights[p] : 1.0f;
+        sw += w;
+        sw2 = fmaf(w, w, sw2);
+        int64_t id = ldi(ids, id_type, p);
+        if (id < 0 || id >= tb->vocab) {
+          flags |= KRS_FLAG_ID_OUT_OF_RANGE;
+          continue;
+        }
+        for (int c = 0; c < dim; ++c)
+          acc[c] = fmaf(w, ld(tb->weights, table_dtype, id * dim + c), acc[c]);
+      }
+      int comb = feats[f].combiner;
+      float den = comb == KRS_MEAN ? sw : (comb == KRS_SQRTN ? sqrtf(sw2) : 1.0f);
+      for (int c = 0; c < dim; ++c) {
+        float v = acc[c];
+        if (comb != KRS_SUM) v = den == 0.0f ? 0.0f : v / den;
+        st(out, out_dtype, b * out_ld + feats[f].out_col + c, v);
+      }
+      if (bag_scale) bag_scale[(int64_t)f * batch + b] = bag_scale_of(comb, sw, sw2);
+    }
+  }
+  if (err_flag && flags) *err_flag |= flags;
+  return KRS_OK;
+}
+
+/*
+ * K2 (dense form).  Gradient of K1 w.r.t. the tables:
+ *   grad.at[cols].add(vals * activation_gradients[rows])   jax/test_utils.py:395-417
+ *   per-table accumulation over features sharing it          jax/test_utils.py:450-468
+ * with vals = w (sum), w/sum w (mean), w/sqrt(sum w^2) (sqrtn) -- the autodiff
+ * of embed_reduce.py:253-274.  Contributions are added in ascending position p
+ * (feature-major), fp32.  grad_tables[t].weights = dE_t [vocab, dim] fp32,
+ * accumulated INTO (caller zero-fills).
+ */
+int krs_oracle_embed_bag_bwd_dense(const krs_table* grad_tables, int n_tables,
+                                   const krs_feature* feats, int n_feats, const void* ids,
+                                   int id_type, const void* offsets, int off_type,
+                                   const float* weights, const float* bag_scale,
+                                   const void* grad, int grad_dtype, int64_t grad_ld, int batch,
+                                   int dim) {
+  (void)n_tables;
+  for (int f = 0; f < n_feats; ++f) {
+    const krs_table* tb = &grad_tables[feats[f].table];
+    float* de = (float*)tb->weights;
+    for (int64_t b = 0; b < batch; ++b) {
+      int64_t s, e;
+      bag_range(feats, f, b, batch, offsets, off_type, &s, &e);
+      float sc = bag_scale ? bag_scale[(int64_t)f * batch + b] : 1.0f;
+      for (int64_t p = s; p < e; ++p) {
+        int64_t id = ldi(ids, id_type, p);
+        if (id < 0 || id >= tb->vocab) continue;
+        float coef = (weights ? weights[p] : 1.0f) * sc;
+        for (int c = 0; c < dim; ++c)
+          de[id * dim + c] =
+              fmaf(coef, ld(grad, grad_dtype, b * grad_ld + feats[f].out_col + c), de[id * dim + c]);
+      }
+    }
+  }
+  return KRS_OK;
+}
+
+/*
+ * Per-table optimizer step on a dense gradient, jax/test_utils.py:474-497:
+ *   SGD      table - lr * grad
+ *   Adagrad  acc += grad*grad ; table - lr / sqrt(acc) * grad   (no epsilon)
+ * Only rows with touched[r] != 0 are updated (the fused device kernels touch
+ * only looked-up rows; for SGD an untouched row has grad 0 so the result is
+ * identical, for Adagrad acc stays and 0/sqrt(acc) = 0 as long as acc > 0).
+ * kind: 0 = SGD, 1 = Adagrad.
+ */
+int krs_oracle_apply_optimizer(void* table, int table_dtype, float* acc, const float* grad,
+                               const uint8_t* touched, int64_t vocab, int dim, float lr,
+                               int kind) {
+  for (int64_t r = 0; r < vocab; ++r) {
+    if (touched && !touched[r]) continue;
+    for (int c = 0; c < dim; ++c) {
+      int64_t i = r * dim + c;
+      float g = grad[i];
+      float t = ld(table, table_dtype, i);
+      if (kind == 1) {
+        float a = fmaf(g, g, acc[i]);
+        acc[i] = a;
+        t = t - lr * g / sqrtf(a);
+      } else {
+        t = t - lr * g;
+      }
+      st(table, table_dtype, i, t);
+    }
+  }
+  return KRS_OK;
+}
+
+static inline float act_apply(int act, float v) {
+  switch (act) {
+    case KRS_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case KRS_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case KRS_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+/*
+ * K3.  The dense contraction + fused epilogue of FeatureCross.call:
+ *   keras Dense: matmul(inputs, kernel) + bias, then activation  feature_cross.py:134-151,187
+ *   u += diag_scale * x                                           feature_cross.py:191-192
+ *   y = x0 * u + x                                                feature_cross.py:194
+ * fp32 accumulation over ascending k; inputs of dtype in_dtype, one rounding
+ * to out_dtype at the end (SURVEY.md section 8c bf16 policy).
+ */
+int krs_oracle_gemm(const void* a, int64_t lda, int a_is_km, const void* b, int64_t ldb,
+                    int b_is_nk, void* c, int64_t ldc, int64_t m, int64_t n, int64_t k,
+                    int in_dtype, int out_dtype, const krs_gemm_epilogue* ep) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < m; ++i) {
+    for (int64_t j = 0; j < n; ++j) {
+      float acc = 0.0f;
+      for (int64_t kk = 0; kk < k; ++kk) {
+        float av = a_is_km ? ld(a, in_dtype, kk * lda + i) : ld(a, in_dtype, i * lda + kk);
+        float bv = b_is_nk ? ld(b, in_dtype, j * ldb + kk) : ld(b, in_dtype, kk * ldb + j);
+        acc = fmaf(av, bv, acc);
+      }
+      float v = acc;
+      if (ep) {
+        if (ep->bias) v += ep->bias[j];
+        v = act_apply(ep->act, v);
+        if (ep->x0) {
+          float xv = ld(ep->x, out_dtype, i * ep->ldx + j);
+          float u = v + ep->diag_scale * xv;
+          if (ep->u_out) st(ep->u_out, out_dtype, i * ep->ldu + j, u);
+          v = ld(ep->x0, out_dtype, i * ep->ldx + j) * u + xv;
+        }
+        if (ep->r) v += ep->beta * ld(ep->r, out_dtype, i * ep->ldr + j);
+      }
+      st(c, out_dtype, i * ldc + j, v);
+    }
+  }
+  return KRS_OK;
+}
+
+/* y = x0 * (u + diag*x) + x   feature_cross.py:191-194 */
+int krs_oracle_cross_epilogue_fwd(const void* u, const void* x0, const void* x, void* y,
+                                  int64_t m, int64_t n, int64_t ldm, float diag_scale,
+                                  int dtype) {
+  for (int64_t i = 0; i < m; ++i)
+    for (int64_t j = 0; j < n; ++j) {
+      int64_t o = i * ldm + j;
+      float xv = ld(x, dtype, o);
+      st(y, dtype, o, ld(x0, dtype, o) * (ld(u, dtype, o) + diag_scale * xv) + xv);
+    }
+  return KRS_OK;
+}
+
+/* Autodiff of y = x0 * (u + diag*x) + x w.r.t. u, x0 and the direct x path. */
+int krs_oracle_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const void* x,
+                                  void* du, void* dx0, int dx0_accumulate, void* dxd,
+                                  float* dbias, int64_t m, int64_t n, int64_t ldm,
+                                  float diag_scale, int dtype) {
+  if (dbias)
+    for (int64_t j = 0; j < n; ++j) dbias[j] = 0.0f;
+  for (int64_t i = 0; i < m; ++i)
+    for (int64_t j = 0; j < n; ++j) {
+      int64_t o = i * ldm + j;
+      float gv = ld(g, dtype, o);
+      float duv = gv * ld(x0, dtype, o);
+      float uf = ld(u, dtype, o) + diag_scale * ld(x, dtype, o);
+      if (du) st(du, dtype, o, duv);
+      if (dx0) st(dx0, dtype, o, (dx0_accumulate ? ld(dx0, dtype, o) : 0.0f) + gv * uf);
+      if (dxd) st(dxd, dtype, o, gv + diag_scale * duv);
+      if (dbias) dbias[j] += duv;
+    }
+  return KRS_OK;
+}
+
+int krs_oracle_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype, float* out) {
+  for (int64_t j = 0; j < n; ++j) out[j] = 0.0f;
+  for (int64_t i = 0; i < m; ++i)
+    for (int64_t j = 0; j < n; ++j) out[j] += ld(a, dtype, i * lda + j);
+  return KRS_OK;
+}
+
+/* Column index of pair (i, j) in the output row, or -1 when (i, j) is not kept.
+ * Row-major lower-triangle order of dot_interaction.py:118-132; the masked
+ * flatten of :96-116 keeps position i*F+j. */
+static inline int64_t di_col(int i, int j, int F, int self_interaction, int skip_gather) {
+  int keep = self_interaction ? (j <= i) : (j < i);
+  if (skip_gather) return keep ? (int64_t)i * F + j : -2; /* -2: written as zero */
+  if (!keep) return -1;
+  return self_interaction ? (int64_t)i * (i + 1) / 2 + j : (int64_t)i * (i - 1) / 2 + j;
+}
+
+/*
+ * K4.  DotInteraction.call, dot_interaction.py:170-203:
+ *   features = stack(inputs, axis=1); P = matmul(features, features^T)
+ *   skip_gather: P * tril(ones, k) reshaped to [B, F*F];  else take(P.flat, tril indices)
+ */
+int krs_oracle_dot_interaction_fwd(const void* const* feats, const int64_t* ldf, int n_feats,
+                                   int64_t batch, int dim, int dtype, int self_interaction,
+                                   int skip_gather, void* out, int64_t out_ld) {
+  int F = n_feats;
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < batch; ++b)
+    for (int i = 0; i < F; ++i)
+      for (int j = 0; j < F; ++j) {
+        int64_t col = di_col(i, j, F, self_interaction, skip_gather);
+        if (col == -1) continue;
+        if (col == -2) {
+          st(out, dtype, b * out_ld + (int64_t)i * F + j, 0.0f);
+          continue;
+        }
+        float acc = 0.0f;
+        for (int c = 0; c < dim; ++c)
+          acc = fmaf(ld(feats[i], dtype, b * ldf[i] + c), ld(feats[j], dtype, b * ldf[j] + c), acc);
+        st(out, dtype, b * out_ld + col, acc);
+      }
+  return KRS_OK;
+}
+
+/* Autodiff of K4: dX[b,i,:] = sum_j (G[b,i,j] + G[b,j,i]) X[b,j,:]. */
+int krs_oracle_dot_interaction_bwd(const void* const* feats, const int64_t* ldf, int n_feats,
+                                   int64_t batch, int dim, int dtype, int self_interaction,
+                                   int skip_gather, const void* grad_out, int64_t grad_ld,
+                                   void* const* grad_feats, const int64_t* gld) {
+  int F = n_feats;
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < batch; ++b)
+    for (int i = 0; i < F; ++i)
+      for (int c = 0; c < dim; ++c) {
+        float acc = 0.0f;
+        for (int j = 0; j < F; ++j) {
+          int64_t cij = di_col(i, j, F, self_interaction, skip_gather);
+          int64_t cji = di_col(j, i, F, self_interaction, skip_gather);
+          float gs = 0.0f;
+          if (cij >= 0) gs += ld(grad_out, dtype, b * grad_ld + cij);
+          if (cji >= 0) gs += ld(grad_out, dtype, b * grad_ld + cji);
+          acc = fmaf(gs, ld(feats[j], dtype, b * ldf[j] + c), acc);
+        }
+        st(grad_feats[i], dtype, b * gld[i] + c, acc);
+      }
+  return KRS_OK;
+}
+
+/*
+ * K5.  MOD sharding (sharding_strategy="MOD", jax/embedding_utils.py:194;
+ * row r -> shard r % S, local row r / S, tensorflow/distributed_embedding.py:316-328).
+ * Stable counting sort by destination shard.
+ */
+int krs_oracle_mod_bucketize(const void* ids, int id_type, int64_t nnz, int n_shards,
+                             void* local_ids, int32_t* perm, int64_t* bucket_counts) {
+  if (n_shards <= 0) return KRS_ERR_INVALID;
+  int64_t* start = (int64_t*)calloc((size_t)n_shards + 1, sizeof(int64_t));
+  for (int s = 0; s < n_shards; ++s) bucket_counts[s] = 0;
+  for (int64_t p = 0; p < nnz; ++p) {
+    int64_t id = ldi(ids, id_type, p);
+    int64_t s = ((id % n_shards) + n_shards) % n_shards;
+    bucket_counts[s]++;
+  }
+  for (int s = 0; s < n_shards; ++s) start[s + 1] = start[s] + bucket_counts[s];
+  for (int64_t p = 0; p < nnz; ++p) {
+    int64_t id = ldi(ids, id_type, p);
+    int64_t s = ((id % n_shards) + n_shards) % n_shards;
+    int64_t q = start[s]++;
+    int64_t loc = (id - s) / n_shards;
+    if (id_type == KRS_I64)
+      ((int64_t*)local_ids)[q] = loc;
+    else
+      ((int32_t*)local_ids)[q] = (int32_t)loc;
+    perm[q] = (int32_t)p;
+  }
+  free(start);
+  return KRS_OK;
+}

@@ -1,0 +1,160 @@
+"""Pins the CPU oracle (oracle/) against the reference's own known-answer tests
+(tests/golden/kat.json, transcribed by tests/golden/make_golden.py)."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import krs_oracle as ko
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+TOL = dict(atol=1e-6, rtol=1e-6)  # keras_rs/src/testing/test_case.py:47-77
+
+
+@pytest.mark.parametrize("case", KAT["feature_cross"]["cases"], ids=lambda c: c["name"])
+def test_feature_cross_kat(case):
+    fc = KAT["feature_cross"]
+    x0 = np.array(fc["x0"], np.float32)
+    x = None if case["one_input"] else np.array(fc["x"], np.float32)
+    d, p = 3, case["projection_dim"]
+    down = None if p is None else np.ones((d, p), np.float32)
+    kernel = np.ones((d if p is None else p, d), np.float32)
+    bias = np.zeros(d, np.float32)
+    y = ko.feature_cross(x0, x, kernel, bias, down, case["diag_scale"])
+    np.testing.assert_allclose(y, np.array(case["expected"], np.float32), **TOL)
+
+
+def test_feature_cross_preactivation_zero_returns_x():
+    fc = KAT["feature_cross"]
+    x0 = np.array(fc["x0"], np.float32)
+    x = np.array(fc["x"], np.float32)
+    # pre_activation=zeros_like -> u == 0 -> y = x0*0 + x
+    y = ko.cross_epilogue_fwd(np.zeros_like(x), x0, x)
+    np.testing.assert_allclose(y, np.array(fc["pre_activation_zero"]["expected"], np.float32), **TOL)
+
+
+def test_feature_cross_shape_mismatch_raises():
+    a, b = KAT["feature_cross"]["errors"]["shape_mismatch"]
+    with pytest.raises(ValueError):
+        ko.feature_cross(np.ones(a, np.float32), np.ones(b, np.float32), np.ones((5, 5), np.float32))
+
+
+@pytest.mark.parametrize("case", KAT["dot_interaction"]["cases"],
+                         ids=lambda c: f"self{int(c['self_interaction'])}_skip{int(c['skip_gather'])}")
+def test_dot_interaction_kat(case):
+    feats = [np.array(f, np.float32) for f in KAT["dot_interaction"]["inputs"]]
+    out = ko.dot_interaction_fwd(feats, case["self_interaction"], case["skip_gather"])
+    np.testing.assert_allclose(out, np.array(case["expected"], np.float32), atol=1e-5, rtol=1e-6)
+
+
+@pytest.mark.parametrize("case", KAT["embed_reduce"]["cases"],
+                         ids=lambda c: f"{c['kind']}_{c['combiner']}_{'w' if c['weights'] else 'now'}")
+def test_embed_reduce_kat(case):
+    er = KAT["embed_reduce"]
+    rng = np.random.default_rng(1337)
+    e = rng.uniform(-0.05, 0.05, (er["input_dim"], er["output_dim"])).astype(np.float32)
+    w = None if case["weights"] is None else np.array(case["weights"], np.float32)
+    if case["kind"] == "bag":
+        out = ko.embed_reduce_csr(e, np.array(case["ids"], np.int32), np.array(case["offsets"], np.int32),
+                                  w, case["combiner"])
+    else:
+        out = ko.embed_reduce(e, np.array(case["ids"], np.int32), w, case["combiner"])
+    exp = np.stack([
+        sum(np.float64(c) * e[r].astype(np.float64) for r, c in terms) / div
+        for terms, div in zip(case["terms"], case["divisor"])
+    ])
+    assert out.shape == (2, er["output_dim"])
+    np.testing.assert_allclose(out, exp.astype(np.float32), **TOL)
+
+
+def test_embed_reduce_int64_ids_and_divide_no_nan():
+    e = np.arange(12, dtype=np.float32).reshape(4, 3)
+    out = ko.embed_reduce(e, np.array([[1, 2], [0, 3]], np.int64),
+                          np.array([[0.0, 0.0], [1.0, 1.0]], np.float32), "mean")
+    np.testing.assert_allclose(out[0], 0.0)  # divide_no_nan: 0 where sum(w) == 0
+    np.testing.assert_allclose(out[1], (e[0] + e[3]) / 2)
+
+
+def test_out_of_range_id_is_flagged_not_clamped():
+    e = np.ones((4, 3), np.float32)
+    with pytest.raises(IndexError):
+        ko.embed_reduce(e, np.array([[1, 4]], np.int32), None, "sum")
+    with pytest.raises(IndexError):
+        ko.embed_reduce(e, np.array([[-1, 2]], np.int32), None, "sum")
+
+
+def test_lookup_grad_matches_scatter_add_formula():
+    # jax/test_utils.py:395-417: grad.at[cols].add(vals * activation_gradients[rows])
+    rng = np.random.default_rng(0)
+    V, D, B, L = 17, 8, 16, 5
+    ids = rng.integers(0, V, (B, L)).astype(np.int32)
+    w = rng.uniform(0, 1, (B, L)).astype(np.float32)
+    g = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    for comb in ("sum", "mean", "sqrtn"):
+        tables = ko.make_tables([np.zeros((V, D), np.float32)])
+        feats = ko.make_features([0], [comb], [0], hots=[L], batch=B)
+        out = np.zeros((B, D), np.float32)
+        scale = np.zeros(B, np.float32)
+        ko.embed_bag_fwd_raw(tables, ko.F32, feats, ids.reshape(-1), None, w.reshape(-1), B, D, out, scale)
+        de = np.zeros((V, D), np.float32)
+        ko.embed_bag_bwd_dense(ko.make_tables([de]), feats, ids.reshape(-1), None, w.reshape(-1),
+                               scale, g, B, D)
+        norm = {"sum": np.ones(B), "mean": w.sum(1), "sqrtn": np.sqrt((w * w).sum(1))}[comb]
+        exp = np.zeros((V, D), np.float64)
+        np.add.at(exp, ids.reshape(-1), ((w / norm[:, None])[:, :, None] * g[:, None, :]).reshape(-1, D))
+        np.testing.assert_allclose(de, exp, atol=1e-5, rtol=1e-5)
+
+
+def test_optimizer_kat():
+    o = KAT["optimizers"]
+    t = np.array([o["sgd"]["table"]], np.float32).T.copy()
+    ko.apply_optimizer(t, None, np.array([o["sgd"]["grad"]], np.float32).T.copy(), None, o["sgd"]["lr"], "sgd")
+    np.testing.assert_allclose(t[:, 0], o["sgd"]["expected"], **TOL)
+    a = o["adagrad"]
+    t = np.array([a["table"]], np.float32).T.copy()
+    acc = np.array([a["acc"]], np.float32).T.copy()
+    ko.apply_optimizer(t, acc, np.array([a["grad"]], np.float32).T.copy(), None, a["lr"], "adagrad")
+    np.testing.assert_allclose(acc[:, 0], a["expected_acc"], **TOL)
+    np.testing.assert_allclose(t[:, 0], a["expected"], **TOL)
+
+
+def test_mod_bucketize_kat():
+    m = KAT["mod_sharding"]
+    ids = np.array(m["ids"], np.int32)
+    local, perm, counts = ko.mod_bucketize(ids, m["n_shards"])
+    shard = np.array(m["shard"])
+    # stable grouping by shard, local row = id // n_shards
+    order = np.argsort(shard, kind="stable")
+    np.testing.assert_array_equal(perm, order)
+    np.testing.assert_array_equal(local, np.array(m["local_row"])[order])
+    np.testing.assert_array_equal(counts, np.bincount(shard, minlength=m["n_shards"]))
+
+
+def test_dot_interaction_bwd_matches_finite_difference():
+    rng = np.random.default_rng(3)
+    F, B, D = 4, 3, 5
+    feats = [rng.standard_normal((B, D)).astype(np.float32) for _ in range(F)]
+    for si in (False, True):
+        for sg in (False, True):
+            cols = ko.dot_interaction_out_cols(F, si, sg)
+            g = rng.standard_normal((B, cols)).astype(np.float32)
+            grads = ko.dot_interaction_bwd(feats, g, si, sg)
+            eps = 1e-2
+            f0 = [f.copy() for f in feats]
+            f0[1][2, 3] += eps
+            up = (ko.dot_interaction_fwd(f0, si, sg).astype(np.float64) * g).sum()
+            f0[1][2, 3] -= 2 * eps
+            dn = (ko.dot_interaction_fwd(f0, si, sg).astype(np.float64) * g).sum()
+            assert abs((up - dn) / (2 * eps) - grads[1][2, 3]) < 2e-2
+
+
+def test_bf16_round_trip_helpers():
+    a = np.array([1.0, 1.00390625, -3.140625, 65504.0], np.float32)
+    bits = ko.f32_to_bf16_bits(a)
+    back = ko.bf16_bits_to_f32(bits)
+    assert np.all(np.abs(back - a) <= np.abs(a) * 2 ** -8)
+    e = ko.f32_to_bf16_bits(np.linspace(-1, 1, 40, dtype=np.float32).reshape(10, 4))
+    out = ko.embed_reduce(e, np.array([3, 7], np.int32), None, "sum")
+    np.testing.assert_array_equal(out, e[[3, 7]])  # gather of bf16 rows is bit-exact
