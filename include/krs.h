@@ -108,13 +108,14 @@ const char* krs_last_error(void);
  * offsets  CSR mode: [n_feats*batch + 1] (int32/int64) bag boundaries into ids;
  *          NULL = dense mode (krs_feature.ids_base / hot describe the bags)
  * weights  [nnz] fp32 per-id weights or NULL (= all ones)
+ * nnz      number of ids (CSR: offsets[last]); also sizes the work split
  * bag_scale optional [n_feats*batch] fp32: receives scale(f,b) for the backward
  * err_flag optional device int, OR'ed with KRS_FLAG_* bits
  * ------------------------------------------------------------------------- */
 int krs_embed_bag_fwd(const krs_table* tables, const krs_feature* feats, int n_feats,
                       const void* ids, int id_type,
                       const void* offsets, int off_type,
-                      const float* weights,
+                      const float* weights, int64_t nnz,
                       int batch, int dim, int table_dtype,
                       void* out, int out_dtype, int64_t out_ld,
                       float* bag_scale, int* err_flag, void* stream);

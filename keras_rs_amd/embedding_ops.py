@@ -1,0 +1,114 @@
+"""Host side of K1/K2: descriptor management and the fused embedding-bag calls.
+
+`FusedBags` owns the device-resident krs_table / krs_feature descriptor arrays
+for one group of same-width tables and launches
+
+    krs_embed_bag_fwd            forward  (one launch for all features)
+    krs_embed_bag_bwd_plan       sort of the lookups by row
+    krs_embed_bag_bwd_{dense,fused_sgd,fused_adagrad}
+
+through the C ABI.  It is the counterpart of the per-feature python loop at
+keras_rs/src/layers/embedding/base_distributed_embedding.py:910-928.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from keras_rs_amd import _lib as L
+
+
+class FusedBags:
+    """Descriptors for `tables` (list of [V, D] tensors of one dtype and width) and
+    `features` = [(table_index, combiner, out_col)], bags numbered feature-major."""
+
+    def __init__(self, tables: Sequence[torch.Tensor], features: Sequence[tuple],
+                 slots: Sequence[torch.Tensor | None] | None = None,
+                 lrs: Sequence[float] | None = None):
+        assert len(tables) > 0
+        self.tables = list(tables)
+        self.slots = list(slots) if slots is not None else [None] * len(tables)
+        self.lrs = list(lrs) if lrs is not None else [0.0] * len(tables)
+        self.features = [(int(t), L.COMBINERS[c] if isinstance(c, str) else int(c), int(col))
+                         for t, c, col in features]
+        self.dim = int(tables[0].shape[1])
+        self.dtype = tables[0].dtype
+        for t in tables:
+            if t.dim() != 2 or t.shape[1] != self.dim or t.dtype != self.dtype:
+                raise L.KrsError("FusedBags: tables must share embedding_dim and dtype")
+        self.row_bases = np.concatenate([[0], np.cumsum([t.shape[0] for t in tables])]).astype(np.int64)
+        self.total_rows = int(self.row_bases[-1])
+        self._tab_key = None
+        self._tab_dev = None
+        self._feat_cache: dict = {}
+
+    # ---- descriptors ------------------------------------------------------
+    def table_desc(self, weights=None, slots=None) -> torch.Tensor:
+        """krs_table array on the device (rebuilt when a storage pointer moved)."""
+        weights = self.tables if weights is None else weights
+        slots = self.slots if slots is None else slots
+        key = tuple(w.data_ptr() for w in weights) + tuple(0 if s is None else s.data_ptr() for s in slots) \
+            + tuple(self.lrs)
+        cacheable = weights is self.tables
+        if cacheable and key == self._tab_key:
+            return self._tab_dev
+        arr = np.zeros(len(weights), dtype=L.TABLE_DT)
+        for i, w in enumerate(weights):
+            L.require_device(w, "embedding table")
+            if not w.is_contiguous():
+                raise L.KrsError("embedding tables must be contiguous")
+            arr[i] = (w.data_ptr(), 0 if slots[i] is None else slots[i].data_ptr(),
+                      self.row_bases[i], w.shape[0], self.lrs[i])
+        dev = L.struct_to_device(arr, weights[0].device)
+        if cacheable:
+            self._tab_key, self._tab_dev = key, dev
+        return dev
+
+    def feature_desc(self, batch: int, hots: Sequence[int] | None, device) -> torch.Tensor:
+        key = (batch, None if hots is None else tuple(hots), str(device))
+        dev = self._feat_cache.get(key)
+        if dev is None:
+            arr = np.zeros(len(self.features), dtype=L.FEATURE_DT)
+            base = 0
+            for i, (t, comb, col) in enumerate(self.features):
+                hot = 0 if hots is None else int(hots[i])
+                arr[i] = (base, t, hot, comb, col)
+                base += batch * hot
+            dev = L.struct_to_device(arr, device)
+            self._feat_cache[key] = dev
+        return dev
+
+    # ---- K1 ---------------------------------------------------------------
+    def forward(self, ids: torch.Tensor, batch: int, hots: Sequence[int] | None = None,
+                offsets: torch.Tensor | None = None, weights: torch.Tensor | None = None,
+                out: torch.Tensor | None = None, out_dtype: torch.dtype | None = None,
+                want_scale: bool = False, err_flag: torch.Tensor | None = None):
+        """ids: flat [nnz] int32/int64 (feature-major).  Dense mode: hots[f] ids per bag of
+        feature f; CSR mode: offsets [n_feats*batch+1].  Returns (out [batch, ld], bag_scale|None)."""
+        L.require_device(ids, "ids")
+        n_feats = len(self.features)
+        dev = ids.device
+        if (hots is None) == (offsets is None):
+            raise L.KrsError("FusedBags.forward: give exactly one of hots (dense) / offsets (CSR)")
+        if out is None:
+            ld = max(col for _, _, col in self.features) + self.dim
+            out = torch.empty((batch, ld), dtype=out_dtype or self.dtype, device=dev)
+        if out.stride(-1) != 1:
+            raise L.KrsError("out must be row-major")
+        scale = torch.empty(n_feats * batch, dtype=torch.float32, device=dev) if want_scale else None
+        if weights is not None and weights.dtype != torch.float32:
+            weights = weights.float()
+        rc = L.lib().krs_embed_bag_fwd(
+            L.ptr(self.table_desc()), L.ptr(self.feature_desc(batch, hots, dev)), C.c_int(n_feats),
+            L.ptr(ids), C.c_int(L.itype(ids)),
+            L.ptr(offsets), C.c_int(L.itype(offsets) if offsets is not None else L.I32),
+            L.ptr(weights), C.c_int64(ids.numel()), C.c_int(batch), C.c_int(self.dim),
+            C.c_int(L.fdtype(self.tables[0])),
+            L.ptr(out), C.c_int(L.fdtype(out)), C.c_int64(out.stride(0)),
+            L.ptr(scale), L.ptr(err_flag), L.stream_ptr())
+        L.check(rc, "krs_embed_bag_fwd")
+        return out, scale

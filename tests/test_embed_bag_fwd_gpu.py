@@ -1,0 +1,105 @@
+"""K1 parity: krs_embed_bag_fwd (HIP, through the C ABI) vs the CPU oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import make_bags, oracle_embed_fwd, to_f32, to_np
+
+pytestmark = pytest.mark.gpu
+
+TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+NP_DT = {"f32": np.float32, "bf16": np.uint16}
+
+
+def _run_case(dim, tdt, odt, csr, use_w, combiners, n_tables=3, batch=37, max_hot=5, seed=0,
+              id_dtype=np.int32, extra_cols=0, shared=False):
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    vocabs_t = [int(v) for v in rng.integers(5, 90, size=n_tables)]
+    tables = [torch.from_numpy(rng.uniform(-1, 1, (v, dim)).astype(np.float32)).to(TORCH_DT[tdt]).to(dev)
+              for v in vocabs_t]
+    # features: one per table (+ one extra on table 0 when `shared`)
+    tix = list(range(n_tables)) + ([0] if shared else [])
+    n_feats = len(tix)
+    specs = [(tix[f], combiners[f % len(combiners)], extra_cols + f * dim) for f in range(n_feats)]
+    out_cols = extra_cols + n_feats * dim + extra_cols
+    bags = make_bags(rng, n_feats, batch, [vocabs_t[t] for t in tix], max_hot, csr, id_dtype=id_dtype)
+
+    fb = FusedBags(tables, specs)
+    out = torch.full((batch, out_cols), 7.0, dtype=TORCH_DT[odt], device=dev)
+    ids = torch.from_numpy(bags["ids"]).to(dev)
+    offs = None if bags["offsets"] is None else torch.from_numpy(bags["offsets"]).to(dev)
+    w = torch.from_numpy(bags["weights"]).to(dev) if use_w else None
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _, scale = fb.forward(ids, batch, hots=bags["hots"], offsets=offs, weights=w, out=out,
+                          want_scale=True, err_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+
+    exp, exp_scale, _ = oracle_embed_fwd([to_np(t) for t in tables], specs, bags, batch, dim, out_cols,
+                                         NP_DT[odt], use_w)
+    got = to_np(out)
+    lo, hi = extra_cols, extra_cols + n_feats * dim
+    if odt == "bf16":
+        # fp32 accumulate in the same order, one rounding: allow 1 bf16 ulp for a/den vs FMA contraction
+        np.testing.assert_allclose(to_f32(got[:, lo:hi]), to_f32(exp[:, lo:hi]), rtol=2 ** -7, atol=1e-6)
+    else:
+        np.testing.assert_allclose(got[:, lo:hi], exp[:, lo:hi], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(scale.cpu().numpy(), exp_scale, rtol=1e-6, atol=0)
+    # columns outside the features' slots are untouched
+    if extra_cols:
+        assert np.all(to_f32(got[:, :lo]) == 7.0) and np.all(to_f32(got[:, hi:]) == 7.0)
+
+
+@pytest.mark.parametrize("dim", [4, 6, 7, 20, 32, 64, 96, 128, 256, 320])
+@pytest.mark.parametrize("tdt,odt", [("f32", "f32"), ("bf16", "bf16"), ("bf16", "f32"), ("f32", "bf16")])
+def test_dims_dtypes_dense(dim, tdt, odt):
+    _run_case(dim, tdt, odt, csr=False, use_w=True, combiners=["sum", "mean", "sqrtn"])
+
+
+@pytest.mark.parametrize("dim", [6, 64, 128])
+@pytest.mark.parametrize("use_w", [False, True])
+@pytest.mark.parametrize("comb", ["sum", "mean", "sqrtn"])
+def test_csr_with_empty_bags(dim, use_w, comb):
+    _run_case(dim, "f32", "f32", csr=True, use_w=use_w, combiners=[comb], batch=53, max_hot=9)
+
+
+def test_int64_ids_and_shared_table_and_padded_output():
+    _run_case(128, "bf16", "bf16", csr=False, use_w=False, combiners=["sum"], id_dtype=np.int64,
+              extra_cols=8, shared=True)
+    _run_case(64, "f32", "f32", csr=True, use_w=True, combiners=["mean"], id_dtype=np.int64,
+              extra_cols=4, shared=True)
+
+
+def test_long_bags_and_batch_not_multiple_of_wave():
+    _run_case(128, "bf16", "bf16", csr=False, use_w=True, combiners=["sum", "mean"], batch=131, max_hot=100)
+    _run_case(128, "f32", "f32", csr=True, use_w=False, combiners=["sqrtn"], batch=3, max_hot=70)
+
+
+def test_gather_is_bit_exact_for_hot1_sum():
+    """hot=1 / sum / no weights is a pure row gather: output rows == table rows, bit for bit."""
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    for dt in (torch.float32, torch.bfloat16):
+        tab = torch.randn(1000, 128, generator=g).to(dt).to(dev)
+        ids = torch.randint(0, 1000, (4096,), generator=g, dtype=torch.int32).to(dev)
+        out, _ = FusedBags([tab], [(0, "sum", 0)]).forward(ids, 4096, hots=[1])
+        assert torch.equal(out, tab[ids.long()])
+
+
+def test_out_of_range_ids_raise_flag_and_contribute_nothing():
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    dev = torch.device("cuda:0")
+    tab = torch.ones(10, 64, device=dev)
+    ids = torch.tensor([[1, 10], [-1, 2], [3, 4]], dtype=torch.int32, device=dev).reshape(-1)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    out, _ = FusedBags([tab], [(0, "sum", 0)]).forward(ids, 3, hots=[2], err_flag=flag)
+    assert int(flag.item()) & L.FLAG_ID_OUT_OF_RANGE
+    assert torch.equal(out[:, 0].cpu(), torch.tensor([1.0, 1.0, 2.0]))
