@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkrs_hip.so")
+LIB_PATH = os.environ.get("KRS_LIB", os.path.join(_HERE, "libkrs_hip.so"))
 
 F32, BF16 = 0, 1
 I32, I64 = 0, 1
@@ -89,9 +89,9 @@ def lib() -> C.CDLL:
             )
         _lib = C.CDLL(LIB_PATH)
         _lib.krs_last_error.restype = C.c_char_p
-        _lib.krs_embed_bag_bwd_workspace_bytes.restype = C.c_size_t
-        _lib.krs_gemm_workspace_bytes.restype = C.c_size_t
-        _lib.krs_mod_bucketize_workspace_bytes.restype = C.c_size_t
+        for name in ("krs_embed_bag_bwd_workspace_bytes", "krs_gemm_workspace_bytes",
+                     "krs_mod_bucketize_workspace_bytes"):
+            getattr(_lib, name).restype = C.c_size_t
     return _lib
 
 

@@ -1,0 +1,546 @@
+// K2 -- index-scatter gradient of the fused embedding bag (backward of K1).
+//
+// Replaces the autodiff of ops.take/multiply/sum (the dense [V, D] scatter-add
+// restated by the reference at keras_rs/src/layers/embedding/jax/test_utils.py:395-417,
+// summed per table over the features that share it, :450-468) and, in the fused
+// forms, the per-table optimizer step of jax/test_utils.py:474-497.
+//
+// Plan (once per batch of ids, independent of the gradient values):
+//   keys[p] = tables[t(f)].row_base + ids[p]   (u32; invalid ids -> 0xffffffff)
+//   vals[p] = (bag(p) << 32) | p               (u64)
+//   stable LSD radix sort of (keys, vals) over ceil(log2(total_rows)) bits
+//   (rocPRIM device radix sort, compiled into this library).
+// Apply: the sorted stream is cut into fixed chunks of positions; a group of
+//   LPR lanes (one 16-byte piece of the gradient row per lane, as in K1) walks
+//   the segments that START in its chunk as one flat stream with four gradient
+//   rows in flight, and on every key change writes the finished row once:
+//   no atomics, one owner per row, contributions summed in ascending p
+//   => run-to-run bit-identical.  The row write is the dense gradient row, or
+//   the SGD / Adagrad update of the table row in place.
+// Algorithmic bytes: bags*D*s_g + nnz*(4+8) + U*(2*D*s_t [+ 2*D*4 Adagrad]).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "krs_common.h"
+
+namespace krs {
+namespace {
+
+constexpr uint32_t kInvalidKey = 0xffffffffu;
+
+struct PlanLayout {
+  uint32_t* keys_in;
+  uint32_t* keys_sorted;
+  uint64_t* vals_in;
+  uint64_t* vals_sorted;
+  uint32_t* head_flag;   // sparse form only
+  uint32_t* head_index;  // sparse form only
+  void* temp;
+  size_t temp_bytes;
+  size_t total_bytes;
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t sort_temp_bytes(int64_t nnz) {
+  size_t bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                           (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)nnz, 0u, 32u,
+                                           (hipStream_t)0);
+  size_t sbytes = 0;
+  hipError_t e2 = rocprim::exclusive_scan(nullptr, sbytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
+                                          (size_t)nnz, rocprim::plus<uint32_t>(), (hipStream_t)0);
+  if (e != hipSuccess || bytes == 0) bytes = (size_t)nnz * 16 + (1 << 20);  // no device visible: upper bound
+  if (e2 != hipSuccess || sbytes == 0) sbytes = (size_t)nnz * 4 + (1 << 20);
+  return align_up(bytes > sbytes ? bytes : sbytes, 256);
+}
+
+PlanLayout plan_layout(void* ws, int64_t nnz, bool need_temp = false) {
+  PlanLayout l;
+  char* p = reinterpret_cast<char*>(ws);
+  size_t o = 0;
+  const size_t n = (size_t)(nnz > 0 ? nnz : 1);
+  l.keys_in = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
+  l.keys_sorted = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
+  l.vals_in = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8, 256);
+  l.vals_sorted = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8, 256);
+  l.head_flag = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
+  l.head_index = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
+  l.temp = p + o;
+  l.temp_bytes = need_temp ? sort_temp_bytes(nnz) : 0;
+  l.total_bytes = o + l.temp_bytes;
+  return l;
+}
+
+// ---- plan: key generation ---------------------------------------------------
+struct KeyParams {
+  const krs_table* tables;
+  const krs_feature* feats;
+  int n_feats;
+  const void* ids;
+  int id64;
+  const void* offsets;
+  int off64;
+  int batch;
+  uint32_t* keys;
+  uint64_t* vals;
+  int* err_flag;
+};
+
+// 16 lanes per bag; lanes stride over the bag's positions (coalesced writes).
+__global__ __launch_bounds__(256) void bag_keys_kernel(const KeyParams p) {
+  const int64_t bag = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15;
+  if (bag >= (int64_t)p.n_feats * p.batch) return;
+  const int f = (int)(bag / p.batch);
+  const int b = (int)(bag - (int64_t)f * p.batch);
+  const krs_feature ft = p.feats[f];
+  const krs_table tb = p.tables[ft.table];
+  int64_t s, e;
+  if (p.offsets) {
+    s = ld_index(p.offsets, p.off64, bag);
+    e = ld_index(p.offsets, p.off64, bag + 1);
+  } else {
+    s = ft.ids_base + (int64_t)b * ft.hot;
+    e = s + ft.hot;
+  }
+  int oob = 0;
+  for (int64_t q = s + sub; q < e; q += 16) {
+    const int64_t id = ld_index(p.ids, p.id64, q);
+    uint32_t key = kInvalidKey;
+    if (id >= 0 && id < tb.vocab)
+      key = (uint32_t)(tb.row_base + id);
+    else
+      oob = 1;
+    p.keys[q] = key;
+    p.vals[q] = ((uint64_t)bag << 32) | (uint64_t)(uint32_t)q;
+  }
+  if (oob && p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
+}
+
+// ---- apply ------------------------------------------------------------------
+enum ApplyMode { kDense = 0, kSgd = 1, kAdagrad = 2, kSparse = 3 };
+
+struct ApplyParams {
+  const krs_table* tables;  // dense: gradient buffers; fused: the tables themselves
+  int n_tables;
+  const krs_feature* feats;
+  const float* weights;
+  const float* bag_scale;
+  const void* grad;
+  int64_t grad_ld;
+  int batch;
+  int dim;
+  int64_t nnz;
+  const uint32_t* keys;
+  const uint64_t* vals;
+  const uint32_t* head_index;  // sparse
+  int64_t* unique_rows;        // sparse
+  float* row_grads;            // sparse
+  int chunk;                   // sorted positions per group
+};
+
+template <typename T>
+struct Piece;  // 16 bytes of gradient elements
+template <>
+struct Piece<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(const uint4& r, float (&f)[4]) {
+    f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y);
+    f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+  }
+};
+template <>
+struct Piece<uint16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void unpack(const uint4& r, float (&f)[8]) {
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+};
+
+template <typename TT, int N>
+__device__ __forceinline__ void load_elems(const TT* src, float (&f)[N]) {
+  if constexpr (sizeof(TT) == 4) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = src[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = bf16_to_f32(src[i]);
+  }
+}
+template <typename TT, int N>
+__device__ __forceinline__ void store_elems(TT* dst, const float (&f)[N]) {
+  if constexpr (sizeof(TT) == 4) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) dst[i] = f[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) dst[i] = f32_to_bf16(f[i]);
+  }
+}
+
+// table index of a global row: tables are few and row_base ascending
+__device__ __forceinline__ int find_table(const krs_table* tables, int n_tables, int64_t row) {
+  int lo = 0, hi = n_tables - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tables[mid].row_base <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+constexpr int kApplyUnroll = 4;
+
+// GT: gradient element, TT: table element (fused modes), LPR lanes per row.
+template <typename GT, typename TT, int LPR, int MODE, bool HAS_W>
+__global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
+  constexpr int N = Piece<GT>::N;
+  const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int sub = threadIdx.x % LPR;
+  const int row_pieces = (int)(((int64_t)p.dim * sizeof(GT)) >> 4);
+  const int64_t i0 = group * p.chunk;
+  if (i0 >= p.nnz || sub >= row_pieces) return;
+  const int64_t i1 = min(i0 + (int64_t)p.chunk, p.nnz);
+
+  // segments that started before this chunk belong to an earlier group
+  int64_t i = i0;
+  if (i > 0) {
+    const uint32_t prev = p.keys[i - 1];
+    while (i < i1 && p.keys[i] == prev) ++i;
+    if (i == i1) return;
+  }
+  uint32_t cur = p.keys[i];
+  if (cur == kInvalidKey) return;  // invalid keys sort last: nothing more to do
+
+  const GT* grad = reinterpret_cast<const GT*>(p.grad) + sub * N;
+  const bool g_aligned =
+      ((reinterpret_cast<uintptr_t>(grad) | (uintptr_t)(p.grad_ld * sizeof(GT))) & 15) == 0;
+
+  float acc[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) acc[k] = 0.0f;
+  int64_t seg_start = i;
+
+  auto finish = [&](uint32_t key) {
+    if constexpr (MODE == kSparse) {
+      const uint32_t u = p.head_index[seg_start];
+      if (sub == 0) p.unique_rows[u] = (int64_t)key;
+      float* dst = p.row_grads + (int64_t)u * p.dim + sub * N;
+#pragma unroll
+      for (int k = 0; k < N; ++k) dst[k] = acc[k];
+    } else {
+      const int t = find_table(p.tables, p.n_tables, (int64_t)key);
+      const krs_table tb = p.tables[t];
+      const int64_t off = ((int64_t)key - tb.row_base) * p.dim + sub * N;
+      if constexpr (MODE == kDense) {
+        float* dst = reinterpret_cast<float*>(tb.weights) + off;
+#pragma unroll
+        for (int k = 0; k < N; ++k) dst[k] = acc[k];
+      } else {
+        TT* w = reinterpret_cast<TT*>(tb.weights) + off;
+        float wv[N];
+        load_elems<TT, N>(w, wv);
+        if constexpr (MODE == kSgd) {
+#pragma unroll
+          for (int k = 0; k < N; ++k) wv[k] = wv[k] - tb.lr * acc[k];
+        } else {
+          float* a = tb.slot + off;
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            const float av = fmaf(acc[k], acc[k], a[k]);
+            a[k] = av;
+            wv[k] = wv[k] - tb.lr * acc[k] / sqrtf(av);
+          }
+        }
+        store_elems<TT, N>(w, wv);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = 0.0f;
+  };
+
+  // flat stream over sorted positions; runs past i1 only to finish the last segment
+  bool done = false;
+  while (!done) {
+    uint32_t kk[kApplyUnroll];
+    uint4 raw[kApplyUnroll];
+    float coef[kApplyUnroll];
+#pragma unroll
+    for (int u = 0; u < kApplyUnroll; ++u) {
+      const int64_t j = i + u;
+      kk[u] = j < p.nnz ? p.keys[j] : kInvalidKey;
+      raw[u] = make_uint4(0, 0, 0, 0);
+      coef[u] = 0.0f;
+      if (kk[u] != kInvalidKey) {
+        const uint64_t v = p.vals[j];
+        const uint32_t bag = (uint32_t)(v >> 32);
+        const uint32_t pos = (uint32_t)v;
+        const int f = (int)(bag / (uint32_t)p.batch);
+        const int b = (int)(bag - (uint32_t)f * (uint32_t)p.batch);
+        float c = 1.0f;
+        if constexpr (HAS_W) c = p.weights[pos];
+        if (p.bag_scale) c *= p.bag_scale[bag];
+        coef[u] = c;
+        const GT* src = grad + (int64_t)b * p.grad_ld + p.feats[f].out_col;
+        if (g_aligned) {
+          raw[u] = *reinterpret_cast<const uint4*>(src);
+        } else {
+          float tmp[N];
+          load_elems<GT, N>(src, tmp);
+          if constexpr (sizeof(GT) == 4) {
+            raw[u] = make_uint4(__float_as_uint(tmp[0]), __float_as_uint(tmp[1]), __float_as_uint(tmp[2]),
+                                __float_as_uint(tmp[3]));
+          } else {
+            raw[u] = make_uint4(src[0] | ((uint32_t)src[1] << 16), src[2] | ((uint32_t)src[3] << 16),
+                                src[4] | ((uint32_t)src[5] << 16), src[6] | ((uint32_t)src[7] << 16));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kApplyUnroll; ++u) {
+      if (done) break;
+      const int64_t j = i + u;
+      if (kk[u] != cur) {
+        finish(cur);
+        // a new segment may only start inside this group's chunk
+        if (j >= i1 || kk[u] == kInvalidKey) {
+          done = true;
+          break;
+        }
+        cur = kk[u];
+        seg_start = j;
+      }
+      float gv[N];
+      Piece<GT>::unpack(raw[u], gv);
+#pragma unroll
+      for (int k = 0; k < N; ++k) acc[k] = fmaf(coef[u], gv[k], acc[k]);
+    }
+    i += kApplyUnroll;
+  }
+}
+
+// Any dim / dtype: LPR lanes per segment head, one column per lane per pass.
+template <int MODE>
+__global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, int grad_dtype, int table_dtype,
+                                                         int lpr) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
+  const int sub = threadIdx.x % lpr;
+  if (i >= p.nnz) return;
+  const uint32_t key = p.keys[i];
+  if (key == kInvalidKey || (i > 0 && p.keys[i - 1] == key)) return;
+  const int t = MODE == kSparse ? 0 : find_table(p.tables, p.n_tables, (int64_t)key);
+  for (int c = sub; c < p.dim; c += lpr) {
+    float acc = 0.0f;
+    for (int64_t j = i; j < p.nnz && p.keys[j] == key; ++j) {
+      const uint64_t v = p.vals[j];
+      const uint32_t bag = (uint32_t)(v >> 32);
+      const int f = (int)(bag / (uint32_t)p.batch);
+      const int b = (int)(bag - (uint32_t)f * (uint32_t)p.batch);
+      float coef = p.weights ? p.weights[(uint32_t)v] : 1.0f;
+      if (p.bag_scale) coef *= p.bag_scale[bag];
+      acc = fmaf(coef, ld_elem(p.grad, grad_dtype, (int64_t)b * p.grad_ld + p.feats[f].out_col + c), acc);
+    }
+    if (MODE == kSparse) {
+      const uint32_t u = p.head_index[i];
+      if (c == 0) p.unique_rows[u] = (int64_t)key;
+      p.row_grads[(int64_t)u * p.dim + c] = acc;
+    } else {
+      const krs_table tb = p.tables[t];
+      const int64_t off = ((int64_t)key - tb.row_base) * p.dim + c;
+      if (MODE == kDense) {
+        reinterpret_cast<float*>(tb.weights)[off] = acc;
+      } else {
+        float w = ld_elem(tb.weights, table_dtype, off);
+        if (MODE == kSgd) {
+          w = w - tb.lr * acc;
+        } else {
+          const float av = fmaf(acc, acc, tb.slot[off]);
+          tb.slot[off] = av;
+          w = w - tb.lr * acc / sqrtf(av);
+        }
+        st_elem(tb.weights, table_dtype, off, w);
+      }
+    }
+  }
+}
+
+__global__ void head_flags_kernel(const uint32_t* keys, int64_t nnz, uint32_t* flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  const uint32_t k = keys[i];
+  flags[i] = (k != kInvalidKey && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+}
+__global__ void count_unique_kernel(const uint32_t* flags, const uint32_t* index, int64_t nnz, int64_t* n_unique) {
+  *n_unique = nnz > 0 ? (int64_t)index[nnz - 1] + flags[nnz - 1] : 0;
+}
+
+template <typename GT, typename TT, int MODE>
+int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
+  const int lpr = pieces <= 8 ? 8 : (pieces <= 16 ? 16 : (pieces <= 32 ? 32 : 64));
+  const int64_t groups = ceil_div(p.nnz, p.chunk);
+  const int64_t blocks = ceil_div(groups * lpr, 256);
+  if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_bwd: grid too large");
+#define KRS_LAUNCH_APPLY(L)                                                                             \
+  if (p.weights)                                                                                        \
+    hipLaunchKernelGGL((bag_apply_kernel<GT, TT, L, MODE, true>), dim3((unsigned)blocks), dim3(256), 0, st, p); \
+  else                                                                                                  \
+    hipLaunchKernelGGL((bag_apply_kernel<GT, TT, L, MODE, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  if (lpr == 8) { KRS_LAUNCH_APPLY(8) }
+  else if (lpr == 16) { KRS_LAUNCH_APPLY(16) }
+  else if (lpr == 32) { KRS_LAUNCH_APPLY(32) }
+  else { KRS_LAUNCH_APPLY(64) }
+#undef KRS_LAUNCH_APPLY
+  KRS_CHECK_LAUNCH("bag_apply_kernel");
+  return KRS_OK;
+}
+
+template <int MODE>
+int run_apply(ApplyParams p, int grad_dtype, int table_dtype, hipStream_t st) {
+  if (p.nnz == 0) return KRS_OK;
+  const int64_t gbytes = (int64_t)p.dim * (grad_dtype == KRS_BF16 ? 2 : 4);
+  // the per-lane piece must also map to whole table / accumulator elements: N elements each
+  if (gbytes % 16 == 0 && gbytes <= 1024) {
+    const int pieces = (int)(gbytes / 16);
+    p.chunk = 8;
+    if (grad_dtype == KRS_F32)
+      return table_dtype == KRS_F32 ? launch_apply_lpr<float, float, MODE>(p, pieces, st)
+                                    : launch_apply_lpr<float, uint16_t, MODE>(p, pieces, st);
+    return table_dtype == KRS_F32 ? launch_apply_lpr<uint16_t, float, MODE>(p, pieces, st)
+                                  : launch_apply_lpr<uint16_t, uint16_t, MODE>(p, pieces, st);
+  }
+  int lpr = 1;
+  while (lpr < p.dim && lpr < 64) lpr <<= 1;
+  const int64_t blocks = ceil_div(p.nnz * lpr, 256);
+  if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_bwd: grid too large");
+  hipLaunchKernelGGL(bag_apply_generic<MODE>, dim3((unsigned)blocks), dim3(256), 0, st, p, grad_dtype,
+                     table_dtype, lpr);
+  KRS_CHECK_LAUNCH("bag_apply_generic");
+  return KRS_OK;
+}
+
+int check_apply_args(const void* tables_or_null, int need_tables, const krs_feature* feats, const void* grad,
+                     int grad_dtype, int batch, int dim, int64_t nnz, const void* workspace) {
+  KRS_REQUIRE(!need_tables || tables_or_null, "embed_bag_bwd: null tables");
+  KRS_REQUIRE(feats && grad && (workspace || nnz == 0), "embed_bag_bwd: null feats/grad/workspace");
+  KRS_REQUIRE(grad_dtype == KRS_F32 || grad_dtype == KRS_BF16, "embed_bag_bwd: bad grad dtype");
+  KRS_REQUIRE(batch > 0 && dim > 0 && nnz >= 0, "embed_bag_bwd: bad sizes");
+  return KRS_OK;
+}
+
+ApplyParams make_apply(const krs_table* tables, int n_tables, const krs_feature* feats, const float* weights,
+                       const float* bag_scale, const void* grad, int64_t grad_ld, int batch, int dim, int64_t nnz,
+                       const void* workspace) {
+  ApplyParams p;
+  const PlanLayout l = plan_layout(const_cast<void*>(workspace), nnz);
+  p.tables = tables; p.n_tables = n_tables; p.feats = feats; p.weights = weights; p.bag_scale = bag_scale;
+  p.grad = grad; p.grad_ld = grad_ld; p.batch = batch; p.dim = dim; p.nnz = nnz;
+  p.keys = l.keys_sorted; p.vals = l.vals_sorted; p.head_index = l.head_index;
+  p.unique_rows = nullptr; p.row_grads = nullptr; p.chunk = 8;
+  return p;
+}
+
+}  // namespace
+}  // namespace krs
+
+using namespace krs;
+
+extern "C" size_t krs_embed_bag_bwd_workspace_bytes(int64_t nnz) {
+  if (nnz < 0) return 0;
+  return plan_layout(nullptr, nnz, true).total_bytes;
+}
+
+extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature* feats, int n_feats,
+                                      const void* ids, int id_type, const void* offsets, int off_type,
+                                      int batch, int64_t nnz, int64_t total_rows, void* workspace,
+                                      size_t workspace_bytes, int* err_flag, void* stream) {
+  KRS_REQUIRE(tables && feats && (ids || nnz == 0), "embed_bag_bwd_plan: null argument");
+  KRS_REQUIRE(n_feats > 0 && batch > 0 && nnz >= 0, "embed_bag_bwd_plan: bad sizes");
+  KRS_REQUIRE(total_rows > 0 && total_rows < 0xffffffffLL, "embed_bag_bwd_plan: total_rows must fit 32-bit keys");
+  KRS_REQUIRE(nnz < 0xffffffffLL && (int64_t)n_feats * batch < 0xffffffffLL,
+              "embed_bag_bwd_plan: nnz / bag count must fit 32 bits");
+  if (nnz == 0) return KRS_OK;
+  KRS_REQUIRE(workspace, "embed_bag_bwd_plan: null workspace");
+  const PlanLayout l = plan_layout(workspace, nnz, true);
+  if (workspace_bytes < l.total_bytes)
+    return fail(KRS_ERR_WORKSPACE, "embed_bag_bwd_plan: workspace %zu < %zu bytes", workspace_bytes, l.total_bytes);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  KeyParams kp;
+  kp.tables = tables; kp.feats = feats; kp.n_feats = n_feats; kp.ids = ids; kp.id64 = id_type == KRS_I64;
+  kp.offsets = offsets; kp.off64 = off_type == KRS_I64; kp.batch = batch; kp.keys = l.keys_in; kp.vals = l.vals_in;
+  kp.err_flag = err_flag;
+  // dense mode never leaves holes; CSR mode covers [offsets[0], offsets[last]) = [0, nnz)
+  const int64_t n_bags = (int64_t)n_feats * batch;
+  hipLaunchKernelGGL(bag_keys_kernel, dim3((unsigned)ceil_div(n_bags, 16)), dim3(256), 0, st, kp);
+  KRS_CHECK_LAUNCH("bag_keys_kernel");
+  // Sort only the significant key bits.  2^bits - 1 > every valid row id, so the
+  // invalid key (all ones) still sorts last.
+  unsigned bits = 1;
+  while (bits < 32 && (1ULL << bits) <= (uint64_t)total_rows) ++bits;
+  size_t temp = l.temp_bytes;
+  KRS_HIP(rocprim::radix_sort_pairs(l.temp, temp, l.keys_in, l.keys_sorted, l.vals_in, l.vals_sorted, (size_t)nnz,
+                                    0u, bits, st));
+  return KRS_OK;
+}
+
+extern "C" int krs_embed_bag_bwd_dense(const krs_table* grad_tables, int n_tables, const krs_feature* feats,
+                                       int n_feats, const float* weights, const float* bag_scale,
+                                       const void* grad, int grad_dtype, int64_t grad_ld, int batch, int dim,
+                                       int64_t nnz, const void* workspace, void* stream) {
+  (void)n_feats;
+  if (int rc = check_apply_args(grad_tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
+  ApplyParams p = make_apply(grad_tables, n_tables, feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  return run_apply<kDense>(p, grad_dtype, KRS_F32, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int krs_embed_bag_bwd_fused_sgd(const krs_table* tables, int n_tables, const krs_feature* feats,
+                                           int n_feats, const float* weights, const float* bag_scale,
+                                           const void* grad, int grad_dtype, int64_t grad_ld, int batch, int dim,
+                                           int table_dtype, int64_t nnz, const void* workspace, void* stream) {
+  (void)n_feats;
+  if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
+  ApplyParams p = make_apply(tables, n_tables, feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  return run_apply<kSgd>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_tables, const krs_feature* feats,
+                                               int n_feats, const float* weights, const float* bag_scale,
+                                               const void* grad, int grad_dtype, int64_t grad_ld, int batch,
+                                               int dim, int table_dtype, int64_t nnz, const void* workspace,
+                                               void* stream) {
+  (void)n_feats;
+  if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
+  ApplyParams p = make_apply(tables, n_tables, feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  return run_apply<kAdagrad>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats, const float* weights,
+                                        const float* bag_scale, const void* grad, int grad_dtype,
+                                        int64_t grad_ld, int batch, int dim, int64_t nnz, const void* workspace,
+                                        int64_t* unique_rows, float* row_grads, int64_t* n_unique, void* stream) {
+  (void)n_feats;
+  if (int rc = check_apply_args(nullptr, 0, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
+  KRS_REQUIRE(unique_rows && row_grads && n_unique, "embed_bag_bwd_sparse: null outputs");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (nnz == 0) {
+    KRS_HIP(hipMemsetAsync(n_unique, 0, sizeof(int64_t), st));
+    return KRS_OK;
+  }
+  const PlanLayout l = plan_layout(const_cast<void*>(workspace), nnz, true);
+  hipLaunchKernelGGL(head_flags_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, l.keys_sorted, nnz,
+                     l.head_flag);
+  KRS_CHECK_LAUNCH("head_flags_kernel");
+  size_t temp = l.temp_bytes;
+  KRS_HIP(rocprim::exclusive_scan(l.temp, temp, l.head_flag, l.head_index, 0u, (size_t)nnz,
+                                  rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(count_unique_kernel, dim3(1), dim3(1), 0, st, l.head_flag, l.head_index, nnz, n_unique);
+  KRS_CHECK_LAUNCH("count_unique_kernel");
+  ApplyParams p = make_apply(nullptr, 0, feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  p.unique_rows = unique_rows;
+  p.row_grads = row_grads;
+  return run_apply<kSparse>(p, grad_dtype, KRS_F32, st);
+}

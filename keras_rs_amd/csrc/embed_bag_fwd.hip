@@ -18,10 +18,24 @@
 //   * ids / offsets are read by all lanes of a group from one address
 //     (a single broadcast transaction per group), sequentially along the bag.
 // Algorithmic bytes per lookup: D*s_t + 4 (+4 with weights); per bag D*s_o + 4.
+#include <cstdlib>
+
 #include "krs_common.h"
+
+#ifndef KRS_K1_UNROLL
+#define KRS_K1_UNROLL 4
+#endif
+#ifndef KRS_K1_NT
+#define KRS_K1_NT 0  // bit0: nontemporal row loads, bit1: nontemporal output stores
+#endif
 
 namespace krs {
 namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kUnroll = KRS_K1_UNROLL;
+constexpr int NT = KRS_K1_NT;
 
 struct EmbedFwdParams {
   const krs_table* tables;
@@ -70,7 +84,11 @@ __device__ __forceinline__ void store_row_piece(OT* dst, const float (&v)[N], bo
     if (aligned) {
 #pragma unroll
       for (int i = 0; i < N; i += 4)
-        *reinterpret_cast<float4*>(dst + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+      {
+        f32x4 t4 = {v[i], v[i + 1], v[i + 2], v[i + 3]};
+        if constexpr (NT & 2) __builtin_nontemporal_store(t4, reinterpret_cast<f32x4*>(dst + i));
+        else *reinterpret_cast<f32x4*>(dst + i) = t4;
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < N; ++i) dst[i] = v[i];
@@ -78,8 +96,10 @@ __device__ __forceinline__ void store_row_piece(OT* dst, const float (&v)[N], bo
   } else {
     if (aligned) {
       if constexpr (N == 8) {
-        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                    pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        u32x4 t4 = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                    pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        if constexpr (NT & 2) __builtin_nontemporal_store(t4, reinterpret_cast<u32x4*>(dst));
+        else *reinterpret_cast<u32x4*>(dst) = t4;
       } else {
         *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
       }
@@ -90,7 +110,6 @@ __device__ __forceinline__ void store_row_piece(OT* dst, const float (&v)[N], bo
   }
 }
 
-constexpr int kUnroll = 4;
 
 // TT: table element (float | uint16_t=bf16), OT: output element, LPR: lanes per row.
 template <typename TT, typename OT, int LPR, bool HAS_W>
@@ -191,7 +210,10 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p)
       if (idc[k] >= 0) {
         const char* src = table + (int64_t)idc[k] * row_bytes + sub * 16;
         if (tab_aligned) {
-          raw[k] = *reinterpret_cast<const uint4*>(src);
+          u32x4 t4;
+          if constexpr (NT & 1) t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+          else t4 = *reinterpret_cast<const u32x4*>(src);
+          raw[k] = make_uint4(t4.x, t4.y, t4.z, t4.w);
         } else {
           const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
           if constexpr (sizeof(TT) == 4) {
@@ -339,6 +361,7 @@ extern "C" int krs_embed_bag_fwd(const krs_table* tables, const krs_feature* fea
   const int64_t mean_hot = nnz / n_bags > 0 ? nnz / n_bags : 1;
   int bpg = (int)(16 / mean_hot);
   p.bpg = bpg < 1 ? 1 : (bpg > 16 ? 16 : bpg);
+  if (const char* e = getenv("KRS_BPG")) p.bpg = atoi(e);  // development override
 
   const int64_t row_bytes = (int64_t)dim * (table_dtype == KRS_BF16 ? 2 : 4);
   if (row_bytes % 16 == 0 && row_bytes <= 1024) {

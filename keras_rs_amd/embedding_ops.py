@@ -112,3 +112,70 @@ class FusedBags:
             L.ptr(scale), L.ptr(err_flag), L.stream_ptr())
         L.check(rc, "krs_embed_bag_fwd")
         return out, scale
+
+    # ---- K2 ---------------------------------------------------------------
+    def plan_backward(self, ids: torch.Tensor, batch: int, hots: Sequence[int] | None = None,
+                      offsets: torch.Tensor | None = None, err_flag: torch.Tensor | None = None):
+        """Sorts the lookups by global row (krs_embed_bag_bwd_plan).  Returns the opaque
+        workspace tensor the apply calls consume; depends only on the ids, not on gradients."""
+        L.require_device(ids, "ids")
+        nnz = ids.numel()
+        nbytes = L.lib().krs_embed_bag_bwd_workspace_bytes(C.c_int64(nnz))
+        ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=ids.device)
+        rc = L.lib().krs_embed_bag_bwd_plan(
+            L.ptr(self.table_desc()), L.ptr(self.feature_desc(batch, hots, ids.device)),
+            C.c_int(len(self.features)), L.ptr(ids), C.c_int(L.itype(ids)),
+            L.ptr(offsets), C.c_int(L.itype(offsets) if offsets is not None else L.I32),
+            C.c_int(batch), C.c_int64(nnz), C.c_int64(self.total_rows),
+            L.ptr(ws), C.c_size_t(ws.numel()), L.ptr(err_flag), L.stream_ptr())
+        L.check(rc, "krs_embed_bag_bwd_plan")
+        return ws
+
+    def _apply_common(self, grad, batch, hots):
+        L.require_device(grad, "grad")
+        if grad.stride(-1) != 1:
+            grad = grad.contiguous()
+        return grad, self.feature_desc(batch, hots, grad.device)
+
+    def backward_dense(self, ws, grad, batch, nnz, hots=None, weights=None, bag_scale=None,
+                       out: Sequence[torch.Tensor] | None = None):
+        """Dense per-table gradients [V, D] fp32 (the reference autodiff result)."""
+        grad, fdesc = self._apply_common(grad, batch, hots)
+        if out is None:
+            out = [torch.zeros(t.shape, dtype=torch.float32, device=grad.device) for t in self.tables]
+        gdesc = self.table_desc(weights=list(out), slots=[None] * len(out))
+        rc = L.lib().krs_embed_bag_bwd_dense(
+            L.ptr(gdesc), C.c_int(len(out)), L.ptr(fdesc), C.c_int(len(self.features)),
+            L.ptr(weights), L.ptr(bag_scale), L.ptr(grad), C.c_int(L.fdtype(grad)),
+            C.c_int64(grad.stride(0)), C.c_int(batch), C.c_int(self.dim), C.c_int64(nnz),
+            L.ptr(ws), L.stream_ptr())
+        L.check(rc, "krs_embed_bag_bwd_dense")
+        return list(out)
+
+    def backward_fused(self, kind, ws, grad, batch, nnz, hots=None, weights=None, bag_scale=None):
+        """In-place SGD / Adagrad on the touched rows of the tables (and Adagrad slots)."""
+        grad, fdesc = self._apply_common(grad, batch, hots)
+        fn = {"sgd": L.lib().krs_embed_bag_bwd_fused_sgd,
+              "adagrad": L.lib().krs_embed_bag_bwd_fused_adagrad}[kind]
+        if kind == "adagrad" and any(s is None for s in self.slots):
+            raise L.KrsError("fused adagrad needs an accumulator slot per table")
+        rc = fn(L.ptr(self.table_desc()), C.c_int(len(self.tables)), L.ptr(fdesc),
+                C.c_int(len(self.features)), L.ptr(weights), L.ptr(bag_scale), L.ptr(grad),
+                C.c_int(L.fdtype(grad)), C.c_int64(grad.stride(0)), C.c_int(batch), C.c_int(self.dim),
+                C.c_int(L.fdtype(self.tables[0])), C.c_int64(nnz), L.ptr(ws), L.stream_ptr())
+        L.check(rc, f"krs_embed_bag_bwd_fused_{kind}")
+
+    def backward_sparse(self, ws, grad, batch, nnz, hots=None, weights=None, bag_scale=None):
+        """(unique global rows [U] int64, summed gradients [U, D] fp32)."""
+        grad, fdesc = self._apply_common(grad, batch, hots)
+        dev = grad.device
+        rows = torch.empty(max(nnz, 1), dtype=torch.int64, device=dev)
+        vals = torch.empty((max(nnz, 1), self.dim), dtype=torch.float32, device=dev)
+        n_u = torch.zeros(1, dtype=torch.int64, device=dev)
+        rc = L.lib().krs_embed_bag_bwd_sparse(
+            L.ptr(fdesc), C.c_int(len(self.features)), L.ptr(weights), L.ptr(bag_scale), L.ptr(grad),
+            C.c_int(L.fdtype(grad)), C.c_int64(grad.stride(0)), C.c_int(batch), C.c_int(self.dim),
+            C.c_int64(nnz), L.ptr(ws), L.ptr(rows), L.ptr(vals), L.ptr(n_u), L.stream_ptr())
+        L.check(rc, "krs_embed_bag_bwd_sparse")
+        u = int(n_u.item())
+        return rows[:u], vals[:u]

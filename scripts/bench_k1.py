@@ -1,5 +1,8 @@
 """Micro-benchmark of K1 (krs_embed_bag_fwd) at the C3 shape; development aid."""
 import argparse
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import time
 
@@ -16,32 +19,84 @@ ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--multihot", action="store_true")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--bpgs", default="")
+ap.add_argument("--stacked", action="store_true")
+ap.add_argument("--copyref", action="store_true")
+ap.add_argument("--idmode", default="rand")
+ap.add_argument("--fmajor_out", action="store_true")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 g = torch.Generator(device=dev).manual_seed(1337)
-tables = [(torch.rand(a.vocab, a.dim, device=dev, generator=g) * 0.1 - 0.05).to(dt) for _ in range(a.tables)]
+if a.stacked:
+    big = torch.empty(a.tables * a.vocab, a.dim, dtype=dt, device=dev)
+    tables = [big[t * a.vocab:(t + 1) * a.vocab] for t in range(a.tables)]
+    for t in tables:
+        t.copy_((torch.rand(a.vocab, a.dim, device=dev, generator=g) * 0.1 - 0.05).to(dt))
+else:
+    tables = [(torch.rand(a.vocab, a.dim, device=dev, generator=g) * 0.1 - 0.05).to(dt) for _ in range(a.tables)]
 HOTS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
 hots = (HOTS * 4)[: a.tables] if a.multihot else [1] * a.tables
 gi = torch.Generator(device=dev).manual_seed(1338)
-ids = torch.cat([torch.randint(0, a.vocab, (a.batch * h,), device=dev, generator=gi, dtype=torch.int32)
-                 for h in hots])
-fb = FusedBags(tables, [(t, "sum", t * a.dim) for t in range(a.tables)])
-out = torch.empty(a.batch, a.tables * a.dim, dtype=dt, device=dev)
-for _ in range(3):
-    fb.forward(ids, a.batch, hots=hots, out=out)
-torch.cuda.synchronize()
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
-ev[0].record()
-for i in range(a.iters):
-    fb.forward(ids, a.batch, hots=hots, out=out)
-    ev[i + 1].record()
-torch.cuda.synchronize()
-ts = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters)]) * 1e-3
-nnz = ids.numel()
-es = 2 if a.dtype == "bf16" else 4
-bytes_ = nnz * (a.dim * es + 4) + a.batch * a.tables * (a.dim * es)
-print(json.dumps({"kernel": "krs_embed_bag_fwd", "nnz": nnz, "median_us": float(np.median(ts) * 1e6),
-                  "min_us": float(ts.min() * 1e6), "lookups_per_s": nnz / float(np.median(ts)),
-                  "GBps": bytes_ / float(np.median(ts)) / 1e9, "frac_of_8TBps": bytes_ / float(np.median(ts)) / 8e12}))
+if a.idmode == "seq":
+    ids = torch.cat([(torch.arange(a.batch * h, device=dev, dtype=torch.int32) % a.vocab) for h in hots])
+else:
+    ids = torch.cat([torch.randint(0, a.vocab, (a.batch * h,), device=dev, generator=gi, dtype=torch.int32)
+                     for h in hots])
+if a.fmajor_out:
+    fb = FusedBags(tables, [(t, "sum", t * a.batch * a.dim) for t in range(a.tables)])
+    out = torch.empty(a.batch * a.tables, a.dim, dtype=dt, device=dev)
+else:
+    fb = FusedBags(tables, [(t, "sum", t * a.dim) for t in range(a.tables)])
+    out = torch.empty(a.batch, a.tables * a.dim, dtype=dt, device=dev)
+if a.copyref:
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+    for _ in range(3): dst.copy_(src)
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): dst.copy_(src)
+    e1.record(); torch.cuda.synchronize()
+    print(json.dumps({"copy_GBps": 2 * 10 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9}))
+for bpg in (a.bpgs.split(",") if a.bpgs else [""]):
+    if bpg:
+        os.environ["KRS_BPG"] = bpg
+    for _ in range(3):
+        fb.forward(ids, a.batch, hots=hots, out=out)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
+    ev[0].record()
+    for i in range(a.iters):
+        fb.forward(ids, a.batch, hots=hots, out=out)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters)]) * 1e-3
+    nnz = ids.numel()
+    es = 2 if a.dtype == "bf16" else 4
+    bytes_ = nnz * (a.dim * es + 4) + a.batch * a.tables * (a.dim * es)
+    print(json.dumps({"lib": os.path.basename(os.environ.get("KRS_LIB", "default")), "bpg": bpg, "stacked": a.stacked, "fmajor_out": a.fmajor_out, "vocab": a.vocab, "idmode": a.idmode, "nnz": nnz, "median_us": float(np.median(ts) * 1e6),
+                      "min_us": float(ts.min() * 1e6), "lookups_per_s": nnz / float(np.median(ts)),
+                      "GBps": bytes_ / float(np.median(ts)) / 1e9, "frac_of_8TBps": bytes_ / float(np.median(ts)) / 8e12}))
+    
+# ---- K2 timings (plan = sort; apply = fused Adagrad) ----
+def timeit(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+if not a.fmajor_out:
+    fb.slots = [torch.full(t.shape, 0.1, dtype=torch.float32, device=dev) for t in tables]
+    fb.lrs = [0.0034] * a.tables
+    grad = (torch.rand(a.batch, a.tables * a.dim, device=dev) * 1e-3).to(dt)
+    nnz = ids.numel()
+    t_plan = timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots))
+    ws = fb.plan_backward(ids, a.batch, hots=hots)
+    t_ada = timeit(lambda: fb.backward_fused("adagrad", ws, grad, a.batch, nnz, hots=hots))
+    t_sgd = timeit(lambda: fb.backward_fused("sgd", ws, grad, a.batch, nnz, hots=hots))
+    print(json.dumps({"k2_plan_us": t_plan * 1e6, "k2_adagrad_us": t_ada * 1e6, "k2_sgd_us": t_sgd * 1e6}))

@@ -33,4 +33,4 @@ def test_struct_layouts_match_header():
     assert L.TABLE_DT.itemsize == 32 and L.FEATURE_DT.itemsize == 24
     import ctypes
 
-    assert ctypes.sizeof(L.GemmEpilogue) == 88
+    assert ctypes.sizeof(L.GemmEpilogue) == 80

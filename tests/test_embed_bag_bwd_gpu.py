@@ -1,0 +1,113 @@
+"""K2 parity: sort-based index-scatter gradient (dense / sparse / fused SGD+Adagrad) vs the oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import krs_oracle as ko
+from tests.helpers import make_bags, to_f32, to_np
+
+pytestmark = pytest.mark.gpu
+TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _setup(dim, tdt, gdt, csr, use_w, combiners, n_tables=3, batch=41, max_hot=6, seed=0, shared=True,
+           vocab_hi=60):
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    vocabs_t = [int(v) for v in rng.integers(3, vocab_hi, size=n_tables)]
+    tables = [torch.from_numpy(rng.uniform(-1, 1, (v, dim)).astype(np.float32)).to(TORCH_DT[tdt]).to(dev)
+              for v in vocabs_t]
+    tix = list(range(n_tables)) + ([0] if shared else [])
+    n_feats = len(tix)
+    specs = [(tix[f], combiners[f % len(combiners)], 2 + f * dim) for f in range(n_feats)]
+    cols = 2 + n_feats * dim + 3
+    bags = make_bags(rng, n_feats, batch, [vocabs_t[t] for t in tix], max_hot, csr)
+    grad = torch.from_numpy(rng.uniform(0, 1, (batch, cols)).astype(np.float32)).to(TORCH_DT[gdt]).to(dev)
+    slots = [torch.full(t.shape, 0.1, dtype=torch.float32, device=dev) for t in tables]
+    fb = FusedBags(tables, specs, slots=slots, lrs=[0.01 * (i + 1) for i in range(n_tables)])
+    ids = torch.from_numpy(bags["ids"]).to(dev)
+    offs = None if bags["offsets"] is None else torch.from_numpy(bags["offsets"]).to(dev)
+    w = torch.from_numpy(bags["weights"]).to(dev) if use_w else None
+    out = torch.empty((batch, cols), dtype=TORCH_DT[tdt], device=dev)
+    _, scale = fb.forward(ids, batch, hots=bags["hots"], offsets=offs, weights=w, out=out, want_scale=True)
+    ws = fb.plan_backward(ids, batch, hots=bags["hots"], offsets=offs)
+
+    # oracle dense gradient
+    feats_np = ko.make_features([t for t, _, _ in specs], [c for _, c, _ in specs], [c for _, _, c in specs],
+                                hots=bags["hots"], batch=batch)
+    de = [np.zeros((v, dim), np.float32) for v in vocabs_t]
+    ko.embed_bag_bwd_dense(ko.make_tables(de), feats_np, bags["ids"], bags["offsets"],
+                           bags["weights"] if use_w else None, scale.cpu().numpy(), to_np(grad), batch, dim)
+    return dict(fb=fb, ws=ws, grad=grad, batch=batch, nnz=bags["nnz"], hots=bags["hots"], w=w, scale=scale,
+                de=de, tables=tables, slots=slots, bags=bags, vocabs=vocabs_t)
+
+
+@pytest.mark.parametrize("dim", [6, 7, 32, 64, 128, 256])
+@pytest.mark.parametrize("tdt,gdt", [("f32", "f32"), ("bf16", "bf16")])
+@pytest.mark.parametrize("csr", [False, True])
+def test_dense_gradient(dim, tdt, gdt, csr):
+    s = _setup(dim, tdt, gdt, csr, use_w=True, combiners=["sum", "mean", "sqrtn"])
+    got = s["fb"].backward_dense(s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                                 bag_scale=s["scale"])
+    torch.cuda.synchronize()
+    for g, e in zip(got, s["de"]):
+        # same summation order (ascending position) and fmaf: agreement far inside 1e-5
+        np.testing.assert_allclose(g.cpu().numpy(), e, rtol=1e-6, atol=1e-6)
+
+
+def test_dense_gradient_is_deterministic_and_handles_heavy_duplicates():
+    s = _setup(128, "f32", "f32", False, use_w=False, combiners=["sum"], n_tables=2, batch=300, max_hot=40,
+               vocab_hi=8)
+    a = s["fb"].backward_dense(s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], bag_scale=s["scale"])
+    b = s["fb"].backward_dense(s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], bag_scale=s["scale"])
+    for x, y, e in zip(a, b, s["de"]):
+        assert torch.equal(x, y)
+        np.testing.assert_allclose(x.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dim", [20, 128])
+def test_sparse_gradient(dim):
+    s = _setup(dim, "f32", "f32", True, use_w=True, combiners=["mean"])
+    rows, vals = s["fb"].backward_sparse(s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"],
+                                         weights=s["w"], bag_scale=s["scale"])
+    rows = rows.cpu().numpy()
+    vals = vals.cpu().numpy()
+    assert np.all(np.diff(rows) > 0)  # unique, ascending global rows
+    dense = np.concatenate(s["de"], axis=0)
+    touched = np.zeros(dense.shape[0], bool)
+    touched[rows] = True
+    np.testing.assert_allclose(vals, dense[rows], rtol=1e-6, atol=1e-6)
+    assert np.all(dense[~touched] == 0)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+@pytest.mark.parametrize("tdt,gdt,dim", [("f32", "f32", 128), ("bf16", "bf16", 128), ("f32", "f32", 7),
+                                         ("bf16", "f32", 64), ("f32", "bf16", 64)])
+def test_fused_optimizers(kind, tdt, gdt, dim):
+    s = _setup(dim, tdt, gdt, False, use_w=True, combiners=["sum", "mean"])
+    exp_tables = [to_np(t).copy() for t in s["tables"]]
+    exp_slots = [x.cpu().numpy().copy() for x in s["slots"]]
+    s["fb"].backward_fused(kind, s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                           bag_scale=s["scale"])
+    torch.cuda.synchronize()
+    # which rows were looked up (per table)
+    ids, hots, bags = s["bags"]["ids"], s["hots"], s["bags"]
+    for t in range(len(exp_tables)):
+        touched = np.zeros(s["vocabs"][t], np.uint8)
+        base = 0
+        for f, (tt, _, _) in enumerate(s["fb"].features):
+            n = s["batch"] * hots[f]
+            if tt == t:
+                touched[ids[base:base + n]] = 1
+            base += n
+        ko.apply_optimizer(exp_tables[t], exp_slots[t], s["de"][t], touched, s["fb"].lrs[t], kind)
+        got = to_np(s["tables"][t])
+        if tdt == "bf16":
+            np.testing.assert_allclose(to_f32(got), to_f32(exp_tables[t]), rtol=2 ** -7, atol=1e-6)
+        else:
+            np.testing.assert_allclose(got, exp_tables[t], rtol=1e-6, atol=1e-6)
+        if kind == "adagrad":
+            np.testing.assert_allclose(s["slots"][t].cpu().numpy(), exp_slots[t], rtol=1e-6, atol=1e-6)
