@@ -1,0 +1,604 @@
+// K3 -- FeatureCross (DCN-v2): the dense projection on MFMA with the cross
+// epilogue fused, plus the elementwise backward pieces.
+//
+// Replaces FeatureCross.call (keras_rs/src/layers/feature_interaction/feature_cross.py:182-194):
+//   keras Dense (matmul + bias + activation, :134-151) -> cast -> + diag_scale*x
+//   -> x0 * u + x, which the reference runs as one GEMM and three separate
+//   elementwise passes over [B, d].
+//
+// krs_gemm: C[M,N] = epilogue(A[M,K] . B[K,N]) for the three operand layouts
+// the layer needs (forward, data gradient, weight gradient):
+//   * 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave
+//     2x2 fragments of v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32
+//     (fp32, exact fmaf chain); fp32 accumulators in registers;
+//   * both operand tiles live in LDS K-contiguous ([row][128 B + 16 B pad]: the
+//     padded 144-byte stride makes ds_read_b128 fragment reads conflict-free),
+//     so a lane's MFMA operand is one 16-byte LDS read; operands stored
+//     K-strided in HBM (keras kernel layout [K,N], or activations contracted
+//     over the batch) are transposed in registers on their way into LDS;
+//   * global->register->LDS staging, next tile's loads issued before the MFMA
+//     phase of the current one (one barrier per K tile, LDS double buffered);
+//   * weight-gradient shapes (tiny M x N, K = batch) are split along K into
+//     fp32 slabs reduced in a fixed order (deterministic, no atomics);
+//   * epilogue on the accumulator: + bias, activation, cross (x0*(v+diag*x)+x),
+//     + beta*R, one rounding to the output dtype.
+// Shapes that do not meet the alignment rules take a plain one-thread-per-
+// output kernel (the reference's toy shapes, d = 3).
+#include <algorithm>
+#include <cstring>
+#include <initializer_list>
+
+#include "krs_common.h"
+
+namespace krs {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 128;          // K extent of a tile row in bytes (64 bf16 / 32 fp32)
+constexpr int LDS_STRIDE = ROW_BYTES + 16;
+constexpr int TILE_BYTES = BM * LDS_STRIDE;  // one operand tile (BM == BN)
+
+struct GemmParams {
+  const char* a; int64_t lda; int a_km;
+  const char* b; int64_t ldb; int b_nk;
+  char* c; int64_t ldc;
+  int64_t m, n, k;
+  int out_dtype;
+  krs_gemm_epilogue ep;
+  int has_ep;
+  // split-K
+  int splits; int64_t k_per_split; float* slabs;
+};
+
+__device__ __forceinline__ float apply_act(int act, float v) {
+  switch (act) {
+    case KRS_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case KRS_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    case KRS_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// epilogue of one element; `odt` = dtype of C, x0, x, u_out, r
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t i, int64_t j, float v) {
+  const int odt = p.out_dtype;
+  if (p.has_ep) {
+    const krs_gemm_epilogue& e = p.ep;
+    if (e.bias) v += e.bias[j];
+    v = apply_act(e.act, v);
+    if (e.x0) {
+      const float xv = ld_elem(e.x, odt, i * e.ldx + j);
+      const float u = v + e.diag_scale * xv;
+      if (e.u_out) st_elem(e.u_out, odt, i * e.ldu + j, u);
+      v = ld_elem(e.x0, odt, i * e.ldx + j) * u + xv;
+    }
+    if (e.r) v += e.beta * ld_elem(e.r, odt, i * e.ldr + j);
+  }
+  st_elem(p.c, odt, i * p.ldc + j, v);
+}
+
+// ---- staging: HBM -> registers -> LDS ([row][k] with 144-byte rows) ---------
+// ES = element size (2 | 4).  `row0` tile origin along the operand's row axis
+// (m for A, n for B), `k0` along K.  rows/kk are the operand extents.
+
+// operand stored K-contiguous: elem(row, k) at base + (row*ld + k)*ES
+template <int ES>
+__device__ __forceinline__ void load_kcontig(const char* base, int64_t ld, int64_t row0, int64_t k0,
+                                             int64_t rows, int64_t kk, u32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  const int c = t & 7;
+  const int64_t kel = k0 + c * (16 / ES);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = row0 + (t >> 3) + 32 * i;
+    u32x4 v = {0, 0, 0, 0};
+    if (row < rows && kel < kk) v = *reinterpret_cast<const u32x4*>(base + (row * ld + kel) * ES);
+    r[i] = v;
+  }
+}
+__device__ __forceinline__ void store_kcontig(char* tile, const u32x4 (&r)[4]) {
+  const int t = threadIdx.x;
+  const int c = t & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<u32x4*>(tile + ((t >> 3) + 32 * i) * LDS_STRIDE + c * 16) = r[i];
+}
+
+// operand stored K-strided: elem(row, k) at base + (k*ld + row)*ES.  A thread
+// takes a 4(k) x (16/ES)(row) block: four 16-byte loads along `row`.
+template <int ES>
+__device__ __forceinline__ void load_kstrided(const char* base, int64_t ld, int64_t row0, int64_t k0,
+                                              int64_t rows, int64_t kk, u32x4 (&r)[4]) {
+  constexpr int RPB = 16 / ES;          // rows per block: 8 (bf16) | 4 (fp32)
+  constexpr int NRB = BM / RPB;         // row blocks per tile: 16 | 32
+  const int t = threadIdx.x;
+  const int rb = t % NRB;
+  const int kb = t / NRB;
+  const int64_t row = row0 + rb * RPB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t kel = k0 + kb * 4 + i;
+    u32x4 v = {0, 0, 0, 0};
+    if (row < rows && kel < kk) v = *reinterpret_cast<const u32x4*>(base + (kel * ld + row) * ES);
+    r[i] = v;
+  }
+}
+template <int ES>
+__device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) {
+  constexpr int RPB = 16 / ES;
+  constexpr int NRB = BM / RPB;
+  const int t = threadIdx.x;
+  const int rb = t % NRB;
+  const int kb = t / NRB;
+  if constexpr (ES == 4) {
+    // 4x4 fp32 transpose is pure register renaming
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = jj;
+      u32x4 o = {r[0][j], r[1][j], r[2][j], r[3][j]};
+      *reinterpret_cast<u32x4*>(tile + (rb * 4 + j) * LDS_STRIDE + kb * 16) = o;
+    }
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int j = jj;
+      const int w = j >> 1;
+      uint32_t lo, hi;
+      if (j & 1) {
+        lo = (r[0][w] >> 16) | (r[1][w] & 0xffff0000u);
+        hi = (r[2][w] >> 16) | (r[3][w] & 0xffff0000u);
+      } else {
+        lo = (r[0][w] & 0xffffu) | (r[1][w] << 16);
+        hi = (r[2][w] & 0xffffu) | (r[3][w] << 16);
+      }
+      *reinterpret_cast<uint2*>(tile + (rb * 8 + j) * LDS_STRIDE + kb * 8) = make_uint2(lo, hi);
+    }
+  }
+}
+
+template <int ES, bool A_KM, bool B_NK>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = ROW_BYTES / ES;  // K elements per tile
+  // buffer b: A tile at smem + 2b*TILE_BYTES, B tile right behind it
+  auto tile_a = [&](int buf) -> char* { return smem + (2 * buf) * TILE_BYTES; };
+  auto tile_b = [&](int buf) -> char* { return smem + (2 * buf + 1) * TILE_BYTES; };
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM;
+  const int64_t n0 = (int64_t)blockIdx.x * BN;
+  const int split = blockIdx.z;
+  const int64_t kbeg = (int64_t)split * p.k_per_split;
+  const int64_t kend = min(p.k, kbeg + p.k_per_split);
+  const int64_t ntiles = (kend - kbeg + BK - 1) / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  u32x4 ra[4], rb[4];
+  auto load_tiles = [&](int64_t t) {
+    const int64_t k0 = kbeg + t * BK;
+    if constexpr (A_KM) load_kstrided<ES>(p.a, p.lda, m0, k0, p.m, kend, ra);
+    else load_kcontig<ES>(p.a, p.lda, m0, k0, p.m, kend, ra);
+    if constexpr (B_NK) load_kcontig<ES>(p.b, p.ldb, n0, k0, p.n, kend, rb);
+    else load_kstrided<ES>(p.b, p.ldb, n0, k0, p.n, kend, rb);
+  };
+  auto store_tiles = [&](int buf) {
+    if constexpr (A_KM) store_kstrided<ES>(tile_a(buf), ra); else store_kcontig(tile_a(buf), ra);
+    if constexpr (B_NK) store_kcontig(tile_b(buf), rb); else store_kstrided<ES>(tile_b(buf), rb);
+  };
+
+  if (ntiles > 0) {
+    load_tiles(0);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  const int frow = lane & 31;          // fragment row (m for A, n for B)
+  const int fk = (lane >> 5) * 16;     // byte offset of this lane's 16-byte K chunk
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < ntiles) load_tiles(t + 1);  // in flight under the MFMAs below
+    const char* ta = tile_a(cur) + (wm * 64 + frow) * LDS_STRIDE + fk;
+    const char* tb = tile_b(cur) + (wn * 64 + frow) * LDS_STRIDE + fk;
+#pragma unroll
+    for (int ks = 0; ks < ROW_BYTES / 32; ++ks) {  // 32 bytes of K per step (2 lane halves x 16 B)
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const u32x4*>(ta + i * 32 * LDS_STRIDE + ks * 32);
+        fb[i] = *reinterpret_cast<const u32x4*>(tb + i * 32 * LDS_STRIDE + ks * 32);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (ES == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i][q]),
+                                                               __uint_as_float(fb[j][q]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    if (t + 1 < ntiles) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+  const int ccol = lane & 31;
+  const int crow = 4 * (lane >> 5);
+  auto write_frag = [&](const f32x16& v, int i, int j) {
+    const int64_t gn = n0 + wn * 64 + j * 32 + ccol;
+    const int64_t gmb = m0 + wm * 64 + i * 32 + crow;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t gm = gmb + (r & 3) + 8 * (r >> 2);
+      if (gm < p.m && gn < p.n) {
+        if (p.splits > 1)
+          p.slabs[((int64_t)split * p.m + gm) * p.n + gn] = v[r];
+        else
+          epilogue_store(p, gm, gn, v[r]);
+      }
+    }
+  };
+  write_frag(acc[0][0], 0, 0);
+  write_frag(acc[0][1], 0, 1);
+  write_frag(acc[1][0], 1, 0);
+  write_frag(acc[1][1], 1, 1);
+}
+
+// fixed-order reduction of the split-K slabs + epilogue
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const GemmParams p) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.m * p.n) return;
+  float v = 0.0f;
+  for (int s = 0; s < p.splits; ++s) v += p.slabs[(int64_t)s * p.m * p.n + idx];
+  epilogue_store(p, idx / p.n, idx % p.n, v);
+}
+
+// any shape / alignment: one thread per output element
+__global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmParams p, int in_dtype) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.m * p.n) return;
+  const int64_t i = idx / p.n, j = idx % p.n;
+  float acc = 0.0f;
+  for (int64_t kk = 0; kk < p.k; ++kk) {
+    const float av = p.a_km ? ld_elem(p.a, in_dtype, kk * p.lda + i) : ld_elem(p.a, in_dtype, i * p.lda + kk);
+    const float bv = p.b_nk ? ld_elem(p.b, in_dtype, j * p.ldb + kk) : ld_elem(p.b, in_dtype, kk * p.ldb + j);
+    acc = fmaf(av, bv, acc);
+  }
+  epilogue_store(p, i, j, acc);
+}
+
+int pick_splits(int64_t m, int64_t n, int64_t k) {
+  const int64_t tiles = ceil_div(m, BM) * ceil_div(n, BN);
+  if (tiles >= 256 || k < 4096) return 1;
+  int64_t s = ceil_div(1024, tiles);       // aim at ~4 workgroups per CU
+  const int64_t max_s = k / 1024;          // keep >= 1024 of K per split
+  if (s > max_s) s = max_s;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : (int)s;
+}
+
+bool mfma_eligible(const GemmParams& p, int es) {
+  const int64_t va = 16 / es;  // elements per 16-byte vector
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!al(p.a) || !al(p.b)) return false;
+  if (p.lda % va || p.ldb % va) return false;
+  // the vector-loaded axis must be a multiple of the vector length
+  if (p.a_km ? (p.m % va) : (p.k % va)) return false;
+  if (p.b_nk ? (p.k % va) : (p.n % va)) return false;
+  return p.m >= 1 && p.n >= 1 && p.k >= 1;
+}
+
+template <int ES>
+int launch_mfma(const GemmParams& p, hipStream_t st) {
+  const dim3 grid((unsigned)ceil_div(p.n, BN), (unsigned)ceil_div(p.m, BM), (unsigned)p.splits);
+  const size_t lds = 4 * TILE_BYTES;
+#define KRS_GEMM_CASE(AK, BK_)                                                                      \
+  {                                                                                                 \
+    auto kern = gemm_mfma_kernel<ES, AK, BK_>;                                                      \
+    static bool attr_set = false;                                                                   \
+    if (!attr_set) {                                                                                \
+      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+      attr_set = true;                                                                              \
+    }                                                                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                          \
+  }
+  if (p.a_km && p.b_nk) return fail(KRS_ERR_UNSUPPORTED, "krs_gemm: A^T . B^T layout is not used by the layer");
+  if (p.a_km) KRS_GEMM_CASE(true, false)
+  else if (p.b_nk) KRS_GEMM_CASE(false, true)
+  else KRS_GEMM_CASE(false, false)
+#undef KRS_GEMM_CASE
+  KRS_CHECK_LAUNCH("gemm_mfma_kernel");
+  return KRS_OK;
+}
+
+// ---- elementwise kernels ------------------------------------------------------
+struct CrossParams {
+  const void* g; const void* u; const void* x0; const void* x;
+  void* y; void* du; void* dx0; void* dxd; float* dbias;
+  int dx0_acc;
+  int64_t m, n, ld;
+  float diag;
+  int dtype;
+};
+
+// one thread per 8 columns; rows strided by gridDim.y*ROWS_PER_BLOCK
+template <typename T, int V>
+struct RowVec;  // V contiguous elements <-> fp32
+template <>
+struct RowVec<float, 4> {
+  static __device__ __forceinline__ void load(const void* p, int64_t o, float (&f)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + o);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  static __device__ __forceinline__ void store(void* p, int64_t o, const float (&f)[4]) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + o) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+};
+template <>
+struct RowVec<uint16_t, 8> {
+  static __device__ __forceinline__ void load(const void* p, int64_t o, float (&f)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + o);
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(void* p, int64_t o, const float (&f)[8]) {
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p) + o) =
+        make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                   pack_bf16x2(f[6], f[7]));
+  }
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void cross_fwd_vec_kernel(const CrossParams p) {
+  const int64_t nv = p.n / V;
+  const int64_t total = p.m * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t i = idx / nv, o = i * p.ld + (idx - i * nv) * V;
+    float u[V], x0[V], x[V], y[V];
+    RowVec<T, V>::load(p.u, o, u);
+    RowVec<T, V>::load(p.x0, o, x0);
+    RowVec<T, V>::load(p.x, o, x);
+#pragma unroll
+    for (int k = 0; k < V; ++k) y[k] = x0[k] * (u[k] + p.diag * x[k]) + x[k];
+    RowVec<T, V>::store(p.y, o, y);
+  }
+}
+
+__global__ __launch_bounds__(256) void cross_fwd_scalar_kernel(const CrossParams p) {
+  const int64_t total = p.m * p.n;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t i = idx / p.n, o = i * p.ld + (idx - i * p.n);
+    const float xv = ld_elem(p.x, p.dtype, o);
+    st_elem(p.y, p.dtype, o, ld_elem(p.x0, p.dtype, o) * (ld_elem(p.u, p.dtype, o) + p.diag * xv) + xv);
+  }
+}
+
+// Backward: grid = (column strips of 64*V, row chunks).  Each thread owns V
+// columns and walks its rows, so the bias gradient is a per-thread register sum
+// followed by one atomic per thread.
+template <typename T, int V>
+__global__ __launch_bounds__(64) void cross_bwd_vec_kernel(const CrossParams p, int rows_per_block) {
+  const int64_t col = ((int64_t)blockIdx.x * 64 + threadIdx.x) * V;
+  if (col >= p.n) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(p.m, r0 + rows_per_block);
+  float db[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) db[k] = 0.0f;
+  for (int64_t i = r0; i < r1; ++i) {
+    const int64_t o = i * p.ld + col;
+    float g[V], u[V], x0[V], x[V], du[V], t[V];
+    RowVec<T, V>::load(p.g, o, g);
+    RowVec<T, V>::load(p.x0, o, x0);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      du[k] = g[k] * x0[k];
+      db[k] += du[k];
+    }
+    if (p.du) RowVec<T, V>::store(p.du, o, du);
+    if (p.dx0) {
+      RowVec<T, V>::load(p.u, o, u);
+      RowVec<T, V>::load(p.x, o, x);
+      if (p.dx0_acc) RowVec<T, V>::load(p.dx0, o, t);
+#pragma unroll
+      for (int k = 0; k < V; ++k) t[k] = (p.dx0_acc ? t[k] : 0.0f) + g[k] * (u[k] + p.diag * x[k]);
+      RowVec<T, V>::store(p.dx0, o, t);
+    }
+    if (p.dxd) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) t[k] = g[k] + p.diag * du[k];
+      RowVec<T, V>::store(p.dxd, o, t);
+    }
+  }
+  if (p.dbias)
+#pragma unroll
+    for (int k = 0; k < V; ++k) atomicAdd(p.dbias + col + k, db[k]);
+}
+
+__global__ __launch_bounds__(64) void cross_bwd_scalar_kernel(const CrossParams p, int rows_per_block) {
+  const int64_t col = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (col >= p.n) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(p.m, r0 + rows_per_block);
+  float db = 0.0f;
+  for (int64_t i = r0; i < r1; ++i) {
+    const int64_t o = i * p.ld + col;
+    const float g = ld_elem(p.g, p.dtype, o);
+    const float du = g * ld_elem(p.x0, p.dtype, o);
+    db += du;
+    if (p.du) st_elem(p.du, p.dtype, o, du);
+    if (p.dx0) {
+      const float uf = ld_elem(p.u, p.dtype, o) + p.diag * ld_elem(p.x, p.dtype, o);
+      st_elem(p.dx0, p.dtype, o, (p.dx0_acc ? ld_elem(p.dx0, p.dtype, o) : 0.0f) + g * uf);
+    }
+    if (p.dxd) st_elem(p.dxd, p.dtype, o, g + p.diag * du);
+  }
+  if (p.dbias) atomicAdd(p.dbias + col, db);
+}
+
+__global__ __launch_bounds__(64) void colsum_kernel(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
+                                                    float* out, int rows_per_block) {
+  const int64_t col = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (col >= n) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(m, r0 + rows_per_block);
+  float s = 0.0f;
+  for (int64_t i = r0; i < r1; ++i) s += ld_elem(a, dtype, i * lda + col);
+  atomicAdd(out + col, s);
+}
+
+bool vec_ok(const CrossParams& p, int v, std::initializer_list<const void*> ptrs) {
+  if (p.n % v || p.ld % v) return false;
+  for (const void* q : ptrs)
+    if (q && (reinterpret_cast<uintptr_t>(q) & 15)) return false;
+  return true;
+}
+
+}  // namespace
+}  // namespace krs
+
+using namespace krs;
+
+extern "C" size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km) {
+  (void)a_is_km;
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
+  const int s = pick_splits(m, n, k);
+  return s > 1 ? (size_t)s * (size_t)m * (size_t)n * sizeof(float) : 0;
+}
+
+extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, int64_t ldb, int b_is_nk,
+                        void* c, int64_t ldc, int64_t m, int64_t n, int64_t k, int in_dtype, int out_dtype,
+                        const krs_gemm_epilogue* epilogue, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  KRS_REQUIRE(a && b && c, "krs_gemm: null operand");
+  KRS_REQUIRE(m >= 0 && n >= 0 && k >= 0, "krs_gemm: negative size");
+  KRS_REQUIRE((in_dtype == KRS_F32 || in_dtype == KRS_BF16) && (out_dtype == KRS_F32 || out_dtype == KRS_BF16),
+              "krs_gemm: bad dtype");
+  if (epilogue && epilogue->x0) KRS_REQUIRE(epilogue->x, "krs_gemm: cross epilogue needs x with x0");
+  if (m == 0 || n == 0) return KRS_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GemmParams p;
+  p.a = reinterpret_cast<const char*>(a); p.lda = lda; p.a_km = a_is_km != 0;
+  p.b = reinterpret_cast<const char*>(b); p.ldb = ldb; p.b_nk = b_is_nk != 0;
+  p.c = reinterpret_cast<char*>(c); p.ldc = ldc; p.m = m; p.n = n; p.k = k; p.out_dtype = out_dtype;
+  p.has_ep = epilogue != nullptr;
+  if (epilogue) p.ep = *epilogue; else memset(&p.ep, 0, sizeof(p.ep));
+  p.splits = 1; p.k_per_split = k; p.slabs = nullptr;
+  const int es = in_dtype == KRS_BF16 ? 2 : 4;
+  if (k > 0 && mfma_eligible(p, es) && !(p.a_km && p.b_nk)) {
+    const int s = pick_splits(m, n, k);
+    if (s > 1) {
+      const size_t need = (size_t)s * m * n * sizeof(float);
+      if (!workspace || workspace_bytes < need)
+        return fail(KRS_ERR_WORKSPACE, "krs_gemm: split-K needs %zu workspace bytes, got %zu", need, workspace_bytes);
+      const int64_t bk = ROW_BYTES / es;
+      p.splits = s;
+      p.k_per_split = ceil_div(ceil_div(k, s), bk) * bk;
+      p.slabs = reinterpret_cast<float*>(workspace);
+    }
+    const int rc = es == 2 ? launch_mfma<2>(p, st) : launch_mfma<4>(p, st);
+    if (rc != KRS_OK) return rc;
+    if (p.splits > 1) {
+      hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p);
+      KRS_CHECK_LAUNCH("gemm_slab_reduce_kernel");
+    }
+    return KRS_OK;
+  }
+  hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p, in_dtype);
+  KRS_CHECK_LAUNCH("gemm_generic_kernel");
+  return KRS_OK;
+}
+
+extern "C" int krs_cross_epilogue_fwd(const void* u, const void* x0, const void* x, void* y, int64_t m,
+                                      int64_t n, int64_t ld, float diag_scale, int dtype, void* stream) {
+  KRS_REQUIRE(u && x0 && x && y, "cross_epilogue_fwd: null operand");
+  KRS_REQUIRE(m >= 0 && n >= 0 && ld >= n, "cross_epilogue_fwd: bad sizes");
+  if (m == 0 || n == 0) return KRS_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  CrossParams p{};
+  p.u = u; p.x0 = x0; p.x = x; p.y = y; p.m = m; p.n = n; p.ld = ld; p.diag = diag_scale; p.dtype = dtype;
+  const int v = dtype == KRS_BF16 ? 8 : 4;
+  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(m * n / (vec_ok(p, v, {u, x0, x, y}) ? v : 1), 256), 16384);
+  if (vec_ok(p, v, {u, x0, x, y})) {
+    if (dtype == KRS_BF16)
+      hipLaunchKernelGGL((cross_fwd_vec_kernel<uint16_t, 8>), dim3(blocks), dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((cross_fwd_vec_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(cross_fwd_scalar_kernel, dim3(blocks), dim3(256), 0, st, p);
+  }
+  KRS_CHECK_LAUNCH("cross_fwd_kernel");
+  return KRS_OK;
+}
+
+extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const void* x, void* du,
+                                      void* dx0, int dx0_accumulate, void* dxd, float* dbias, int64_t m,
+                                      int64_t n, int64_t ld, float diag_scale, int dtype, void* stream) {
+  KRS_REQUIRE(g && x0, "cross_epilogue_bwd: null g/x0");
+  KRS_REQUIRE(!dx0 || (u && x), "cross_epilogue_bwd: dx0 needs u and x");
+  KRS_REQUIRE(m >= 0 && n >= 0 && ld >= n, "cross_epilogue_bwd: bad sizes");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dbias) KRS_HIP(hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), st));
+  if (m == 0 || n == 0) return KRS_OK;
+  CrossParams p{};
+  p.g = g; p.u = u; p.x0 = x0; p.x = x; p.du = du; p.dx0 = dx0; p.dxd = dxd; p.dbias = dbias;
+  p.dx0_acc = dx0_accumulate; p.m = m; p.n = n; p.ld = ld; p.diag = diag_scale; p.dtype = dtype;
+  const int v = dtype == KRS_BF16 ? 8 : 4;
+  const bool vec = vec_ok(p, v, {g, u, x0, x, du, dx0, dxd});
+  const int64_t cols = vec ? n / v : n;
+  const int64_t strips = ceil_div(cols, 64);
+  // enough row chunks to fill the chip, few enough to keep the atomics cheap
+  int64_t chunks = ceil_div(4096, strips);
+  if (chunks > m) chunks = m;
+  const int rows_per_block = (int)ceil_div(m, chunks);
+  const dim3 grid((unsigned)strips, (unsigned)ceil_div(m, rows_per_block));
+  if (vec) {
+    if (dtype == KRS_BF16)
+      hipLaunchKernelGGL((cross_bwd_vec_kernel<uint16_t, 8>), grid, dim3(64), 0, st, p, rows_per_block);
+    else
+      hipLaunchKernelGGL((cross_bwd_vec_kernel<float, 4>), grid, dim3(64), 0, st, p, rows_per_block);
+  } else {
+    hipLaunchKernelGGL(cross_bwd_scalar_kernel, grid, dim3(64), 0, st, p, rows_per_block);
+  }
+  KRS_CHECK_LAUNCH("cross_bwd_kernel");
+  return KRS_OK;
+}
+
+extern "C" int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype, float* out,
+                          void* stream) {
+  KRS_REQUIRE(a && out, "colsum: null operand");
+  KRS_REQUIRE(m >= 0 && n >= 0, "colsum: bad sizes");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n == 0) return KRS_OK;
+  KRS_HIP(hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st));
+  if (m == 0) return KRS_OK;
+  const int64_t strips = ceil_div(n, 64);
+  int64_t chunks = ceil_div(4096, strips);
+  if (chunks > m) chunks = m;
+  const int rows_per_block = (int)ceil_div(m, chunks);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)strips, (unsigned)ceil_div(m, rows_per_block)), dim3(64), 0,
+                     st, a, lda, m, n, dtype, out, rows_per_block);
+  KRS_CHECK_LAUNCH("colsum_kernel");
+  return KRS_OK;
+}

@@ -1,0 +1,178 @@
+"""Host side of K3/K4/K5: thin torch wrappers over krs_gemm, the cross epilogue
+kernels, krs_dot_interaction_{fwd,bwd} and krs_mod_bucketize.
+
+Everything here marshals raw device pointers into the C ABI (include/krs.h);
+torch only provides memory and the current stream.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import torch
+
+from keras_rs_amd import _lib as L
+
+ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID,
+        "tanh": L.ACT_TANH}
+
+
+def _rowmajor(t: torch.Tensor, what: str) -> torch.Tensor:
+    L.require_device(t, what)
+    if t.dim() != 2:
+        raise L.KrsError(f"{what}: expected a matrix, got shape {tuple(t.shape)}")
+    return t if t.stride(1) == 1 else t.contiguous()
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, a_is_km: bool = False, b_is_nk: bool = False,
+         out_dtype: torch.dtype | None = None, bias: torch.Tensor | None = None, act: int = L.ACT_NONE,
+         diag_scale: float = 0.0, x0: torch.Tensor | None = None, x: torch.Tensor | None = None,
+         want_u: bool = False, r: torch.Tensor | None = None, beta: float = 1.0,
+         out: torch.Tensor | None = None):
+    """C = epilogue(A @ B) (include/krs.h: krs_gemm).  Returns (C, u_or_None).
+
+    a: [M,K] (or [K,M] when a_is_km);  b: [K,N] (or [N,K] when b_is_nk)."""
+    a = _rowmajor(a, "gemm A")
+    b = _rowmajor(b, "gemm B")
+    if a.dtype != b.dtype:
+        raise L.KrsError("gemm: A and B must share a dtype")
+    m, k = (a.shape[1], a.shape[0]) if a_is_km else (a.shape[0], a.shape[1])
+    kb, n = (b.shape[1], b.shape[0]) if b_is_nk else (b.shape[0], b.shape[1])
+    if k != kb:
+        raise L.KrsError(f"gemm: inner dimensions differ ({k} vs {kb})")
+    odt = out_dtype or a.dtype
+    c = out if out is not None else torch.empty((m, n), dtype=odt, device=a.device)
+    ep = L.GemmEpilogue()
+    keep = []
+    if bias is not None:
+        bias = bias.float().contiguous()
+        keep.append(bias)
+        ep.bias = bias.data_ptr()
+    ep.act = act
+    ep.diag_scale = float(diag_scale or 0.0)
+    if x0 is not None:
+        x0 = _rowmajor(x0, "gemm x0")
+        x = _rowmajor(x, "gemm x")
+        if x0.stride(0) != x.stride(0):
+            x0, x = x0.contiguous(), x.contiguous()
+        if x0.dtype != odt or x.dtype != odt:
+            raise L.KrsError("gemm: x0/x must have the output dtype")
+        keep += [x0, x]
+        ep.x0, ep.x, ep.ldx = x0.data_ptr(), x.data_ptr(), x.stride(0)
+    u = None
+    if want_u:
+        u = torch.empty((m, n), dtype=odt, device=a.device)
+        ep.u_out, ep.ldu = u.data_ptr(), u.stride(0)
+    if r is not None:
+        r = _rowmajor(r, "gemm R")
+        if r.dtype != odt:
+            raise L.KrsError("gemm: R must have the output dtype")
+        keep.append(r)
+        ep.r, ep.ldr, ep.beta = r.data_ptr(), r.stride(0), float(beta)
+    wsb = L.lib().krs_gemm_workspace_bytes(C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int(int(a_is_km)))
+    ws = torch.empty(int(wsb), dtype=torch.uint8, device=a.device) if wsb else None
+    rc = L.lib().krs_gemm(
+        L.ptr(a), C.c_int64(a.stride(0)), C.c_int(int(a_is_km)),
+        L.ptr(b), C.c_int64(b.stride(0)), C.c_int(int(b_is_nk)),
+        L.ptr(c), C.c_int64(c.stride(0)), C.c_int64(m), C.c_int64(n), C.c_int64(k),
+        C.c_int(L.fdtype(a)), C.c_int(L.fdtype(c)), C.byref(ep),
+        L.ptr(ws), C.c_size_t(int(wsb)), L.stream_ptr())
+    L.check(rc, "krs_gemm")
+    return c, u
+
+
+def cross_epilogue_fwd(u, x0, x, diag_scale=0.0):
+    u, x0, x = (_rowmajor(t, "cross_epilogue_fwd").contiguous() for t in (u, x0, x))
+    y = torch.empty_like(x)
+    m, n = x.shape
+    rc = L.lib().krs_cross_epilogue_fwd(L.ptr(u), L.ptr(x0), L.ptr(x), L.ptr(y), C.c_int64(m), C.c_int64(n),
+                                        C.c_int64(n), C.c_float(diag_scale or 0.0), C.c_int(L.fdtype(x)),
+                                        L.stream_ptr())
+    L.check(rc, "krs_cross_epilogue_fwd")
+    return y
+
+
+def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, dx0_into: torch.Tensor | None = None,
+                       want_du=True, want_dxd=True, want_dbias=True):
+    """Returns (du, dx0, dxd, dbias); dx0 accumulates into `dx0_into` when given."""
+    g, u, x0, x = (_rowmajor(t, "cross_epilogue_bwd").contiguous() for t in (g, u, x0, x))
+    m, n = x.shape
+    du = torch.empty_like(x) if want_du else None
+    dx0 = dx0_into if dx0_into is not None else torch.empty_like(x)
+    if not dx0.is_contiguous():
+        raise L.KrsError("cross_epilogue_bwd: dx0 buffer must be contiguous")
+    dxd = torch.empty_like(x) if want_dxd else None
+    dbias = torch.empty(n, dtype=torch.float32, device=x.device) if want_dbias else None
+    rc = L.lib().krs_cross_epilogue_bwd(
+        L.ptr(g), L.ptr(u), L.ptr(x0), L.ptr(x), L.ptr(du), L.ptr(dx0), C.c_int(int(dx0_into is not None)),
+        L.ptr(dxd), L.ptr(dbias), C.c_int64(m), C.c_int64(n), C.c_int64(n), C.c_float(diag_scale or 0.0),
+        C.c_int(L.fdtype(x)), L.stream_ptr())
+    L.check(rc, "krs_cross_epilogue_bwd")
+    return du, dx0, dxd, dbias
+
+
+def colsum(a: torch.Tensor) -> torch.Tensor:
+    a = _rowmajor(a, "colsum")
+    out = torch.empty(a.shape[1], dtype=torch.float32, device=a.device)
+    rc = L.lib().krs_colsum(L.ptr(a), C.c_int64(a.stride(0)), C.c_int64(a.shape[0]), C.c_int64(a.shape[1]),
+                            C.c_int(L.fdtype(a)), L.ptr(out), L.stream_ptr())
+    L.check(rc, "krs_colsum")
+    return out
+
+
+def _ptr_table(ts: Sequence[torch.Tensor]):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), (C.c_int64 * len(ts))(*[t.stride(0) for t in ts])
+
+
+def dot_out_cols(n_feats: int, self_interaction: bool, skip_gather: bool) -> int:
+    if skip_gather:
+        return n_feats * n_feats
+    return n_feats * (n_feats + 1) // 2 if self_interaction else n_feats * (n_feats - 1) // 2
+
+
+def dot_interaction_fwd(feats: Sequence[torch.Tensor], self_interaction=False, skip_gather=False):
+    feats = [_rowmajor(f, "dot_interaction feature") for f in feats]
+    batch, dim = feats[0].shape
+    out = torch.empty((batch, dot_out_cols(len(feats), self_interaction, skip_gather)), dtype=feats[0].dtype,
+                      device=feats[0].device)
+    ptrs, lds = _ptr_table(feats)
+    rc = L.lib().krs_dot_interaction_fwd(ptrs, lds, C.c_int(len(feats)), C.c_int64(batch), C.c_int(dim),
+                                         C.c_int(L.fdtype(feats[0])), C.c_int(int(self_interaction)),
+                                         C.c_int(int(skip_gather)), L.ptr(out), C.c_int64(out.stride(0)),
+                                         L.stream_ptr())
+    L.check(rc, "krs_dot_interaction_fwd")
+    return out
+
+
+def dot_interaction_bwd(feats: Sequence[torch.Tensor], grad_out: torch.Tensor, self_interaction=False,
+                        skip_gather=False):
+    feats = [_rowmajor(f, "dot_interaction feature") for f in feats]
+    grad_out = _rowmajor(grad_out, "dot_interaction grad")
+    batch, dim = feats[0].shape
+    grads = [torch.empty((batch, dim), dtype=f.dtype, device=f.device) for f in feats]
+    ptrs, lds = _ptr_table(feats)
+    gptrs, glds = _ptr_table(grads)
+    rc = L.lib().krs_dot_interaction_bwd(ptrs, lds, C.c_int(len(feats)), C.c_int64(batch), C.c_int(dim),
+                                         C.c_int(L.fdtype(feats[0])), C.c_int(int(self_interaction)),
+                                         C.c_int(int(skip_gather)), L.ptr(grad_out),
+                                         C.c_int64(grad_out.stride(0)), gptrs, glds, L.stream_ptr())
+    L.check(rc, "krs_dot_interaction_bwd")
+    return grads
+
+
+def mod_bucketize(ids: torch.Tensor, n_shards: int):
+    """Stable grouping of ids by id % n_shards.  Returns (local_ids, perm, bucket_counts[int64])."""
+    L.require_device(ids, "ids")
+    ids = ids.contiguous().reshape(-1)
+    nnz = ids.numel()
+    local = torch.empty_like(ids)
+    perm = torch.empty(nnz, dtype=torch.int32, device=ids.device)
+    counts = torch.empty(n_shards, dtype=torch.int64, device=ids.device)
+    wsb = L.lib().krs_mod_bucketize_workspace_bytes(C.c_int64(nnz), C.c_int(n_shards))
+    ws = torch.empty(max(int(wsb), 1), dtype=torch.uint8, device=ids.device)
+    rc = L.lib().krs_mod_bucketize(L.ptr(ids), C.c_int(L.itype(ids)), C.c_int64(nnz), C.c_int(n_shards),
+                                   L.ptr(local), L.ptr(perm), L.ptr(counts), L.ptr(ws), C.c_size_t(ws.numel()),
+                                   L.stream_ptr())
+    L.check(rc, "krs_mod_bucketize")
+    return local, perm, counts

@@ -1,0 +1,169 @@
+"""K3 / K4 / K5 parity: krs_gemm (+ fused cross epilogue), cross elementwise kernels,
+DotInteraction fwd/bwd and MOD bucketise vs the CPU oracle, through the C ABI."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import krs_oracle as ko
+from tests.helpers import to_f32, to_np
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+
+
+def _t(a, dt=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dt).to(DEV)
+
+
+def _tol(dt, k):
+    # bf16: inputs exact, fp32 accumulate (different order than the oracle), one rounding of the result
+    if dt == torch.bfloat16:
+        return dict(rtol=2 ** -6, atol=2e-2 * max(1.0, k ** 0.5 / 8))
+    return dict(rtol=2e-5, atol=2e-5 * max(1.0, k ** 0.5 / 4))  # north-star: 1e-5 class for fp32
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 3, 3), (5, 7, 9), (128, 128, 64), (130, 200, 72), (256, 512, 512),
+                                   (300, 136, 1000), (64, 3456, 512)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
+def test_gemm_layouts(m, n, k, dt, layout):
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(m * 31 + n * 7 + k)
+    a = _t(rng.uniform(-1, 1, (m, k)), dt)
+    b = _t(rng.uniform(-1, 1, (k, n)), dt)
+    a_in = a.t().contiguous() if layout == "tn" else a
+    b_in = b.t().contiguous() if layout == "nt" else b
+    c, _ = D.gemm(a_in, b_in, a_is_km=layout == "tn", b_is_nk=layout == "nt")
+    exp, _ = ko.gemm(to_np(a), to_np(b), m, n, k)
+    np.testing.assert_allclose(to_f32(to_np(c)), to_f32(exp), **_tol(dt, k))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [None, "relu", "sigmoid", "tanh"])
+@pytest.mark.parametrize("m,d,p", [(64, 128, 128), (200, 256, 64), (33, 24, 24)])
+def test_gemm_cross_epilogue(dt, act, m, d, p):
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(7)
+    h = _t(rng.uniform(-1, 1, (m, p)), dt)
+    kern = _t(rng.uniform(-0.2, 0.2, (p, d)), dt)
+    bias = _t(rng.uniform(-0.5, 0.5, (d,)))
+    x0 = _t(rng.uniform(-1, 1, (m, d)), dt)
+    x = _t(rng.uniform(-1, 1, (m, d)), dt)
+    y, u = D.gemm(h, kern, bias=bias, act=D.ACTS[act], diag_scale=0.3, x0=x0, x=x, want_u=True)
+    ey, eu = ko.gemm(to_np(h), to_np(kern), m, d, p, bias=to_np(bias), act=act, diag_scale=0.3,
+                     x0=to_np(x0), x=to_np(x), want_u=True)
+    np.testing.assert_allclose(to_f32(to_np(y)), to_f32(ey), **_tol(dt, p))
+    np.testing.assert_allclose(to_f32(to_np(u)), to_f32(eu), **_tol(dt, p))
+
+
+def test_gemm_residual_and_fp32_out_from_bf16_and_splitk():
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(11)
+    # weight-gradient shape: contraction over a long batch axis -> split-K slabs
+    B, p, d = 8192, 128, 256
+    h = _t(rng.uniform(-1, 1, (B, p)), torch.bfloat16)
+    dz = _t(rng.uniform(-1, 1, (B, d)), torch.bfloat16)
+    dw, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)
+    exp = to_f32(to_np(h)).astype(np.float64).T @ to_f32(to_np(dz)).astype(np.float64)
+    np.testing.assert_allclose(dw.cpu().numpy(), exp, rtol=1e-4, atol=5e-3)
+    dw2, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)
+    assert torch.equal(dw, dw2)  # slab reduction is deterministic
+    # residual epilogue: C = A@B + beta*R
+    a = _t(rng.uniform(-1, 1, (96, 64)))
+    b = _t(rng.uniform(-1, 1, (64, 40)))
+    r = _t(rng.uniform(-1, 1, (96, 40)))
+    c, _ = D.gemm(a, b, r=r, beta=0.5)
+    np.testing.assert_allclose(c.cpu().numpy(), (a @ b + 0.5 * r).cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", KAT["feature_cross"]["cases"], ids=lambda c: c["name"])
+def test_feature_cross_kat_through_hip(case):
+    from keras_rs_amd import dense_ops as D
+
+    fc = KAT["feature_cross"]
+    x0 = _t(fc["x0"])
+    x = x0 if case["one_input"] else _t(fc["x"])
+    d, p = 3, case["projection_dim"]
+    h = x
+    if p is not None:
+        h, _ = D.gemm(x, torch.ones(d, p, device=DEV))
+    y, _ = D.gemm(h, torch.ones(h.shape[1], d, device=DEV), bias=torch.zeros(d, device=DEV),
+                  diag_scale=case["diag_scale"], x0=x0, x=x)
+    np.testing.assert_allclose(y.cpu().numpy(), np.array(case["expected"], np.float32), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,n", [(37, 24), (64, 128), (5, 3)])
+def test_cross_elementwise_fwd_bwd(dt, m, n):
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(3)
+    g, u, x0, x = (_t(rng.uniform(-1, 1, (m, n)), dt) for _ in range(4))
+    y = D.cross_epilogue_fwd(u, x0, x, 0.25)
+    np.testing.assert_array_equal(to_np(y), ko.cross_epilogue_fwd(to_np(u), to_np(x0), to_np(x), 0.25))
+    acc = _t(rng.uniform(-1, 1, (m, n)), dt)
+    acc0 = acc.clone()
+    du, dx0, dxd, dbias = D.cross_epilogue_bwd(g, u, x0, x, 0.25, dx0_into=acc)
+    edu, edx0, edxd, edb = ko.cross_epilogue_bwd(to_np(g), to_np(u), to_np(x0), to_np(x), 0.25,
+                                                 dx0_init=to_np(acc0))
+    np.testing.assert_array_equal(to_np(du), edu)
+    np.testing.assert_array_equal(to_np(dx0), edx0)
+    np.testing.assert_array_equal(to_np(dxd), edxd)
+    np.testing.assert_allclose(dbias.cpu().numpy(), edb, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(D.colsum(g).cpu().numpy(), ko.colsum(to_np(g)), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", KAT["dot_interaction"]["cases"],
+                         ids=lambda c: f"self{int(c['self_interaction'])}_skip{int(c['skip_gather'])}")
+def test_dot_interaction_kat_through_hip(case):
+    from keras_rs_amd import dense_ops as D
+
+    feats = [_t(f) for f in KAT["dot_interaction"]["inputs"]]
+    out = D.dot_interaction_fwd(feats, case["self_interaction"], case["skip_gather"])
+    np.testing.assert_allclose(out.cpu().numpy(), np.array(case["expected"], np.float32), rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("F,D_,B", [(3, 5, 4), (27, 128, 70), (8, 64, 33), (32, 16, 9), (40, 8, 5), (4, 256, 6)])
+@pytest.mark.parametrize("si,sg", [(False, False), (True, False), (False, True), (True, True)])
+def test_dot_interaction_fwd_bwd(dt, F, D_, B, si, sg):
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(F * 100 + D_)
+    # features as column views of one concat buffer (the ml_perf layout)
+    buf = _t(rng.uniform(-1, 1, (B, F * D_)), dt)
+    feats = [buf[:, f * D_:(f + 1) * D_] for f in range(F)]
+    out = D.dot_interaction_fwd(feats, si, sg)
+    fn = [np.ascontiguousarray(to_np(buf)[:, f * D_:(f + 1) * D_]) for f in range(F)]
+    exp = ko.dot_interaction_fwd(fn, si, sg)
+    tol = dict(rtol=2 ** -6, atol=3e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(to_f32(to_np(out)), to_f32(exp), **tol)
+    g = _t(rng.uniform(-1, 1, tuple(out.shape)), dt)
+    grads = D.dot_interaction_bwd(feats, g, si, sg)
+    eg = ko.dot_interaction_bwd(fn, to_np(g), si, sg)
+    tol = dict(rtol=2 ** -6, atol=6e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=2e-5)
+    for a, e in zip(grads, eg):
+        np.testing.assert_allclose(to_f32(to_np(a)), to_f32(e), **tol)
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 4, 8, 5])
+@pytest.mark.parametrize("idt", [np.int32, np.int64])
+@pytest.mark.parametrize("nnz", [0, 1, 255, 2048, 100_003])
+def test_mod_bucketize_bit_exact(n_shards, idt, nnz):
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(nnz + n_shards)
+    ids = rng.integers(0, 1_000_000, size=nnz).astype(idt)
+    local, perm, counts = D.mod_bucketize(torch.from_numpy(ids).to(DEV), n_shards)
+    el, ep, ec = ko.mod_bucketize(ids, n_shards)
+    np.testing.assert_array_equal(counts.cpu().numpy(), ec)
+    np.testing.assert_array_equal(perm.cpu().numpy(), ep)
+    np.testing.assert_array_equal(local.cpu().numpy(), el)
