@@ -204,8 +204,8 @@ int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats,
  *      v  = act(v)
  *      v  = x0[m,n] * (v + diag_scale * x[m,n]) + x[m,n]   (x0 != NULL: cross)
  *      v += beta * R[m,n]          (R != NULL: residual / gradient accumulate)
- *   u_out (optional, cross form only) receives act(v)+diag_scale*x, the factor
- *   the backward needs (dx0 = g * u).
+ *   u_out (optional, cross form only) receives v = act(A@B + bias), the
+ *   activation output the backward needs (dx0 = g*(v + diag_scale*x), act'(v)).
  * ------------------------------------------------------------------------- */
 typedef struct krs_gemm_epilogue {
   const float* bias;  /* [N] fp32 or NULL */
@@ -233,17 +233,19 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
 /* Elementwise halves of FeatureCross for the host-composed path (arbitrary
  * pre_activation callables) and for the backward:
  *   fwd: y = x0 * (u + diag_scale*x) + x                     feature_cross.py:191-194
- *   bwd: given g = dL/dy:  du = g * x0 ; dx0 (+)= g * (u+diag*x) ;
- *        dxd = g + diag_scale * du   (the non-GEMM part of dL/dx)
- *        dbias[n] = sum_m du[m,n]    (only valid when act is NONE; optional)
- *   `u` here is the pre-diag factor act(h@K+b). */
+ *   bwd: given g = dL/dy and u = act(z) (z = h@K+b):
+ *        dx0 (+)= g * (u + diag_scale*x)
+ *        dxd = g + diag_scale * g*x0      (the non-GEMM part of dL/dx)
+ *        du  = dz = g*x0 * act'(z), act' written through u (relu: u>0,
+ *              sigmoid: u(1-u), tanh: 1-u^2)
+ *        dbias[n] = sum_m dz[m,n]         (optional) */
 int krs_cross_epilogue_fwd(const void* u, const void* x0, const void* x, void* y,
                            int64_t m, int64_t n, int64_t ld, float diag_scale,
                            int dtype, void* stream);
 int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const void* x,
                            void* du, void* dx0, int dx0_accumulate, void* dxd,
                            float* dbias,
-                           int64_t m, int64_t n, int64_t ld, float diag_scale,
+                           int64_t m, int64_t n, int64_t ld, float diag_scale, int act,
                            int dtype, void* stream);
 
 /* Column sum: out[n] = sum_m a[m,n] (fp32 out).  Dense bias gradient. */

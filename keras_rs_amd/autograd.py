@@ -1,0 +1,150 @@
+"""torch.autograd.Function wrappers: one per op of the hot path, each calling the
+HIP kernels through the C ABI (embedding_ops / dense_ops).  Gradients follow
+SURVEY.md section 8 rows a4 (embedding), a9 (FeatureCross) and a11 (DotInteraction).
+"""
+
+from __future__ import annotations
+
+import torch
+
+from keras_rs_amd import _lib as L
+from keras_rs_amd import dense_ops as D
+
+
+class CrossLayerFn(torch.autograd.Function):
+    """y = x0 * (act(h @ K + b) + diag * x) + x,  h = x (full rank) or x @ U (low rank).
+
+    Reference: FeatureCross.call, feature_cross.py:182-194.  Forward = one MFMA GEMM
+    per Dense with the cross epilogue fused; backward = one elementwise pass
+    (dz, dx0, bias gradient) + the data/weight-gradient GEMMs.
+    Weight layouts are the keras ones: U [d, p], K [p or d, d], b [d]."""
+
+    @staticmethod
+    def forward(ctx, x0, x, down, kernel, bias, diag_scale, act, compute_dtype):
+        same = x is x0 or (x.data_ptr() == x0.data_ptr() and x.shape == x0.shape and x.stride() == x0.stride())
+        cd = compute_dtype
+        x0c = x0.to(cd).contiguous()
+        xc = x0c if same else x.to(cd).contiguous()
+        kc = kernel.to(cd)
+        h = xc
+        dc = None
+        if down is not None:
+            dc = down.to(cd)
+            h, _ = D.gemm(xc, dc)
+        y, u = D.gemm(h, kc, bias=bias, act=act, diag_scale=diag_scale, x0=x0c, x=xc, want_u=True)
+        ctx.save_for_backward(x0c, xc, h if down is not None else None, u, dc, kc)
+        ctx.meta = (diag_scale, act, same, down is not None, bias is not None,
+                    x0.dtype, x.dtype, None if down is None else down.dtype, kernel.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x0c, xc, h, u, dc, kc = ctx.saved_tensors
+        diag, act, same, low_rank, has_bias, x0_dt, x_dt, down_dt, k_dt = ctx.meta
+        g = g.to(x0c.dtype).contiguous()
+        need_dxd = bool(diag)
+        dz, dx0, dxd, dbias = D.cross_epilogue_bwd(g, u, x0c, xc, diag, act=act, want_dxd=need_dxd,
+                                                   want_dbias=has_bias)
+        direct = dxd if need_dxd else g  # dL/dx through "+ x" and "diag * x"
+        if low_rank:
+            dk, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)      # dK = h^T dz     [p, d]
+            dh, _ = D.gemm(dz, kc, b_is_nk=True)                               # dh = dz K^T     [B, p]
+            dd, _ = D.gemm(xc, dh, a_is_km=True, out_dtype=torch.float32)      # dU = x^T dh     [d, p]
+            dx, _ = D.gemm(dh, dc, b_is_nk=True, r=direct, beta=1.0)           # dx = dh U^T + direct
+        else:
+            dk, _ = D.gemm(xc, dz, a_is_km=True, out_dtype=torch.float32)      # dK = x^T dz     [d, d]
+            dd = None
+            dx, _ = D.gemm(dz, kc, b_is_nk=True, r=direct, beta=1.0)           # dx = dz K^T + direct
+        if same:
+            dx0 = dx0 + dx
+            gx0, gx = dx0.to(x0_dt), None
+        else:
+            gx0, gx = dx0.to(x0_dt), dx.to(x_dt)
+        return (gx0, gx, None if dd is None else dd.to(down_dt), dk.to(k_dt),
+                dbias if has_bias else None, None, None, None)
+
+
+class CrossEpilogueFn(torch.autograd.Function):
+    """y = x0 * (u + diag*x) + x for a host-composed u (arbitrary pre_activation callables)."""
+
+    @staticmethod
+    def forward(ctx, u, x0, x, diag_scale):
+        u, x0, x = u.contiguous(), x0.contiguous(), x.contiguous()
+        ctx.save_for_backward(u, x0, x)
+        ctx.diag = diag_scale
+        return D.cross_epilogue_fwd(u, x0, x, diag_scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        u, x0, x = ctx.saved_tensors
+        du, dx0, dxd, _ = D.cross_epilogue_bwd(g.contiguous(), u, x0, x, ctx.diag, want_dbias=False)
+        return du, dx0, dxd, None
+
+
+class DotInteractionFn(torch.autograd.Function):
+    """DotInteraction.call (dot_interaction.py:170-203) and its gradient."""
+
+    @staticmethod
+    def forward(ctx, self_interaction, skip_gather, *feats):
+        ctx.save_for_backward(*feats)
+        ctx.flags = (self_interaction, skip_gather)
+        return D.dot_interaction_fwd(feats, self_interaction, skip_gather)
+
+    @staticmethod
+    def backward(ctx, g):
+        feats = ctx.saved_tensors
+        si, sg = ctx.flags
+        grads = D.dot_interaction_bwd(feats, g, si, sg)
+        return (None, None, *grads)
+
+
+class EmbedBagFn(torch.autograd.Function):
+    """Fused gather+pool over a FusedBags group with the reference's autodiff semantics:
+    dense [V, D] table gradients, computed by the sort-based K2."""
+
+    @staticmethod
+    def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, check_ids, *tables):
+        # `tables` are passed explicitly so autograd tracks them; `bags.tables` hold the same storage
+        err = torch.zeros(1, dtype=torch.int32, device=ids.device) if check_ids else None
+        out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
+                                  out_dtype=out_dtype, want_scale=True, err_flag=err)
+        if check_ids and int(err.item()) & L.FLAG_ID_OUT_OF_RANGE:
+            raise IndexError("embedding id out of range for its table (ids are never clamped)")
+        ctx.bags, ctx.batch, ctx.hots = bags, batch, hots
+        ctx.save_for_backward(ids, offsets, weights, scale)
+        ctx.table_dtypes = [t.dtype for t in tables]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, offsets, weights, scale = ctx.saved_tensors
+        bags = ctx.bags
+        ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
+        grads = bags.backward_dense(ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
+                                    bag_scale=scale)
+        grads = [gr.to(dt) for gr, dt in zip(grads, ctx.table_dtypes)]
+        return (None, None, None, None, None, None, None, None, *grads)
+
+
+class EmbedBagFusedFn(torch.autograd.Function):
+    """Fused gather+pool whose backward applies the per-table optimizer to the touched rows
+    in place (the SparseCore-style path: jax/embedding_lookup.py:174-273 returns updated
+    tables instead of gradients).  `anchor` is a dummy scalar that requires grad so that the
+    backward runs; it receives a zero gradient."""
+
+    @staticmethod
+    def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, optimizer, anchor):
+        out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
+                                  out_dtype=out_dtype, want_scale=True)
+        ctx.bags, ctx.batch, ctx.hots, ctx.optimizer = bags, batch, hots, optimizer
+        ctx.save_for_backward(ids, offsets, weights, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, offsets, weights, scale = ctx.saved_tensors
+        bags = ctx.bags
+        ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
+        bags.backward_fused(ctx.optimizer, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
+                            bag_scale=scale)
+        return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device))

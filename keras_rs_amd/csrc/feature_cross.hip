@@ -72,8 +72,8 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t i, i
     v = apply_act(e.act, v);
     if (e.x0) {
       const float xv = ld_elem(e.x, odt, i * e.ldx + j);
+      if (e.u_out) st_elem(e.u_out, odt, i * e.ldu + j, v);
       const float u = v + e.diag_scale * xv;
-      if (e.u_out) st_elem(e.u_out, odt, i * e.ldu + j, u);
       v = ld_elem(e.x0, odt, i * e.ldx + j) * u + xv;
     }
     if (e.r) v += e.beta * ld_elem(e.r, odt, i * e.ldr + j);
@@ -337,8 +337,18 @@ struct CrossParams {
   int dx0_acc;
   int64_t m, n, ld;
   float diag;
+  int act;
   int dtype;
 };
+
+__device__ __forceinline__ float act_grad_from_output(int act, float u) {
+  switch (act) {
+    case KRS_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
+    case KRS_ACT_SIGMOID: return u * (1.0f - u);
+    case KRS_ACT_TANH: return 1.0f - u * u;
+    default: return 1.0f;
+  }
+}
 
 // one thread per 8 columns; rows strided by gridDim.y*ROWS_PER_BLOCK
 template <typename T, int V>
@@ -408,17 +418,23 @@ __global__ __launch_bounds__(64) void cross_bwd_vec_kernel(const CrossParams p, 
   for (int k = 0; k < V; ++k) db[k] = 0.0f;
   for (int64_t i = r0; i < r1; ++i) {
     const int64_t o = i * p.ld + col;
-    float g[V], u[V], x0[V], x[V], du[V], t[V];
+    float g[V], u[V], x0[V], x[V], gx0[V], dz[V], t[V];
     RowVec<T, V>::load(p.g, o, g);
     RowVec<T, V>::load(p.x0, o, x0);
+    if (p.u) {
+      RowVec<T, V>::load(p.u, o, u);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) u[k] = 0.0f;
+    }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      du[k] = g[k] * x0[k];
-      db[k] += du[k];
+      gx0[k] = g[k] * x0[k];
+      dz[k] = gx0[k] * act_grad_from_output(p.act, u[k]);
+      db[k] += dz[k];
     }
-    if (p.du) RowVec<T, V>::store(p.du, o, du);
+    if (p.du) RowVec<T, V>::store(p.du, o, dz);
     if (p.dx0) {
-      RowVec<T, V>::load(p.u, o, u);
       RowVec<T, V>::load(p.x, o, x);
       if (p.dx0_acc) RowVec<T, V>::load(p.dx0, o, t);
 #pragma unroll
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(64) void cross_bwd_vec_kernel(const CrossParams p, 
     }
     if (p.dxd) {
 #pragma unroll
-      for (int k = 0; k < V; ++k) t[k] = g[k] + p.diag * du[k];
+      for (int k = 0; k < V; ++k) t[k] = g[k] + p.diag * gx0[k];
       RowVec<T, V>::store(p.dxd, o, t);
     }
   }
@@ -445,14 +461,16 @@ __global__ __launch_bounds__(64) void cross_bwd_scalar_kernel(const CrossParams 
   for (int64_t i = r0; i < r1; ++i) {
     const int64_t o = i * p.ld + col;
     const float g = ld_elem(p.g, p.dtype, o);
-    const float du = g * ld_elem(p.x0, p.dtype, o);
-    db += du;
-    if (p.du) st_elem(p.du, p.dtype, o, du);
+    const float gx0 = g * ld_elem(p.x0, p.dtype, o);
+    const float uv = p.u ? ld_elem(p.u, p.dtype, o) : 0.0f;
+    const float dz = gx0 * act_grad_from_output(p.act, uv);
+    db += dz;
+    if (p.du) st_elem(p.du, p.dtype, o, dz);
     if (p.dx0) {
-      const float uf = ld_elem(p.u, p.dtype, o) + p.diag * ld_elem(p.x, p.dtype, o);
+      const float uf = uv + p.diag * ld_elem(p.x, p.dtype, o);
       st_elem(p.dx0, p.dtype, o, (p.dx0_acc ? ld_elem(p.dx0, p.dtype, o) : 0.0f) + g * uf);
     }
-    if (p.dxd) st_elem(p.dxd, p.dtype, o, g + p.diag * du);
+    if (p.dxd) st_elem(p.dxd, p.dtype, o, g + p.diag * gx0);
   }
   if (p.dbias) atomicAdd(p.dbias + col, db);
 }
@@ -554,8 +572,10 @@ extern "C" int krs_cross_epilogue_fwd(const void* u, const void* x0, const void*
 
 extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const void* x, void* du,
                                       void* dx0, int dx0_accumulate, void* dxd, float* dbias, int64_t m,
-                                      int64_t n, int64_t ld, float diag_scale, int dtype, void* stream) {
+                                      int64_t n, int64_t ld, float diag_scale, int act, int dtype,
+                                      void* stream) {
   KRS_REQUIRE(g && x0, "cross_epilogue_bwd: null g/x0");
+  KRS_REQUIRE(act == KRS_ACT_NONE || u, "cross_epilogue_bwd: an activation needs the saved u");
   KRS_REQUIRE(!dx0 || (u && x), "cross_epilogue_bwd: dx0 needs u and x");
   KRS_REQUIRE(m >= 0 && n >= 0 && ld >= n, "cross_epilogue_bwd: bad sizes");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -563,7 +583,7 @@ extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* 
   if (m == 0 || n == 0) return KRS_OK;
   CrossParams p{};
   p.g = g; p.u = u; p.x0 = x0; p.x = x; p.du = du; p.dx0 = dx0; p.dxd = dxd; p.dbias = dbias;
-  p.dx0_acc = dx0_accumulate; p.m = m; p.n = n; p.ld = ld; p.diag = diag_scale; p.dtype = dtype;
+  p.dx0_acc = dx0_accumulate; p.m = m; p.n = n; p.ld = ld; p.diag = diag_scale; p.act = act; p.dtype = dtype;
   const int v = dtype == KRS_BF16 ? 8 : 4;
   const bool vec = vec_ok(p, v, {g, u, x0, x, du, dx0, dxd});
   const int64_t cols = vec ? n / v : n;

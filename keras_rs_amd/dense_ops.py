@@ -93,7 +93,8 @@ def cross_epilogue_fwd(u, x0, x, diag_scale=0.0):
     return y
 
 
-def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, dx0_into: torch.Tensor | None = None,
+def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
+                       dx0_into: torch.Tensor | None = None,
                        want_du=True, want_dxd=True, want_dbias=True):
     """Returns (du, dx0, dxd, dbias); dx0 accumulates into `dx0_into` when given."""
     g, u, x0, x = (_rowmajor(t, "cross_epilogue_bwd").contiguous() for t in (g, u, x0, x))
@@ -107,7 +108,7 @@ def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, dx0_into: torch.Tensor | 
     rc = L.lib().krs_cross_epilogue_bwd(
         L.ptr(g), L.ptr(u), L.ptr(x0), L.ptr(x), L.ptr(du), L.ptr(dx0), C.c_int(int(dx0_into is not None)),
         L.ptr(dxd), L.ptr(dbias), C.c_int64(m), C.c_int64(n), C.c_int64(n), C.c_float(diag_scale or 0.0),
-        C.c_int(L.fdtype(x)), L.stream_ptr())
+        C.c_int(act), C.c_int(L.fdtype(x)), L.stream_ptr())
     L.check(rc, "krs_cross_epilogue_bwd")
     return du, dx0, dxd, dbias
 

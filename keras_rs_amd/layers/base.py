@@ -1,0 +1,409 @@
+"""Minimal Keras-style layer protocol on torch.nn.Module.
+
+Keras is not installed where this runs (and must not be needed on the GPU box),
+so the drop-in layers keep the *surface* of keras.layers.Layer that the
+reference's hot path relies on -- constructor kwargs (`dtype`, `name`),
+`__call__` -> lazy `build(input_shape)` -> `call(...)`, `.weights` in creation
+order, `get_config()/from_config()`, `built`, `supports_masking` -- without
+importing it.  INTEGRATION.md shows how the same classes register as real
+keras layers when keras (torch backend) is present.
+"""
+
+from __future__ import annotations
+
+import itertools
+import math
+from typing import Any, Callable
+
+import torch
+
+_name_counters: dict[str, itertools.count] = {}
+
+
+def _auto_name(prefix: str) -> str:
+    c = _name_counters.setdefault(prefix, itertools.count())
+    i = next(c)
+    return prefix if i == 0 else f"{prefix}_{i}"
+
+
+def default_device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+# --------------------------------------------------------------------------- #
+# dtype policy (keras.DTypePolicy subset: float32 | bfloat16 | mixed_bfloat16)
+# --------------------------------------------------------------------------- #
+class DTypePolicy:
+    def __init__(self, name: str | None = None):
+        name = name or "float32"
+        if isinstance(name, DTypePolicy):
+            name = name.name
+        if isinstance(name, torch.dtype):
+            name = {torch.float32: "float32", torch.bfloat16: "bfloat16"}[name]
+        if name not in ("float32", "bfloat16", "mixed_bfloat16"):
+            raise ValueError(f"Unsupported dtype policy '{name}' (float32, bfloat16, mixed_bfloat16)")
+        self.name = name
+        self.compute_dtype = torch.float32 if name == "float32" else torch.bfloat16
+        self.variable_dtype = torch.bfloat16 if name == "bfloat16" else torch.float32
+
+
+# --------------------------------------------------------------------------- #
+# initializers (the ones the hot path's layers and examples use)
+# --------------------------------------------------------------------------- #
+class Initializer:
+    def __call__(self, shape, dtype=torch.float32, device=None) -> torch.Tensor:
+        raise NotImplementedError
+
+    def get_config(self) -> dict:
+        return {}
+
+    def serialize(self) -> dict:
+        return {"class_name": type(self).__name__, "config": self.get_config()}
+
+    def clone(self) -> "Initializer":
+        return type(self)(**self.get_config())
+
+
+def _fans(shape):
+    if len(shape) < 1:
+        return 1, 1
+    if len(shape) == 1:
+        return shape[0], shape[0]
+    return shape[-2], shape[-1]
+
+
+class Zeros(Initializer):
+    def __call__(self, shape, dtype=torch.float32, device=None):
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+
+class Ones(Initializer):
+    def __call__(self, shape, dtype=torch.float32, device=None):
+        return torch.ones(shape, dtype=dtype, device=device)
+
+
+class Constant(Initializer):
+    def __init__(self, value=0.0):
+        self.value = value
+
+    def __call__(self, shape, dtype=torch.float32, device=None):
+        return torch.full(shape, float(self.value), dtype=dtype, device=device)
+
+    def get_config(self):
+        return {"value": self.value}
+
+
+class RandomUniform(Initializer):
+    def __init__(self, minval=-0.05, maxval=0.05, seed=None):
+        self.minval, self.maxval, self.seed = minval, maxval, seed
+
+    def __call__(self, shape, dtype=torch.float32, device=None):
+        g = None if self.seed is None else torch.Generator().manual_seed(int(self.seed))
+        t = torch.rand(shape, generator=g, dtype=torch.float32) * (self.maxval - self.minval) + self.minval
+        return t.to(dtype).to(device)
+
+    def get_config(self):
+        return {"minval": self.minval, "maxval": self.maxval, "seed": self.seed}
+
+
+class VarianceScaling(Initializer):
+    """keras.initializers.VarianceScaling (default of TableConfig is mode="fan_out",
+    distributed_embedding_config.py:54-56)."""
+
+    def __init__(self, scale=1.0, mode="fan_in", distribution="truncated_normal", seed=None):
+        self.scale, self.mode, self.distribution, self.seed = scale, mode, distribution, seed
+
+    def __call__(self, shape, dtype=torch.float32, device=None):
+        fan_in, fan_out = _fans(tuple(shape))
+        n = {"fan_in": fan_in, "fan_out": fan_out, "fan_avg": (fan_in + fan_out) / 2.0}[self.mode]
+        scale = self.scale / max(1.0, n)
+        g = None if self.seed is None else torch.Generator().manual_seed(int(self.seed))
+        if self.distribution == "uniform":
+            lim = math.sqrt(3.0 * scale)
+            t = (torch.rand(shape, generator=g) * 2.0 - 1.0) * lim
+        elif self.distribution in ("truncated_normal", "normal"):
+            std = math.sqrt(scale) / 0.87962566103423978
+            t = torch.empty(shape)
+            torch.nn.init.trunc_normal_(t, 0.0, std, -2 * std, 2 * std, generator=g)
+        else:  # untruncated_normal
+            t = torch.randn(shape, generator=g) * math.sqrt(scale)
+        return t.to(dtype).to(device)
+
+    def get_config(self):
+        return {"scale": self.scale, "mode": self.mode, "distribution": self.distribution, "seed": self.seed}
+
+
+class GlorotUniform(VarianceScaling):
+    def __init__(self, seed=None):
+        super().__init__(scale=1.0, mode="fan_avg", distribution="uniform", seed=seed)
+
+    def get_config(self):
+        return {"seed": self.seed}
+
+
+class LecunNormal(VarianceScaling):
+    def __init__(self, seed=None):
+        super().__init__(scale=1.0, mode="fan_in", distribution="truncated_normal", seed=seed)
+
+    def get_config(self):
+        return {"seed": self.seed}
+
+
+class CallableInitializer(Initializer):
+    """Wraps a user callable `(shape, dtype) -> array-like`."""
+
+    def __init__(self, fn: Callable):
+        self.fn = fn
+
+    def __call__(self, shape, dtype=torch.float32, device=None):
+        return torch.as_tensor(self.fn(tuple(shape), dtype)).to(dtype).to(device)
+
+    def get_config(self):
+        return {"fn": getattr(self.fn, "__name__", repr(self.fn))}
+
+    def clone(self):
+        return CallableInitializer(self.fn)
+
+
+_INITIALIZERS = {
+    "zeros": Zeros, "ones": Ones, "uniform": RandomUniform, "random_uniform": RandomUniform,
+    "glorot_uniform": GlorotUniform, "variance_scaling": VarianceScaling, "lecun_normal": LecunNormal,
+    "Zeros": Zeros, "Ones": Ones, "RandomUniform": RandomUniform, "GlorotUniform": GlorotUniform,
+    "VarianceScaling": VarianceScaling, "LecunNormal": LecunNormal, "Constant": Constant,
+}
+
+
+def get_initializer(identifier) -> Initializer:
+    if isinstance(identifier, Initializer):
+        return identifier
+    if isinstance(identifier, str):
+        if identifier not in _INITIALIZERS:
+            raise ValueError(f"Unknown initializer '{identifier}'")
+        return _INITIALIZERS[identifier]()
+    if isinstance(identifier, dict):
+        return _INITIALIZERS[identifier["class_name"]](**identifier.get("config", {}))
+    if callable(identifier):
+        return CallableInitializer(identifier)
+    raise ValueError(f"Cannot interpret initializer {identifier!r}")
+
+
+def clone_initializer(init: Initializer) -> Initializer:
+    """keras_rs/src/utils/keras_utils.py:30-51: sublayers get their own initializer object."""
+    return init.clone()
+
+
+# --------------------------------------------------------------------------- #
+# activations fused in the GEMM epilogue
+# --------------------------------------------------------------------------- #
+def relu(x):
+    return torch.relu(x)
+
+
+def sigmoid(x):
+    return torch.sigmoid(x)
+
+
+def tanh(x):
+    return torch.tanh(x)
+
+
+def linear(x):
+    return x
+
+
+_ACTIVATIONS = {None: None, "linear": linear, "relu": relu, "sigmoid": sigmoid, "tanh": tanh}
+
+
+def get_activation(identifier):
+    if identifier is None or callable(identifier):
+        return identifier
+    if identifier not in _ACTIVATIONS:
+        raise ValueError(f"Unknown activation '{identifier}'")
+    return _ACTIVATIONS[identifier]
+
+
+def serialize_activation(fn):
+    if fn is None:
+        return "linear"
+    return getattr(fn, "__name__", repr(fn))
+
+
+# --------------------------------------------------------------------------- #
+# nested-structure helpers (the keras.tree subset DistributedEmbedding needs)
+# --------------------------------------------------------------------------- #
+def _is_nest(x) -> bool:
+    return isinstance(x, (dict, list, tuple)) and not hasattr(x, "_fields_krs_leaf")
+
+
+def flatten_with_path(structure, is_leaf=None, _path=()):
+    """[(path tuple, leaf)], dict keys in sorted order (keras.tree / optree convention)."""
+    if is_leaf is not None and is_leaf(structure):
+        return [(_path, structure)]
+    if isinstance(structure, dict):
+        out = []
+        for k in sorted(structure.keys(), key=str):
+            out += flatten_with_path(structure[k], is_leaf, _path + (k,))
+        return out
+    if isinstance(structure, (list, tuple)):
+        out = []
+        for i, v in enumerate(structure):
+            out += flatten_with_path(v, is_leaf, _path + (i,))
+        return out
+    return [(_path, structure)]
+
+
+def flatten(structure, is_leaf=None):
+    return [v for _, v in flatten_with_path(structure, is_leaf)]
+
+
+def pack_sequence_as(structure, flat, is_leaf=None):
+    it = iter(flat)
+
+    def rec(s):
+        if is_leaf is not None and is_leaf(s):
+            return next(it)
+        if isinstance(s, dict):
+            vals = {k: rec(s[k]) for k in sorted(s.keys(), key=str)}
+            return {k: vals[k] for k in s.keys()}  # keep the caller's insertion order
+        if isinstance(s, tuple):
+            return tuple(rec(v) for v in s)
+        if isinstance(s, list):
+            return [rec(v) for v in s]
+        return next(it)
+
+    return rec(structure)
+
+
+def map_structure_up_to(shallow, fn, *structures, is_leaf=None):
+    """Walks `shallow`; at each of its leaves calls fn(*matching sub-structures of `structures`)
+    (keras.tree.map_structure_up_to)."""
+
+    def rec(s, others):
+        if (is_leaf is not None and is_leaf(s)) or not isinstance(s, (dict, list, tuple)):
+            return fn(*others)
+        if isinstance(s, dict):
+            for o in others:
+                if not isinstance(o, dict) or set(o.keys()) != set(s.keys()):
+                    raise ValueError("The two structures don't have the same nested structure.")
+            return {k: rec(s[k], [o[k] for o in others]) for k in s.keys()}
+        for o in others:
+            if not isinstance(o, (list, tuple)) or len(o) != len(s):
+                raise ValueError("The two structures don't have the same nested structure.")
+        out = [rec(v, [o[i] for o in others]) for i, v in enumerate(s)]
+        return tuple(out) if isinstance(s, tuple) else out
+
+    return rec(shallow, list(structures))
+
+
+def assert_same_structure(a, b, is_leaf=None):
+    def rec(x, y):
+        if (is_leaf is not None and is_leaf(x)) or not isinstance(x, (dict, list, tuple)):
+            if isinstance(y, (dict, list, tuple)) and not (is_leaf is not None and is_leaf(y)):
+                # a leaf on one side may face an array-like on the other; nests must match nests
+                if isinstance(y, dict) or (isinstance(y, (list, tuple)) and any(isinstance(e, (dict, list, tuple)) for e in y)):
+                    raise ValueError("The two structures don't have the same nested structure.")
+            return
+        if isinstance(x, dict):
+            if not isinstance(y, dict) or set(x.keys()) != set(y.keys()):
+                raise ValueError("The two structures don't have the same nested structure.")
+            for k in x:
+                rec(x[k], y[k])
+        else:
+            if not isinstance(y, (list, tuple)) or len(x) != len(y):
+                raise ValueError("The two structures don't have the same nested structure.")
+            for u, v in zip(x, y):
+                rec(u, v)
+
+    rec(a, b)
+
+
+# --------------------------------------------------------------------------- #
+# Layer
+# --------------------------------------------------------------------------- #
+class Layer(torch.nn.Module):
+    """keras.layers.Layer look-alike (see module docstring)."""
+
+    def __init__(self, *, dtype=None, name: str | None = None, trainable: bool = True, device=None,
+                 **kwargs: Any):
+        super().__init__()
+        if kwargs:
+            raise TypeError(f"Unrecognized keyword arguments passed to {type(self).__name__}: {kwargs}")
+        self.dtype_policy = dtype if isinstance(dtype, DTypePolicy) else DTypePolicy(dtype)
+        self.name = name or _auto_name(_snake(type(self).__name__))
+        self.trainable = trainable
+        self.built = False
+        self.supports_masking = False
+        self._device = torch.device(device) if device is not None else default_device()
+        self._weight_order: list[torch.nn.Parameter] = []
+
+    # keras spelling
+    @property
+    def compute_dtype(self):
+        return self.dtype_policy.compute_dtype
+
+    @property
+    def variable_dtype(self):
+        return self.dtype_policy.variable_dtype
+
+    @property
+    def dtype(self):
+        return self.dtype_policy.variable_dtype
+
+    def add_weight(self, shape, initializer, name: str, dtype=None, trainable=True) -> torch.nn.Parameter:
+        init = get_initializer(initializer)
+        value = init(tuple(shape), dtype or self.variable_dtype, self._device)
+        p = torch.nn.Parameter(value, requires_grad=trainable and self.trainable)
+        pname = name.replace(".", "_")
+        if pname in self._parameters:
+            self._parameters[pname] = p  # declared as None in __init__
+        else:
+            self.register_parameter(pname, p)
+        self._weight_order.append(p)
+        return p
+
+    @property
+    def weights(self) -> list[torch.nn.Parameter]:
+        out = list(self._weight_order)
+        for m in self.children():
+            if isinstance(m, Layer):
+                out += m.weights
+        return out
+
+    @property
+    def trainable_weights(self):
+        return [w for w in self.weights if w.requires_grad]
+
+    @property
+    def variables(self):
+        return self.weights
+
+    def build(self, *input_shapes) -> None:
+        self.built = True
+
+    def call(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def _input_shapes(self, args):
+        return tuple(tuple(a.shape) if hasattr(a, "shape") else a for a in args)
+
+    def forward(self, *args, **kwargs):
+        if not self.built:
+            self.build(*self._input_shapes(args))
+            self.built = True
+        return self.call(*args, **kwargs)
+
+    def get_config(self) -> dict:
+        return {"name": self.name, "trainable": self.trainable, "dtype": self.dtype_policy.name}
+
+    @classmethod
+    def from_config(cls, config: dict):
+        return cls(**config)
+
+
+def _snake(name: str) -> str:
+    out = []
+    for i, ch in enumerate(name):
+        if ch.isupper() and i and not name[i - 1].isupper():
+            out.append("_")
+        out.append(ch.lower())
+    return "".join(out)

@@ -1,0 +1,547 @@
+"""DistributedEmbedding on MI355X: drop-in for keras_rs.layers.DistributedEmbedding.
+
+Keeps the public surface of keras_rs/src/layers/embedding/base_distributed_embedding.py
+(constructor :468-477, preprocess :630-729, call :740-808, get_embedding_tables
+:810-825, has_sparsecores :940-988, get_config/from_config :1053-1139) and fills
+the backend hook set `_sparsecore_{init,build,preprocess,call,get_embedding_tables}`
+(:990-1042) with the MI355X path -- the third sibling of the reference's jax/
+and tensorflow/ backends:
+
+  * all features of a placement that share an embedding width are looked up by
+    ONE launch of the fused gather+pool kernel (K1) instead of the per-feature
+    python loop of :910-928;
+  * "default_device" tables keep the reference's autodiff semantics (dense
+    [V, D] gradients on ordinary trainable weights, computed by K2);
+  * "sparsecore" tables take the accelerated path: their per-table optimizer
+    (SGD / Adagrad of TableConfig.optimizer) runs inside the backward on the
+    touched rows only (the design of jax/embedding_lookup.py:174-273);
+  * "auto" resolves to "sparsecore" when an MI355X is present and the table's
+    optimizer can be fused, else "default_device".
+
+`preprocess` may be called concurrently from loader threads
+(examples/ml_perf/main.py:56-87): it only reads immutable configuration.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import threading
+from typing import Any, Sequence
+
+import numpy as np
+import torch
+
+from keras_rs_amd import _lib as L
+from keras_rs_amd.autograd import EmbedBagFn, EmbedBagFusedFn
+from keras_rs_amd.embedding_ops import FusedBags
+from keras_rs_amd.layers import base
+from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig, TableConfig
+from keras_rs_amd.layers.embed_reduce import Ragged, check_shapes_compatible
+
+SUPPORTED_PLACEMENTS = ("auto", "default_device", "sparsecore")
+
+
+# ---- per-table optimizers that K2 can fuse (jax/test_utils.py:474-497) -------------
+@dataclasses.dataclass
+class SGD:
+    learning_rate: float = 0.01
+
+    def get_config(self):
+        return {"learning_rate": self.learning_rate}
+
+
+@dataclasses.dataclass
+class Adagrad:
+    learning_rate: float = 0.001
+    initial_accumulator_value: float = 0.1
+
+    def get_config(self):
+        return {"learning_rate": self.learning_rate, "initial_accumulator_value": self.initial_accumulator_value}
+
+
+def optimizer_from_config(cfg: dict):
+    return {"SGD": SGD, "Adagrad": Adagrad}[cfg["class_name"]](**cfg.get("config", {}))
+
+
+def resolve_fused_optimizer(opt):
+    """-> ("sgd"|"adagrad", lr, acc0) or None when the optimizer cannot be fused."""
+    if isinstance(opt, str):
+        o = opt.lower()
+        if o == "sgd":
+            return ("sgd", 0.01, 0.0)
+        if o == "adagrad":
+            return ("adagrad", 0.001, 0.1)
+        return None
+    name = type(opt).__name__.lower()
+    lr = getattr(opt, "learning_rate", None)
+    if callable(lr) or lr is None:
+        return None
+    if name == "sgd":
+        return ("sgd", float(lr), 0.0)
+    if name == "adagrad":
+        return ("adagrad", float(lr), float(getattr(opt, "initial_accumulator_value", 0.1)))
+    return None
+
+
+@dataclasses.dataclass(eq=True, unsafe_hash=True, order=True)
+class PlacementAndPath:
+    placement: str
+    path: str
+
+
+def _is_feature_config(x) -> bool:
+    return isinstance(x, FeatureConfig)
+
+
+def _is_placement_leaf(x) -> bool:
+    return isinstance(x, PlacementAndPath)
+
+
+@dataclasses.dataclass
+class _Group:
+    """Features of one placement sharing (embedding_dim): one FusedBags, one launch."""
+
+    placement: str
+    dim: int
+    paths: list
+    table_index: list          # per feature: index into `tables`
+    table_configs: list        # unique TableConfig objects
+    bags: FusedBags | None = None
+    fused_kind: str | None = None
+
+
+class DistributedEmbedding(base.Layer):
+    """Args (base_distributed_embedding.py:468-477): feature_configs (nested structure of
+    FeatureConfig), table_stacking ("auto" | names), update_stats, **kwargs."""
+
+    def __init__(self, feature_configs, *, table_stacking="auto", update_stats: bool = False, **kwargs: Any):
+        super().__init__(**kwargs)
+        self._table_stacking = table_stacking
+        self.update_stats = update_stats
+        self._lock = threading.Lock()
+        self._anchor = None
+        self._init_feature_configs_structures(feature_configs)
+        self._groups: dict[str, list[_Group]] = {}
+        self._table_params: dict[int, torch.nn.Parameter] = {}
+        self._table_slots: dict[int, torch.Tensor | None] = {}
+        if "sparsecore" in self._placement_to_path_to_feature_config:
+            self._sparsecore_init(self._placement_to_path_to_feature_config["sparsecore"], table_stacking)
+        if "default_device" in self._placement_to_path_to_feature_config:
+            self._default_device_init(self._placement_to_path_to_feature_config["default_device"], table_stacking)
+
+    # ------------------------------------------------------------------ structure
+    def _init_feature_configs_structures(self, feature_configs) -> None:
+        self._feature_configs = feature_configs
+        placement_and_paths = []
+        self._placement_to_path_to_feature_config: dict[str, dict[str, FeatureConfig]] = {}
+        has_sc = None
+        for path, fc in base.flatten_with_path(feature_configs, is_leaf=_is_feature_config):
+            if not isinstance(fc, FeatureConfig):
+                raise ValueError(f"feature_configs leaves must be FeatureConfig, got {type(fc).__name__}")
+            placement = fc.table.placement
+            if placement == "auto":
+                if has_sc is None:
+                    has_sc = self.has_sparsecores()
+                fusable = resolve_fused_optimizer(fc.table.optimizer) is not None
+                placement = "sparsecore" if (has_sc and fusable) else "default_device"
+            spath = ".".join(str(e) for e in path)
+            if placement not in SUPPORTED_PLACEMENTS:  # base:573-577
+                raise ValueError(f"Feature '{spath}' with name '{fc.name}' has unsupported placement '{placement}'.")
+            placement_and_paths.append(PlacementAndPath(placement, spath))
+            self._placement_to_path_to_feature_config.setdefault(placement, {})[spath] = fc
+        self._feature_deeply_nested_placement_and_paths = base.pack_sequence_as(
+            feature_configs, placement_and_paths, is_leaf=_is_feature_config)
+
+    @classmethod
+    def has_sparsecores(cls) -> bool:
+        """True when the accelerated embedding path is available: on this backend, an
+        AMD GPU visible to torch (the role SparseCores play at base:940-988)."""
+        return bool(torch.cuda.is_available() and getattr(torch.version, "hip", None))
+
+    # ------------------------------------------------------------------ backend hooks
+    def _make_groups(self, placement: str, feature_configs: dict[str, FeatureConfig]) -> None:
+        by_dim: dict[int, _Group] = {}
+        for path, fc in feature_configs.items():
+            g = by_dim.get(fc.table.embedding_dim)
+            if g is None:
+                g = by_dim[fc.table.embedding_dim] = _Group(placement, fc.table.embedding_dim, [], [], [])
+            # one table per distinct TableConfig object (base:836-852)
+            idx = next((i for i, t in enumerate(g.table_configs) if t is fc.table), None)
+            if idx is None:
+                idx = len(g.table_configs)
+                g.table_configs.append(fc.table)
+            g.paths.append(path)
+            g.table_index.append(idx)
+        self._groups[placement] = list(by_dim.values())
+
+    def _sparsecore_init(self, feature_configs, table_stacking) -> None:
+        del table_stacking  # same-width tables are always looked up together here
+        if not self.has_sparsecores():
+            raise self._unsupported_placement_error("sparsecore")
+        for path, fc in feature_configs.items():
+            if resolve_fused_optimizer(fc.table.optimizer) is None:
+                raise NotImplementedError(
+                    f"Table '{fc.table.name}': the 'sparsecore' placement fuses the table optimizer into the "
+                    f"backward and supports SGD and Adagrad; got {fc.table.optimizer!r}. Use "
+                    "placement='default_device' for other optimizers.")
+        self._make_groups("sparsecore", feature_configs)
+
+    def _default_device_init(self, feature_configs, table_stacking) -> None:
+        del table_stacking
+        self._make_groups("default_device", feature_configs)
+
+    def _build_groups(self, placement: str) -> None:
+        for gi, g in enumerate(self._groups.get(placement, [])):
+            if g.bags is not None:
+                continue
+            tables, slots, lrs = [], [], []
+            kinds = set()
+            for tc in g.table_configs:
+                key = id(tc)
+                if key not in self._table_params:
+                    p = self.add_weight((tc.vocabulary_size, tc.embedding_dim), tc.initializer,
+                                        f"{placement}_{tc.name}_embeddings",
+                                        trainable=placement == "default_device")
+                    self._table_params[key] = p
+                    self._table_slots[key] = None
+                p = self._table_params[key]
+                tables.append(p)
+                lr = 0.0
+                if placement == "sparsecore":
+                    kind, lr, acc0 = resolve_fused_optimizer(tc.optimizer)
+                    kinds.add(kind)
+                    if kind == "adagrad" and self._table_slots[key] is None:
+                        self._table_slots[key] = torch.full(p.shape, acc0, dtype=torch.float32, device=p.device)
+                slots.append(self._table_slots[key])
+                lrs.append(lr)
+            if len(kinds) > 1:
+                raise NotImplementedError("Tables of one embedding width on 'sparsecore' must share an optimizer type")
+            g.fused_kind = kinds.pop() if kinds else None
+            fcs = self._placement_to_path_to_feature_config[placement]
+            feats = [(g.table_index[i], fcs[p].table.combiner, i * g.dim) for i, p in enumerate(g.paths)]
+            g.bags = FusedBags(tables, feats, slots=slots, lrs=lrs)
+
+    def _sparsecore_build(self, input_shapes) -> None:
+        del input_shapes
+        self._build_groups("sparsecore")
+        if self._anchor is None:
+            dev = self._groups["sparsecore"][0].bags.tables[0].device
+            self._anchor = torch.zeros((), device=dev, requires_grad=True)
+
+    def _default_device_build(self, input_shapes) -> None:
+        del input_shapes
+        self._build_groups("default_device")
+
+    # preprocess: per group, concatenate the features' ids feature-major into one buffer
+    def _fuse_inputs(self, placement: str, inputs: dict, weights: dict | None):
+        fcs = self._placement_to_path_to_feature_config[placement]
+        out_inputs, out_weights = {}, {}
+        for gi, g in enumerate(self._groups[placement]):
+            dev = g.bags.tables[0].device
+            id_parts, w_parts, hots, lens = [], [], [], []
+            ragged = False
+            batch = None
+            use_w = weights is not None
+            for path in g.paths:
+                x = inputs[path]
+                w = None if weights is None else weights[path]
+                x, w = _ragged_numpy_to_csr(x, w)
+                if isinstance(x, Ragged):
+                    ragged = True
+                    vals = _to_tensor(x.values)
+                    offs = np.asarray(_to_numpy(x.row_offsets), dtype=np.int64)
+                    b = len(offs) - 1
+                    id_parts.append(vals.reshape(-1))
+                    lens.append(np.diff(offs))
+                    hots.append(None)
+                    if w is not None:
+                        w_parts.append(_to_tensor(w.values if isinstance(w, Ragged) else w).reshape(-1))
+                else:
+                    t = _to_tensor(x)
+                    if t.dim() == 1:
+                        # rank-1: no reduction; weights only survive for "sum" (embed_reduce.py:224)
+                        if fcs[path].table.combiner != "sum":
+                            w = None if w is None else torch.ones(t.shape)
+                        t = t.reshape(-1, 1)
+                    elif t.dim() != 2:
+                        raise ValueError(f"Feature '{path}': inputs must be rank 1 or 2, got {tuple(t.shape)}")
+                    b = t.shape[0]
+                    id_parts.append(t.reshape(-1))
+                    hots.append(int(t.shape[1]))
+                    lens.append(np.full(b, t.shape[1], dtype=np.int64))
+                    if w is not None:
+                        wt = _to_tensor(w).float()
+                        if wt.numel() != t.numel():
+                            raise ValueError(f"Feature '{path}': weights shape {tuple(wt.shape)} does not match "
+                                             f"inputs shape {tuple(t.shape)}")
+                        w_parts.append(wt.reshape(-1))
+                if batch is None:
+                    batch = b
+                elif batch != b:
+                    raise ValueError("All features of a DistributedEmbedding call must share the batch size")
+            ids = _cat_index(id_parts).to(dev, non_blocking=True)
+            offsets = None
+            if ragged:
+                offsets = torch.from_numpy(
+                    np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.int32)).to(dev, non_blocking=True)
+                hots_t = None
+            else:
+                hots_t = tuple(hots)
+            key = f"group{gi}"
+            out_inputs[key] = {"ids": ids, "offsets": offsets, "hots": hots_t, "batch": batch}
+            if use_w:
+                if len(w_parts) != len(g.paths):
+                    raise ValueError("weights must be given for every feature or for none")
+                out_weights[key] = torch.cat([p.reshape(-1) for p in w_parts]).float().to(dev, non_blocking=True)
+        res = {"inputs": out_inputs}
+        if weights is not None:
+            res["weights"] = out_weights
+        return res
+
+    def _sparsecore_preprocess(self, inputs, weights, training=False):
+        del training
+        return self._fuse_inputs("sparsecore", inputs, weights)
+
+    def _default_device_preprocess(self, inputs, weights, training=False):
+        del training
+        return self._fuse_inputs("default_device", inputs, weights)
+
+    def _call_groups(self, placement: str, inputs: dict, weights: dict | None):
+        outputs = {}
+        for gi, g in enumerate(self._groups[placement]):
+            key = f"group{gi}"
+            fi = inputs[key]
+            w = None if weights is None else weights[key]
+            out_dtype = self.compute_dtype
+            if placement == "sparsecore":
+                out = EmbedBagFusedFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w, out_dtype,
+                                            g.fused_kind, self._anchor)
+            else:
+                out = EmbedBagFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w, out_dtype,
+                                       False, *g.bags.tables)
+            for i, path in enumerate(g.paths):
+                outputs[path] = out[:, i * g.dim:(i + 1) * g.dim]
+        return outputs
+
+    def _sparsecore_call(self, inputs, weights=None, training=False):
+        del training
+        return self._call_groups("sparsecore", inputs, weights)
+
+    def _default_device_call(self, inputs, weights=None, training=False):
+        del training
+        return self._call_groups("default_device", inputs, weights)
+
+    def _get_tables(self, placement: str) -> dict:
+        tables = {}
+        for g in self._groups.get(placement, []):
+            for tc in g.table_configs:
+                tables[tc.name] = self._table_params[id(tc)].detach()
+        return tables
+
+    def _sparsecore_get_embedding_tables(self):
+        return self._get_tables("sparsecore")
+
+    def _default_device_get_embedding_tables(self):
+        return self._get_tables("default_device")
+
+    # ------------------------------------------------------------------ public API
+    def _input_shapes(self, args):
+        inputs = args[0]
+        if self._is_preprocessed(inputs):
+            return (inputs,)
+        return (base.map_structure_up_to(self._feature_configs, lambda fc, x: _shape_of(x), self._feature_configs,
+                                         inputs, is_leaf=_is_feature_config),)
+
+    def build(self, input_shapes=None, *_) -> None:
+        if self.built:
+            return
+        with self._lock:
+            if self.built:
+                return
+            if input_shapes is not None:
+                self._verify_input_shapes(input_shapes)
+            if "sparsecore" in self._placement_to_path_to_feature_config:
+                self._sparsecore_build(None)
+            if "default_device" in self._placement_to_path_to_feature_config:
+                self._default_device_build(None)
+            self.built = True
+
+    def preprocess(self, inputs, weights=None, training: bool = False):
+        """Bundles the (possibly ragged, possibly host-resident) inputs of every placement
+        into the fused feature-major form the kernels consume (base:630-729)."""
+        base.assert_same_structure(self._feature_configs, inputs, is_leaf=_is_feature_config)
+        if weights is not None:
+            base.assert_same_structure(self._feature_configs, weights, is_leaf=_is_feature_config)
+        if not self.built:
+            self.build(self._input_shapes((inputs,))[0])
+
+        def to_placement_to_path(tensors):
+            result = {p: {} for p in self._placement_to_path_to_feature_config}
+            base.map_structure_up_to(
+                self._feature_deeply_nested_placement_and_paths,
+                lambda pp, x: result[pp.placement].__setitem__(pp.path, x),
+                self._feature_deeply_nested_placement_and_paths, tensors, is_leaf=_is_placement_leaf)
+            return result
+
+        p_inputs = to_placement_to_path(inputs)
+        p_weights = to_placement_to_path(weights) if weights is not None else None
+        pre = {}
+        if "sparsecore" in p_inputs:
+            pre["sparsecore"] = self._sparsecore_preprocess(
+                p_inputs["sparsecore"], p_weights["sparsecore"] if p_weights is not None else None, training)
+        if "default_device" in p_inputs:
+            pre["default_device"] = self._default_device_preprocess(
+                p_inputs["default_device"], p_weights["default_device"] if p_weights is not None else None, training)
+        return {"preprocessed_inputs_per_placement": pre}
+
+    def _is_preprocessed(self, inputs) -> bool:
+        return isinstance(inputs, dict) and "preprocessed_inputs_per_placement" in inputs
+
+    def call(self, inputs, weights=None, training: bool = False):
+        pre = inputs if self._is_preprocessed(inputs) else self.preprocess(inputs, weights, training)
+        pre = pre["preprocessed_inputs_per_placement"]
+        outs = {}
+        if "sparsecore" in pre:
+            outs["sparsecore"] = self._sparsecore_call(**pre["sparsecore"], training=training)
+        if "default_device" in pre:
+            outs["default_device"] = self._default_device_call(**pre["default_device"], training=training)
+        return base.map_structure_up_to(
+            self._feature_deeply_nested_placement_and_paths, lambda pp: outs[pp.placement][pp.path],
+            self._feature_deeply_nested_placement_and_paths, is_leaf=_is_placement_leaf)
+
+    def get_embedding_tables(self) -> dict[str, torch.Tensor]:
+        """{TableConfig.name: [vocabulary_size, embedding_dim]} (base:810-825)."""
+        if not self.built:
+            self.build(None)
+        tables = {}
+        if "sparsecore" in self._placement_to_path_to_feature_config:
+            tables.update(self._sparsecore_get_embedding_tables())
+        if "default_device" in self._placement_to_path_to_feature_config:
+            tables.update(self._default_device_get_embedding_tables())
+        return tables
+
+    def set_embedding_tables(self, tables: dict) -> None:
+        """Overwrites tables by name (jax/distributed_embedding.py:746-756)."""
+        if not self.built:
+            self.build(None)
+        with torch.no_grad():
+            for groups in self._groups.values():
+                for g in groups:
+                    for tc in g.table_configs:
+                        if tc.name in tables:
+                            p = self._table_params[id(tc)]
+                            p.copy_(torch.as_tensor(np.asarray(tables[tc.name].detach().cpu()
+                                                               if isinstance(tables[tc.name], torch.Tensor)
+                                                               else tables[tc.name])).to(p.dtype))
+
+    def compute_output_shape(self, input_shapes):
+        self._verify_input_shapes(input_shapes)
+        return base.map_structure_up_to(self._feature_configs, lambda fc: fc.output_shape, self._feature_configs,
+                                        is_leaf=_is_feature_config)
+
+    def get_config(self) -> dict:
+        # shared tables are serialised once, features refer to them by index (base:1053-1093)
+        table_dicts: list = []
+        table_index: dict[int, int] = {}
+
+        def ser(fc: FeatureConfig):
+            d = fc.get_config()
+            if id(fc.table) not in table_index:
+                table_index[id(fc.table)] = len(table_dicts)
+                table_dicts.append(d["table"])
+            d["table"] = table_index[id(fc.table)]
+            return d
+
+        config = super().get_config()
+        config["feature_configs"] = base.map_structure_up_to(self._feature_configs, ser, self._feature_configs,
+                                                             is_leaf=_is_feature_config)
+        config["tables"] = table_dicts
+        config["table_stacking"] = self._table_stacking
+        return config
+
+    @classmethod
+    def from_config(cls, config: dict):
+        config = dict(config)
+        table_dicts = config.pop("tables")
+        tables: list = [None] * len(table_dicts)
+
+        def is_fc_dict(d):
+            return isinstance(d, dict) and isinstance(d.get("name"), str) and "table" in d
+
+        def de(d):
+            d = dict(d)
+            idx = d["table"]
+            d["table"] = table_dicts[idx]
+            fc = FeatureConfig.from_config(d)
+            if tables[idx] is None:
+                tables[idx] = fc.table
+            else:
+                fc.table = tables[idx]
+            return fc
+
+        flat = base.flatten(config["feature_configs"], is_leaf=is_fc_dict)
+        config["feature_configs"] = base.pack_sequence_as(config["feature_configs"], [de(d) for d in flat],
+                                                          is_leaf=is_fc_dict)
+        return cls(**config)
+
+    def _verify_input_shapes(self, input_shapes) -> None:
+        if self._is_preprocessed(input_shapes):
+            return
+
+        def verify(fc: FeatureConfig, shape):
+            if shape is None:
+                return
+            if not isinstance(shape, (tuple, list)) or not all(isinstance(d, (int, type(None))) for d in shape):
+                raise ValueError(f"Received invalid input shape {shape}.")
+            if len(shape) < 1:
+                raise ValueError(f"Received input shape {shape}. Rank must be 1 or above.")
+            # The reference discards this result (base:1179-1181): a mismatch is accepted
+            # (examples/ml_perf/main.py:175-177 relies on it).
+            check_shapes_compatible(tuple(fc.input_shape), tuple(shape))
+
+        base.map_structure_up_to(self._feature_configs, verify, self._feature_configs, input_shapes,
+                                 is_leaf=_is_feature_config)
+
+    def _unsupported_placement_error(self, placement: str) -> Exception:
+        return NotImplementedError(f"No AMD GPU visible to torch: the '{placement}' placement is not available.")
+
+
+# ---------------------------------------------------------------------- helpers
+def _to_numpy(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def _to_tensor(x) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        return x
+    if hasattr(x, "numpy") and callable(x.numpy):
+        x = x.numpy()
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def _cat_index(parts: Sequence[torch.Tensor]) -> torch.Tensor:
+    dt = torch.int64 if any(p.dtype == torch.int64 for p in parts) else torch.int32
+    return torch.cat([p.to(dt) for p in parts]) if len(parts) > 1 else parts[0].to(dt).contiguous()
+
+
+def _shape_of(x):
+    if isinstance(x, Ragged):
+        return (len(x.row_offsets) - 1, None)
+    if isinstance(x, np.ndarray) and x.dtype == object:
+        return (len(x), None)
+    return tuple(x.shape) if hasattr(x, "shape") else None
+
+
+def _ragged_numpy_to_csr(x, w):
+    """numpy object arrays of rows (the ragged form of base:31-92) -> Ragged CSR.
+    Results equal the reference's pad-to-dense form (padding carries weight 0)."""
+    if isinstance(x, np.ndarray) and x.dtype == object and len(x) > 0:
+        rx = Ragged.from_rows(list(x), dtype=np.asarray(x[0]).dtype if np.asarray(x[0]).dtype.kind == "i" else np.int32)
+        rw = None
+        if w is not None:
+            rw = Ragged(np.concatenate([np.asarray(r, np.float32) for r in w] + [np.zeros(0, np.float32)]),
+                        rx.row_offsets)
+        return rx, rw
+    return x, w

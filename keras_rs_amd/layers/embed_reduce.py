@@ -1,0 +1,184 @@
+"""EmbedReduce on MI355X: drop-in for keras_rs.layers.EmbedReduce
+(keras_rs/src/layers/embedding/embed_reduce.py:133-309): an embedding lookup
+followed by a weighted sum / mean / sqrtn reduction over axis -2, in one HIP
+kernel (K1), with the reference's dense-gradient autodiff (K2)."""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import torch
+
+from keras_rs_amd import _lib as L
+from keras_rs_amd.autograd import EmbedBagFn
+from keras_rs_amd.embedding_ops import FusedBags
+from keras_rs_amd.layers import base
+
+SUPPORTED_COMBINERS = ("mean", "sum", "sqrtn")
+
+
+class Ragged:
+    """Rows of variable length as CSR: `values` [nnz], `row_offsets` [rows + 1].
+    Stands in for tf.RaggedTensor / sparse inputs (embed_reduce_test.py:51-80)."""
+
+    def __init__(self, values, row_offsets):
+        self.values = values
+        self.row_offsets = row_offsets
+
+    @classmethod
+    def from_rows(cls, rows, dtype=np.int32):
+        lens = [len(r) for r in rows]
+        vals = np.concatenate([np.asarray(r, dtype=dtype) for r in rows] + [np.zeros(0, dtype)])
+        return cls(vals.astype(dtype), np.concatenate([[0], np.cumsum(lens)]).astype(np.int32))
+
+    @property
+    def shape(self):
+        return (len(self.row_offsets) - 1, None)
+
+
+def as_index_tensor(x, device) -> torch.Tensor:
+    t = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x)
+    if t.dtype not in (torch.int32, torch.int64):
+        t = t.to(torch.int32)  # keras.layers.Embedding.call casts other dtypes to int32
+    return t.to(device)
+
+
+def check_shapes_compatible(a, b) -> bool:
+    """keras_rs/src/utils/keras_utils.py:54-64: equal rank, every known pair equal."""
+    if len(a) != len(b):
+        return False
+    return all(x is None or y is None or x == y for x, y in zip(a, b))
+
+
+class EmbedReduce(base.Layer):
+    """Args (embed_reduce.py:133-160): input_dim, output_dim, embeddings_initializer,
+    embeddings_regularizer, embeddings_constraint, mask_zero, weights (initial table),
+    combiner in {mean, sum, sqrtn}."""
+
+    def __init__(self, input_dim: int, output_dim: int, embeddings_initializer="uniform",
+                 embeddings_regularizer=None, embeddings_constraint=None, mask_zero: bool = False,
+                 weights=None, combiner: str = "mean", **kwargs: Any):
+        super().__init__(**kwargs)
+        if combiner not in SUPPORTED_COMBINERS:  # embed_reduce.py:155-159
+            raise ValueError(f"Invalid `combiner`: '{combiner}', use one of {', '.join(SUPPORTED_COMBINERS)}.")
+        self.input_dim = int(input_dim)
+        self.output_dim = int(output_dim)
+        self.embeddings_initializer = base.get_initializer(embeddings_initializer)
+        self.embeddings_regularizer = embeddings_regularizer
+        self.embeddings_constraint = embeddings_constraint
+        self.mask_zero = mask_zero
+        self.combiner = combiner
+        self._initial_weights = weights
+        self.register_parameter("embeddings", None)
+        self._bags: dict = {}
+
+    def build(self, *_) -> None:
+        if self.embeddings is None:
+            self.embeddings = self.add_weight((self.input_dim, self.output_dim), self.embeddings_initializer,
+                                              "embeddings")
+            if self._initial_weights is not None:
+                with torch.no_grad():
+                    self.embeddings.copy_(torch.as_tensor(np.asarray(self._initial_weights)))
+        self.built = True
+
+    def _input_shapes(self, args):
+        return (getattr(args[0], "shape", None),)
+
+    def _fused(self, combiner: str) -> FusedBags:
+        fb = self._bags.get(combiner)
+        if fb is None or fb.tables[0] is not self.embeddings:
+            fb = FusedBags([self.embeddings], [(0, combiner, 0)])
+            self._bags[combiner] = fb
+        return fb
+
+    def call(self, inputs, weights=None) -> torch.Tensor:
+        dev = self.embeddings.device
+        if isinstance(inputs, Ragged):
+            ids = as_index_tensor(inputs.values, dev).reshape(-1)
+            offsets = torch.as_tensor(np.asarray(inputs.row_offsets) if not isinstance(inputs.row_offsets, torch.Tensor)
+                                      else inputs.row_offsets).to(torch.int32).to(dev)
+            batch = offsets.numel() - 1
+            w = None
+            if weights is not None:
+                wv = weights.values if isinstance(weights, Ragged) else weights
+                w = torch.as_tensor(np.asarray(wv) if not isinstance(wv, torch.Tensor) else wv).to(dev)
+                if w.numel() != ids.numel():
+                    raise ValueError(f"The shape of `weights`: {tuple(w.shape)} is not compatible with the ragged "
+                                     f"`inputs` ({ids.numel()} values).")
+            out_dtype = self._out_dtype(w)
+            return EmbedBagFn.apply(self._fused(self.combiner), ids, batch, None, offsets,
+                                    None if w is None else w.float().reshape(-1), out_dtype, True, self.embeddings)
+
+        ids = as_index_tensor(inputs, dev)
+        if ids.dim() not in (1, 2):
+            raise ValueError(f"EmbedReduce inputs must be rank 1 or 2, got shape {tuple(ids.shape)}")
+        unreduced = tuple(ids.shape) + (self.output_dim,)
+        w = None
+        if weights is not None:
+            w = torch.as_tensor(np.asarray(weights) if not isinstance(weights, torch.Tensor) else weights).to(dev)
+            if w.dim() > len(unreduced) or not check_shapes_compatible(unreduced[: w.dim()], tuple(w.shape)):
+                raise ValueError(f"The shape of `weights`: {tuple(w.shape)} is not compatible with the shape of "
+                                 f"`inputs` after embedding: {unreduced}.")  # embed_reduce.py:182-190
+        out_dtype = self._out_dtype(w)
+        combiner = self.combiner
+        if ids.dim() == 1:
+            # no reduction; weights only survive for "sum" (embed_reduce.py:224)
+            if combiner != "sum":
+                w = None
+            combiner, hot = "sum", 1
+        else:
+            hot = ids.shape[1]
+        batch = ids.shape[0]
+        if w is not None:
+            w = w.float().expand(ids.shape).contiguous().reshape(-1) if w.dim() < ids.dim() else \
+                w.float().contiguous().reshape(-1)
+        return EmbedBagFn.apply(self._fused(combiner), ids.contiguous().reshape(-1), batch, (hot,), None, w,
+                                out_dtype, True, self.embeddings)
+
+    def _out_dtype(self, w):
+        cd = self.compute_dtype
+        # keras.backend.result_type(x.dtype, weights.dtype): bf16 x fp32 weights -> fp32
+        if w is not None and w.dtype == torch.float32 and cd == torch.bfloat16:
+            return torch.float32
+        return cd
+
+    def compute_output_shape(self, input_shape, weights_shape=None):
+        if len(input_shape) <= 1:
+            return (*input_shape, self.output_dim)
+        return (*input_shape[0:-1], self.output_dim)
+
+    def get_config(self) -> dict:
+        config = super().get_config()
+        config.update({
+            "input_dim": self.input_dim,
+            "output_dim": self.output_dim,
+            "embeddings_initializer": self.embeddings_initializer.serialize(),
+            "embeddings_regularizer": self.embeddings_regularizer,
+            "embeddings_constraint": self.embeddings_constraint,
+            "mask_zero": self.mask_zero,
+            "combiner": self.combiner,
+        })
+        return config
+
+
+class Embedding(EmbedReduce):
+    """keras.layers.Embedding look-alike (plain row gather, no reduction): ids of any
+    rank -> ids.shape + (output_dim,).  Used by the examples' small tables
+    (examples/ml_perf/model.py:193-201, README.md:56-60); runs on the same K1 kernel
+    with every id as its own one-element bag."""
+
+    def __init__(self, input_dim: int, output_dim: int, embeddings_initializer="uniform", **kwargs):
+        kwargs.pop("combiner", None)
+        super().__init__(input_dim, output_dim, embeddings_initializer=embeddings_initializer, combiner="sum",
+                         **kwargs)
+
+    def call(self, inputs, weights=None) -> torch.Tensor:
+        if weights is not None:
+            raise ValueError("Embedding takes no weights; use EmbedReduce")
+        ids = as_index_tensor(inputs, self.embeddings.device)
+        flat = super().call(ids.reshape(-1))
+        return flat.reshape(*ids.shape, self.output_dim)
+
+    def compute_output_shape(self, input_shape, weights_shape=None):
+        return (*input_shape, self.output_dim)

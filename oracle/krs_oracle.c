@@ -235,8 +235,8 @@ int krs_oracle_gemm(const void* a, int64_t lda, int a_is_km, const void* b, int6
         v = act_apply(ep->act, v);
         if (ep->x0) {
           float xv = ld(ep->x, out_dtype, i * ep->ldx + j);
+          if (ep->u_out) st(ep->u_out, out_dtype, i * ep->ldu + j, v);
           float u = v + ep->diag_scale * xv;
-          if (ep->u_out) st(ep->u_out, out_dtype, i * ep->ldu + j, u);
           v = ld(ep->x0, out_dtype, i * ep->ldx + j) * u + xv;
         }
         if (ep->r) v += ep->beta * ld(ep->r, out_dtype, i * ep->ldr + j);
@@ -260,23 +260,36 @@ int krs_oracle_cross_epilogue_fwd(const void* u, const void* x0, const void* x, 
   return KRS_OK;
 }
 
-/* Autodiff of y = x0 * (u + diag*x) + x w.r.t. u, x0 and the direct x path. */
+static inline float act_grad_from_output(int act, float u) {
+  switch (act) {
+    case KRS_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
+    case KRS_ACT_SIGMOID: return u * (1.0f - u);
+    case KRS_ACT_TANH: return 1.0f - u * u;
+    default: return 1.0f;
+  }
+}
+
+/* Autodiff of y = x0 * (act(z) + diag*x) + x w.r.t. z, x0 and the direct x path;
+ * u = act(z) as saved by the forward. */
 int krs_oracle_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const void* x,
                                   void* du, void* dx0, int dx0_accumulate, void* dxd,
                                   float* dbias, int64_t m, int64_t n, int64_t ldm,
-                                  float diag_scale, int dtype) {
+                                  float diag_scale, int act, int dtype) {
   if (dbias)
     for (int64_t j = 0; j < n; ++j) dbias[j] = 0.0f;
   for (int64_t i = 0; i < m; ++i)
     for (int64_t j = 0; j < n; ++j) {
       int64_t o = i * ldm + j;
       float gv = ld(g, dtype, o);
-      float duv = gv * ld(x0, dtype, o);
-      float uf = ld(u, dtype, o) + diag_scale * ld(x, dtype, o);
-      if (du) st(du, dtype, o, duv);
-      if (dx0) st(dx0, dtype, o, (dx0_accumulate ? ld(dx0, dtype, o) : 0.0f) + gv * uf);
-      if (dxd) st(dxd, dtype, o, gv + diag_scale * duv);
-      if (dbias) dbias[j] += duv;
+      float gx0 = gv * ld(x0, dtype, o);
+      float uv = u ? ld(u, dtype, o) : 0.0f;
+      float dz = gx0 * act_grad_from_output(act, uv);
+      if (du) st(du, dtype, o, dz);
+      if (dx0)
+        st(dx0, dtype, o,
+           (dx0_accumulate ? ld(dx0, dtype, o) : 0.0f) + gv * (uv + diag_scale * ld(x, dtype, o)));
+      if (dxd) st(dxd, dtype, o, gv + diag_scale * gx0);
+      if (dbias) dbias[j] += dz;
     }
   return KRS_OK;
 }

@@ -207,7 +207,7 @@ def cross_epilogue_fwd(u, x0, x, diag_scale=0.0):
     return y
 
 
-def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, dx0_init=None):
+def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, dx0_init=None, act=None):
     m, n = x.shape
     du = np.zeros_like(x)
     dx0 = np.zeros_like(x) if dx0_init is None else dx0_init.copy()
@@ -216,7 +216,7 @@ def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, dx0_init=None):
     rc = lib().krs_oracle_cross_epilogue_bwd(
         _p(g), _p(u), _p(x0), _p(x), _p(du), _p(dx0), C.c_int(int(dx0_init is not None)),
         _p(dxd), _p(dbias), C.c_int64(m), C.c_int64(n), C.c_int64(n), C.c_float(diag_scale),
-        C.c_int(fdtype(x)))
+        C.c_int(ACTS[act] if not isinstance(act, int) else act), C.c_int(fdtype(x)))
     assert rc == 0, rc
     return du, dx0, dxd, dbias
 

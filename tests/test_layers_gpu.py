@@ -1,0 +1,297 @@
+"""The reference's own layer tests, replayed on the MI355X layers (HIP through the C ABI):
+known-answer vectors (tests/golden/kat.json), gradients against an independent plain-torch
+composition of the same formulas, DistributedEmbedding correctness / shared tables / one
+training step."""
+
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import to_f32, to_np
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat.json")))
+TOL = dict(atol=1e-6, rtol=1e-6)  # keras_rs/src/testing/test_case.py:47-77
+
+
+def _layers():
+    import keras_rs_amd.layers as kl
+
+    return kl
+
+
+@pytest.mark.parametrize("case", KAT["feature_cross"]["cases"], ids=lambda c: c["name"])
+def test_feature_cross_kat(case):
+    kl = _layers()
+    fc = KAT["feature_cross"]
+    x0 = torch.tensor(fc["x0"], device=DEV)
+    x = torch.tensor(fc["x"], device=DEV)
+    layer = kl.FeatureCross(projection_dim=case["projection_dim"], diag_scale=case["diag_scale"],
+                            kernel_initializer="ones")
+    out = layer(x0) if case["one_input"] else layer(x0, x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), np.array(case["expected"], np.float32), **TOL)
+    assert [list(w.shape) for w in layer.weights] == case["weight_shapes"]
+
+
+def test_feature_cross_pre_activation_callable():
+    kl = _layers()
+    fc = KAT["feature_cross"]
+    x0 = torch.tensor(fc["x0"], device=DEV)
+    x = torch.tensor(fc["x"], device=DEV)
+    out = kl.FeatureCross(pre_activation=torch.zeros_like)(x0, x)  # feature_cross_test.py:75-79
+    np.testing.assert_allclose(out.detach().cpu().numpy(), np.array(fc["pre_activation_zero"]["expected"]), **TOL)
+
+
+def _torch_cross(x0, x, down, kernel, bias, diag, act):
+    h = x if down is None else x @ down
+    z = h @ kernel + (0 if bias is None else bias)
+    u = {None: lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](z)
+    return x0 * (u + diag * x) + x
+
+
+@pytest.mark.parametrize("p", [None, 8])
+@pytest.mark.parametrize("act", [None, "relu", "tanh", "sigmoid"])
+@pytest.mark.parametrize("shape", [(37, 24), (4, 5, 16)])
+def test_feature_cross_forward_and_gradients_fp32(p, act, shape):
+    kl = _layers()
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(shape, generator=g).to(DEV).requires_grad_()
+    x = torch.randn(shape, generator=g).to(DEV).requires_grad_()
+    layer = kl.FeatureCross(projection_dim=p, diag_scale=0.3, pre_activation=act, bias_initializer="uniform")
+    y = layer(x0, x)
+    gy = torch.randn(shape, generator=g).to(DEV)
+    y.backward(gy)
+    got = [x0.grad, x.grad] + [w.grad for w in layer.weights]
+    # independent composition on fp64 copies
+    r0, r = x0.detach().double().requires_grad_(), x.detach().double().requires_grad_()
+    ws = [w.detach().double().requires_grad_() for w in layer.weights]
+    down, kern, bias = (ws[0], ws[1], ws[2]) if p is not None else (None, ws[0], ws[1])
+    ry = _torch_cross(r0, r, down, kern, bias, 0.3, act)
+    ry.backward(gy.double())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ry.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    for a, b in zip(got, [r0.grad, r.grad] + [w.grad for w in ws]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_feature_cross_same_tensor_twice_and_dcn_stack():
+    kl = _layers()
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(33, 32, generator=g).to(DEV).requires_grad_()
+    layers = [kl.FeatureCross(projection_dim=8) for _ in range(3)]
+    xl = x0
+    for layer in layers:  # DCNBlock.call, examples/ml_perf/model.py:332-336
+        xl = layer(x0, xl)
+    xl.sum().backward()
+    r0 = x0.detach().double().requires_grad_()
+    rl = r0
+    for layer in layers:
+        w = [t.detach().double() for t in layer.weights]
+        rl = _torch_cross(r0, rl, w[0], w[1], w[2], 0.0, None)
+    rl.sum().backward()
+    np.testing.assert_allclose(xl.detach().cpu().numpy(), rl.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(x0.grad.cpu().numpy(), r0.grad.cpu().numpy(), rtol=5e-5, atol=5e-5)
+
+
+def test_feature_cross_bf16_policy():
+    kl = _layers()
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(256, 128, generator=g).to(DEV)
+    layer = kl.FeatureCross(projection_dim=64, dtype="mixed_bfloat16")
+    y = layer(x0.bfloat16(), x0.bfloat16())
+    assert y.dtype == torch.bfloat16 and layer.weights[0].dtype == torch.float32
+    w = [t.detach().bfloat16().float() for t in layer.weights[:2]] + [layer.weights[2].detach()]
+    xb = x0.bfloat16().float()
+    ref = _torch_cross(xb, xb, w[0], w[1], w[2], 0.0, None)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ref.cpu().numpy(), rtol=2 ** -6, atol=2e-2)
+
+
+@pytest.mark.parametrize("case", KAT["dot_interaction"]["cases"],
+                         ids=lambda c: f"self{int(c['self_interaction'])}_skip{int(c['skip_gather'])}")
+def test_dot_interaction_kat_and_grad(case):
+    kl = _layers()
+    feats = [torch.tensor(f, device=DEV, requires_grad=True) for f in KAT["dot_interaction"]["inputs"]]
+    layer = kl.DotInteraction(case["self_interaction"], case["skip_gather"])
+    out = layer(feats)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), np.array(case["expected"], np.float32), rtol=1e-6, atol=1e-5)
+    assert tuple(out.shape) == layer.compute_output_shape([(1, 5)] * 3)
+    w = torch.arange(1, out.numel() + 1, device=DEV, dtype=torch.float32).reshape(out.shape)
+    (out * w).sum().backward()
+    ref = [f.detach().double().requires_grad_() for f in feats]
+    X = torch.stack(ref, 1)
+    P = X @ X.transpose(1, 2)
+    F = 3
+    if case["skip_gather"]:
+        mask = torch.tril(torch.ones(F, F, dtype=torch.float64, device=DEV), 0 if case["self_interaction"] else -1)
+        r = (P * mask).reshape(1, F * F)
+    else:
+        idx = [i * F + j for i in range(F) for j in range(i + 1 if case["self_interaction"] else i)]
+        r = P.reshape(1, F * F)[:, idx]
+    (r * w.double()).sum().backward()
+    for a, b in zip(feats, ref):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", KAT["embed_reduce"]["cases"],
+                         ids=lambda c: f"{c['kind']}_{c['combiner']}_{'w' if c['weights'] else 'now'}")
+def test_embed_reduce_kat(case):
+    kl = _layers()
+    er = KAT["embed_reduce"]
+    layer = kl.EmbedReduce(er["input_dim"], er["output_dim"], combiner=case["combiner"])
+    w = None if case["weights"] is None else np.array(case["weights"], np.float32)
+    if case["kind"] == "bag":
+        inputs = kl.Ragged(np.array(case["ids"], np.int32), np.array(case["offsets"], np.int32))
+        res = layer(inputs, None if w is None else kl.Ragged(w, inputs.row_offsets))
+    else:
+        res = layer(torch.tensor(case["ids"], device=DEV), None if w is None else torch.tensor(w, device=DEV))
+    assert tuple(res.shape) == (2, er["output_dim"])
+    e = layer.embeddings.detach().cpu().numpy().astype(np.float64)
+    exp = np.stack([sum(c * e[r] for r, c in terms) / div for terms, div in zip(case["terms"], case["divisor"])])
+    np.testing.assert_allclose(res.detach().cpu().numpy(), exp.astype(np.float32), **TOL)
+
+
+def test_embed_reduce_out_of_range_raises_and_dense_gradient():
+    kl = _layers()
+    layer = kl.EmbedReduce(10, 8, combiner="mean")
+    with pytest.raises(IndexError):
+        layer(torch.tensor([[1, 10]], device=DEV))
+    ids = torch.tensor([[1, 2, 2], [3, 1, 1]], device=DEV)
+    w = torch.tensor([[1.0, 2.0, 0.5], [1.0, 1.0, 3.0]], device=DEV)
+    out = layer(ids, w)
+    g = torch.randn(2, 8, device=DEV)
+    out.backward(g)
+    e = layer.embeddings.detach().double().requires_grad_()
+    ref = (e[ids] * w.double()[..., None]).sum(1) / w.double().sum(1, keepdim=True)
+    ref.backward(g.double())
+    np.testing.assert_allclose(layer.embeddings.grad.cpu().numpy(), e.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _de_configs(placement, optimizer="sgd", combiner="mean"):
+    kl = _layers()
+    de = KAT["distributed_embedding"]
+    t = kl.TableConfig("table", de["vocabulary_size"], de["embedding_dim"], placement=placement,
+                       optimizer=optimizer, combiner=combiner)
+    return t
+
+
+@pytest.mark.parametrize("placement", ["default_device", "sparsecore", "auto"])
+@pytest.mark.parametrize("combiner", ["sum", "mean", "sqrtn"])
+@pytest.mark.parametrize("kind", ["dense1d", "dense2d", "ragged"])
+@pytest.mark.parametrize("use_w", [False, True])
+def test_distributed_embedding_correctness(placement, combiner, kind, use_w):
+    # distributed_embedding_test.py:411-599: closed forms through the nested API, batch 16
+    kl = _layers()
+    de = KAT["distributed_embedding"]
+    B, D = de["batch"], de["embedding_dim"]
+    t = _de_configs(placement, combiner=combiner)
+    n = B // 2
+    if kind == "dense1d":
+        x = np.array(de["dense1d_ids_pattern"] * n, np.int32)
+        w = np.array([1.0, 2.0] * n, np.float32)
+        fc = kl.FeatureConfig("f", t, (B,), (B, D))
+    elif kind == "dense2d":
+        x = np.array([[2, 3], [4, 5]] * n, np.int32)
+        w = np.array([[1.0, 2.0], [3.0, 4.0]] * n, np.float32)
+        fc = kl.FeatureConfig("f", t, (B, 2), (B, D))
+    else:
+        x = np.empty(B, dtype=object)
+        w = np.empty(B, dtype=object)
+        for i in range(n):
+            x[2 * i], x[2 * i + 1] = np.array([1], np.int32), np.array([2, 3, 4, 5], np.int32)
+            w[2 * i], w[2 * i + 1] = np.array([1.0], np.float32), np.array([1.0, 2.0, 3.0, 4.0], np.float32)
+        fc = kl.FeatureConfig("f", t, (B, 4), (B, D))
+    layer = kl.DistributedEmbedding({"group": {"f": fc}})
+    res = layer({"group": {"f": x}}, {"group": {"f": w}} if use_w else None)["group"]["f"]
+    assert tuple(res.shape) == (B, D)
+    e = layer.get_embedding_tables()["table"].cpu().numpy().astype(np.float64)
+    rows = []
+    for b in range(B):
+        ids = np.atleast_1d(x[b])
+        ww = np.atleast_1d(w[b]).astype(np.float64) if use_w else np.ones(len(ids))
+        if kind == "dense1d" and combiner != "sum":
+            ww = np.ones(len(ids))
+        s = (ww[:, None] * e[ids]).sum(0)
+        if kind != "dense1d":
+            if combiner == "mean":
+                s = s / ww.sum()
+            elif combiner == "sqrtn":
+                s = s / math.sqrt((ww * ww).sum())
+        rows.append(s)
+    np.testing.assert_allclose(res.detach().cpu().numpy(), np.stack(rows).astype(np.float32), rtol=1e-5, atol=1e-6)
+
+
+def test_distributed_embedding_shared_table_and_preprocessed_call():
+    kl = _layers()
+    t = _de_configs("default_device", combiner="sum")
+    fcs = [kl.FeatureConfig(f"f{i}", t, (16, 1), (16, 7)) for i in range(3)]
+    layer = kl.DistributedEmbedding(fcs)
+    xs = [np.full((16, 1), i + 1, np.int32) for i in range(3)]
+    pre = layer.preprocess(xs)
+    outs = layer(pre)
+    assert len(layer.weights) == 1
+    e = layer.get_embedding_tables()["table"]
+    for i, o in enumerate(outs):
+        assert torch.equal(o, e[i + 1].expand(16, 7))
+
+
+@pytest.mark.parametrize("placement,optimizer", [("default_device", "sgd"), ("sparsecore", "sgd"),
+                                                 ("sparsecore", "adagrad")])
+def test_distributed_embedding_training_step_matches_formula(placement, optimizer):
+    # one step with loss = sum(out * g): table rows move by the optimizer formula of
+    # jax/test_utils.py:474-497 (fused) / by a torch SGD step on the dense gradient
+    kl = _layers()
+    lr = 0.1
+    opt = kl.SGD(lr) if optimizer == "sgd" else kl.Adagrad(lr, 0.1)
+    t = kl.TableConfig("table", 23, 7, placement=placement, optimizer=opt, combiner="sum")
+    layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t, (16, 2), (16, 7))})
+    x = np.random.default_rng(0).integers(0, 23, (16, 2)).astype(np.int32)
+    before = layer({"a": x})["a"].detach().clone()
+    table0 = layer.get_embedding_tables()["table"].clone()
+    g = torch.rand(16, 7, device=DEV)
+    out = layer({"a": x})["a"]
+    (out * g).sum().backward()
+    if placement == "default_device":
+        with torch.no_grad():
+            for p in layer.weights:
+                p -= lr * p.grad
+    after = layer({"a": x})["a"].detach()
+    assert not torch.allclose(before, after)  # distributed_embedding_test.py:240-384
+    dense = torch.zeros(23, 7, dtype=torch.float64, device=DEV)
+    dense.index_add_(0, torch.from_numpy(x.reshape(-1)).long().to(DEV), g.double().repeat_interleave(2, 0))
+    if optimizer == "sgd":
+        exp = table0.double() - lr * dense
+    else:
+        acc = 0.1 + dense * dense
+        exp = torch.where(dense != 0, table0.double() - lr * dense / acc.sqrt(), table0.double())
+    np.testing.assert_allclose(layer.get_embedding_tables()["table"].cpu().numpy(), exp.cpu().numpy(),
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_set_embedding_tables_and_mixed_width_groups():
+    kl = _layers()
+    t1 = kl.TableConfig("t1", 30, 8, placement="default_device", combiner="sum")
+    t2 = kl.TableConfig("t2", 40, 16, placement="sparsecore", optimizer="sgd", combiner="mean")
+    layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t1, (4, 2), (4, 8)),
+                                     "b": kl.FeatureConfig("b", t2, (4, 3), (4, 16))})
+    layer.build(None)
+    layer.set_embedding_tables({"t1": np.ones((30, 8), np.float32), "t2": np.full((40, 16), 2.0, np.float32)})
+    out = layer({"a": np.zeros((4, 2), np.int32), "b": np.zeros((4, 3), np.int32)})
+    assert torch.all(out["a"] == 2.0) and torch.all(out["b"] == 2.0)
+
+
+def test_embedding_layer_and_readme_quickstart_shape():
+    # README.md:46-76 / feature_cross.py:68-86: Embedding(32, 6) -> FeatureCross x2
+    kl = _layers()
+    emb = kl.Embedding(32, 6)
+    ids = torch.randint(0, 32, (2,), device=DEV)
+    x0 = emb(ids)
+    x1 = kl.FeatureCross()(x0, x0)
+    x2 = kl.FeatureCross()(x0, x1)
+    assert tuple(x2.shape) == (2, 6)
+    assert torch.equal(x0, emb.embeddings[ids.long()])
+    seq = emb(torch.randint(0, 32, (3, 4), device=DEV))
+    assert tuple(seq.shape) == (3, 4, 6)

@@ -1,0 +1,158 @@
+"""Host-side logic of the drop-in layers (no GPU): constructor/config/error behaviour of the
+reference API surface, nested-structure plumbing, loud failure on CPU."""
+
+import numpy as np
+import pytest
+import torch
+
+import keras_rs_amd
+from keras_rs_amd.layers import (DistributedEmbedding, DotInteraction, EmbedReduce, FeatureConfig, FeatureCross,
+                                 TableConfig)
+from keras_rs_amd.layers import base
+
+
+def test_feature_cross_constructor_errors_and_config():
+    with pytest.raises(ValueError):  # feature_cross_test.py:63-65
+        FeatureCross(diag_scale=-1.0)
+    layer = FeatureCross(projection_dim=20, diag_scale=0.5, use_bias=False, pre_activation="relu",
+                         kernel_initializer="ones", name="fc")
+    cfg = layer.get_config()
+    for key in ("projection_dim", "diag_scale", "use_bias", "pre_activation", "kernel_initializer",
+                "bias_initializer", "kernel_regularizer", "bias_regularizer"):  # feature_cross.py:196-222
+        assert key in cfg
+    clone = FeatureCross.from_config(cfg)
+    assert clone.get_config() == cfg
+    assert layer.supports_masking
+
+
+def test_feature_cross_weight_order_and_shape_error_before_any_kernel():
+    layer = FeatureCross(projection_dim=1, kernel_initializer="ones", device="cpu")
+    layer.build((1, 3))
+    assert [tuple(w.shape) for w in layer.weights] == [(3, 1), (1, 3), (3,)]  # feature_cross_test.py:44-47
+    full = FeatureCross(device="cpu")
+    full.build((1, 3))
+    assert [tuple(w.shape) for w in full.weights] == [(3, 3), (3,)]
+    with pytest.raises(ValueError):  # feature_cross_test.py:54-61
+        FeatureCross(device="cpu")(torch.ones(12, 5), torch.ones(12, 7))
+
+
+def test_no_cpu_fallback():
+    with pytest.raises(keras_rs_amd.KrsError):
+        FeatureCross(device="cpu")(torch.ones(2, 4), torch.ones(2, 4))
+    with pytest.raises(keras_rs_amd.KrsError):
+        DotInteraction()([torch.ones(2, 4), torch.ones(2, 4)])
+    with pytest.raises(keras_rs_amd.KrsError):
+        EmbedReduce(10, 4, device="cpu")(torch.tensor([1, 2]))
+
+
+def test_dot_interaction_shapes_and_errors():
+    assert DotInteraction().compute_output_shape([(8, 5)] * 3) == (8, 3)
+    assert DotInteraction(self_interaction=True).compute_output_shape([(8, 5)] * 3) == (8, 6)
+    assert DotInteraction(skip_gather=True).compute_output_shape([(8, 5)] * 3) == (8, 9)
+    with pytest.raises(ValueError):  # dot_interaction_test.py:93-98
+        DotInteraction()([torch.ones(3), torch.ones(3)])
+    with pytest.raises(ValueError):  # :100-105
+        DotInteraction()([torch.ones(1, 3), torch.ones(1, 4)])
+    cfg = DotInteraction(self_interaction=True, skip_gather=True).get_config()
+    assert cfg["self_interaction"] and cfg["skip_gather"]
+
+
+def test_embed_reduce_errors_and_shapes():
+    with pytest.raises(ValueError):
+        EmbedReduce(10, 20, combiner="max")
+    layer = EmbedReduce(10, 20, combiner="sqrtn", device="cpu")
+    assert layer.compute_output_shape((7,)) == (7, 20)
+    assert layer.compute_output_shape((7, 3)) == (7, 20)
+    assert layer.get_config()["combiner"] == "sqrtn"
+    layer.build(None)
+    with pytest.raises(ValueError):  # weights incompatible with inputs (embed_reduce.py:182-190)
+        layer(torch.tensor([[1, 2], [3, 4]]), torch.ones(3, 2))
+
+
+def _two_table_configs(placement="default_device"):
+    t1 = TableConfig("table1", 23, 7, placement=placement, optimizer="sgd")
+    t2 = TableConfig("table2", 23, 11, placement=placement, optimizer="sgd")
+    return {"feature_group": {"feature1": FeatureConfig("feature1", t1, (16, 2), (16, 7)),
+                              "feature2": FeatureConfig("feature2", t2, (16, 2), (16, 11))}}
+
+
+def test_distributed_embedding_structure_and_variables():
+    # distributed_embedding_test.py:59-88,173-230
+    layer = DistributedEmbedding(_two_table_configs(), device="cpu")
+    layer.build(None)
+    assert len(layer.weights) == 2
+    tables = layer.get_embedding_tables()
+    assert set(tables) == {"table1", "table2"}
+    assert tuple(tables["table1"].shape) == (23, 7) and tuple(tables["table2"].shape) == (23, 11)
+    assert layer.compute_output_shape({"feature_group": {"feature1": (16, 2), "feature2": (16, 2)}}) == \
+        {"feature_group": {"feature1": (16, 7), "feature2": (16, 11)}}
+
+
+def test_distributed_embedding_shared_table_single_variable_and_config_roundtrip():
+    # distributed_embedding_test.py:601-652, base:1053-1139
+    t = TableConfig("table", 23, 7, placement="default_device")
+    fcs = [FeatureConfig(f"f{i}", t, (16, 1), (16, 7)) for i in range(3)]
+    layer = DistributedEmbedding(fcs, device="cpu")
+    layer.build(None)
+    assert len(layer.weights) == 1
+    cfg = layer.get_config()
+    assert len(cfg["tables"]) == 1 and [f["table"] for f in cfg["feature_configs"]] == [0, 0, 0]
+    clone = DistributedEmbedding.from_config(cfg)
+    flat = base.flatten(clone._feature_configs, is_leaf=lambda x: isinstance(x, FeatureConfig))
+    assert flat[0].table is flat[1].table is flat[2].table
+    assert clone.get_config()["tables"] == cfg["tables"]
+
+
+def test_distributed_embedding_placement_rules():
+    assert DistributedEmbedding.has_sparsecores() is False  # no GPU in this container
+    bad = TableConfig("t", 5, 4, placement="moon")
+    with pytest.raises(ValueError):  # base:573-577
+        DistributedEmbedding([FeatureConfig("f", bad, (2,), (2, 4))])
+    sc = TableConfig("t", 5, 4, placement="sparsecore", optimizer="sgd")
+    with pytest.raises(NotImplementedError):  # base:1190-1194: placement unavailable without the hardware
+        DistributedEmbedding([FeatureConfig("f", sc, (2,), (2, 4))])
+    auto = TableConfig("t", 5, 4)  # "auto" -> default_device here
+    layer = DistributedEmbedding([FeatureConfig("f", auto, (2,), (2, 4))])
+    assert list(layer._placement_to_path_to_feature_config) == ["default_device"]
+
+
+def test_preprocess_structure_and_input_shape_mismatch_is_accepted():
+    layer = DistributedEmbedding(_two_table_configs(), device="cpu")
+    x = {"feature_group": {"feature1": np.zeros((16, 5), np.int32), "feature2": np.zeros((16, 5), np.int32)}}
+    pre = layer.preprocess(x)  # FeatureConfig.input_shape says (16, 2): accepted like base:1179-1181
+    assert set(pre) == {"preprocessed_inputs_per_placement"}
+    dd = pre["preprocessed_inputs_per_placement"]["default_device"]
+    assert set(dd) == {"inputs"}
+    with pytest.raises(ValueError):
+        layer.preprocess({"feature_group": {"feature1": np.zeros((16, 5), np.int32)}})
+    with pytest.raises(keras_rs_amd.KrsError):  # compute needs the GPU
+        layer(pre)
+
+
+def test_ragged_numpy_inputs_become_csr():
+    t = TableConfig("t", 50, 8, placement="default_device", combiner="sum")
+    layer = DistributedEmbedding({"a": FeatureConfig("a", t, (2, 4), (2, 8))}, device="cpu")
+    rows = np.empty(2, dtype=object)
+    rows[0], rows[1] = np.array([1], np.int32), np.array([2, 3, 4, 5], np.int32)
+    pre = layer.preprocess({"a": rows})["preprocessed_inputs_per_placement"]["default_device"]["inputs"]["group0"]
+    assert pre["offsets"].tolist() == [0, 1, 5] and pre["ids"].tolist() == [1, 2, 3, 4, 5] and pre["hots"] is None
+
+
+def test_tree_helpers():
+    s = {"b": [1, (2, 3)], "a": 4}
+    assert [p for p, _ in base.flatten_with_path(s)] == [("a",), ("b", 0), ("b", 1, 0), ("b", 1, 1)]
+    assert base.pack_sequence_as(s, [40, 10, 20, 30]) == {"b": [10, (20, 30)], "a": 40}
+    assert base.map_structure_up_to(s, lambda x, y: x + y, s, s) == {"b": [2, (4, 6)], "a": 8}
+    with pytest.raises(ValueError):
+        base.assert_same_structure(s, {"b": [1, (2,)], "a": 4})
+
+
+def test_initializers_and_policy():
+    w = base.get_initializer("glorot_uniform")((64, 32))
+    lim = (6.0 / 96) ** 0.5
+    assert w.abs().max() <= lim + 1e-6 and w.std() > 0.5 * lim / 3 ** 0.5
+    assert base.get_initializer("uniform")((1000,)).abs().max() <= 0.05
+    a = base.VarianceScaling(seed=3)((8, 8))
+    assert torch.equal(a, base.VarianceScaling(seed=3)((8, 8)))
+    pol = base.DTypePolicy("mixed_bfloat16")
+    assert pol.compute_dtype == torch.bfloat16 and pol.variable_dtype == torch.float32
