@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""bench.py -- the hot path's headline benchmark (see BASELINE.json / SURVEY.md section 8d).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic batch, through the drop-in layers
+(keras_rs_amd.layers, HIP kernels behind the C ABI):
+
+    embedding gather+pool of 26 tables (K1) -> DotInteraction over the 27 feature vectors (K4)
+    -> 3 x FeatureCross(d = 3456, projection 512) (K3) -> loss
+    -> backward of all of it, including the index-scatter embedding gradient with the fused
+       Adagrad row update (K2) and an Adagrad step on the FeatureCross weights.
+
+Workload C3 (DLRM-small): 26 tables x 1,000,000 rows x 128, batch 65,536 global, bf16 tables
+and activations with fp32 accumulation, fp32 master weights for the dense kernels.
+`--multihot` switches the bag lengths from L = 1 to the ml_perf list (sum L = 214).
+With N > 1 the tables are MOD row-sharded over the ranks (C4), B_local = 65,536 / N.
+
+Prints ONE JSON line (rank 0) with `value` = whole-job embedding lookups/s, `ms_per_step` =
+the DCN fwd+bwd step time, a `roofline` object for K1 measured live with HIP events on the
+launch stream, and a `cpu_baseline` object (the oracle timed on this box's host cores on a
+bounded sample of the same workload).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ML_PERF_HOTS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
+HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tables", type=int, default=26)
+    ap.add_argument("--vocab", type=int, default=1_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=65536, help="global batch")
+    ap.add_argument("--projection", type=int, default=512)
+    ap.add_argument("--cross-layers", type=int, default=3)
+    ap.add_argument("--multihot", action="store_true", help="ml_perf bag lengths (sum L = 214) instead of L = 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2048)
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    if n <= 1:
+        return 0, 1, 0
+    import torch.distributed as dist
+
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    world = int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return rank, world, local
+
+
+class Model(torch.nn.Module):
+    """Embedding -> [DotInteraction] -> DCN cross stack, from the drop-in layers."""
+
+    def __init__(self, a, hots, world, rank):
+        super().__init__()
+        import keras_rs_amd.layers as kl
+        from keras_rs_amd.layers import base
+
+        self.a, self.hots = a, hots
+        opt = kl.Adagrad(learning_rate=0.0034, initial_accumulator_value=0.1)  # configs/v6e_8.py lr
+        feats = {}
+        for t in range(a.tables):
+            tc = kl.TableConfig(name=f"cat_{t}", vocabulary_size=a.vocab, embedding_dim=a.dim,
+                                initializer=base.RandomUniform(-0.05, 0.05, seed=1337 + t), optimizer=opt,
+                                combiner="sum", placement="sparsecore")
+            feats[f"cat_{t:02d}_id"] = kl.FeatureConfig(f"cat_{t}", tc, (a.batch // world, hots[t]),
+                                                       (a.batch // world, a.dim))
+        if world > 1:
+            from keras_rs_amd.sharded import ShardedDistributedEmbedding
+
+            self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16")
+        else:
+            self.embedding = kl.DistributedEmbedding(feats, dtype="bfloat16", name="embedding_layer")
+        self.dot = kl.DotInteraction()
+        self.cross = torch.nn.ModuleList(
+            kl.FeatureCross(projection_dim=a.projection, kernel_initializer=base.GlorotUniform(seed=1337 + i),
+                            dtype="mixed_bfloat16") for i in range(a.cross_layers))
+
+    def forward(self, dense_out, pre):
+        emb = self.embedding(pre)
+        feats = [dense_out] + [emb[k] for k in emb]
+        inter = self.dot(feats)                                   # [B, 351]
+        x0 = torch.cat(feats, dim=-1)                             # [B, 3456]  (model.py:204-207)
+        xl = x0
+        for layer in self.cross:                                  # DCNBlock.call, model.py:332-336
+            xl = layer(x0, xl)
+        return xl, inter
+
+
+def make_inputs(a, hots, b_local, rank, dev):
+    g = torch.Generator(device=dev).manual_seed(1338 + rank)
+    ids = {f"cat_{t:02d}_id": torch.randint(0, a.vocab, (b_local, hots[t]), device=dev, generator=g,
+                                            dtype=torch.int32) for t in range(a.tables)}
+    dense = (torch.rand(b_local, a.dim, device=dev, generator=g) * 0.9).to(torch.bfloat16)
+    return ids, dense
+
+
+def k1_bytes(nnz, bags, dim, es):
+    # nnz*(D*s_t + i) + bags*(D*s_o + 4)
+    return nnz * (dim * es + 4) + bags * (dim * es + 4)
+
+
+def cpu_baseline(a, hots):
+    """The oracle (C restatement, OpenMP) on a bounded sample: batch `cpu_sample_batch`, same tables
+    count/width/bag lengths, vocab capped so the tables fit comfortably in host memory."""
+    from oracle import krs_oracle as ko
+
+    b = a.cpu_sample_batch
+    vocab = min(a.vocab, 200_000)
+    rng = np.random.default_rng(1337)
+    tables = [ko.f32_to_bf16_bits(rng.uniform(-0.05, 0.05, (vocab, a.dim)).astype(np.float32))
+              for _ in range(a.tables)]
+    ids = np.concatenate([rng.integers(0, vocab, b * h) for h in hots]).astype(np.int32)
+    tabs = ko.make_tables(tables)
+    feats = ko.make_features(list(range(a.tables)), ["sum"] * a.tables, [t * a.dim for t in range(a.tables)],
+                             hots=hots, batch=b)
+    out = np.zeros((b, a.tables * a.dim), np.uint16)
+    ko.embed_bag_fwd_raw(tabs, ko.BF16, feats, ids, None, None, b, a.dim, out)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 3.0 or reps < 3:
+        ko.embed_bag_fwd_raw(tabs, ko.BF16, feats, ids, None, None, b, a.dim, out)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    # the dense part of the step on the same sample: one low-rank FeatureCross layer fwd, scaled x3 layers x3 (fwd+bwd)
+    d = (a.tables + 1) * a.dim
+    x = ko.f32_to_bf16_bits(rng.uniform(-1, 1, (256, d)).astype(np.float32))
+    u = ko.f32_to_bf16_bits(rng.uniform(-0.03, 0.03, (d, a.projection)).astype(np.float32))
+    v = ko.f32_to_bf16_bits(rng.uniform(-0.03, 0.03, (a.projection, d)).astype(np.float32))
+    t1 = time.perf_counter()
+    h, _ = ko.gemm(x, u, 256, a.projection, d)
+    ko.gemm(h, v, 256, d, a.projection, x0=x, x=x)
+    t_cross = (time.perf_counter() - t1) * (b / 256) * a.cross_layers * 3
+    lookups = b * sum(hots)
+    return {
+        "value": lookups / (dt + t_cross), "unit": "lookups/s", "cores": os.cpu_count(), "kind": "port",
+        "embed_fwd_lookups_per_s": lookups / dt,
+        "sample": f"oracle/krs_oracle.c (OpenMP, {os.cpu_count()} threads): batch {b} of the same 26-table "
+                  f"workload (vocab capped at {vocab}); embedding gather+pool timed {reps}x, FeatureCross "
+                  "GEMMs timed on 256 rows and scaled to the sample batch x layers x fwd+bwd",
+    }
+
+
+def main():
+    a = parse()
+    rank, world, local = dist_setup(a.gpus)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    hots = (ML_PERF_HOTS * 8)[: a.tables] if a.multihot else [1] * a.tables
+    b_local = a.batch // world
+
+    from keras_rs_amd.build import build
+
+    if rank == 0:
+        build()
+    if world > 1:
+        torch.distributed.barrier()
+
+    model = Model(a, hots, world, rank)
+    ids, dense = make_inputs(a, hots, b_local, rank, dev)
+    model.embedding.build(None)
+    pre = model.embedding.preprocess(ids)
+    opt = None  # created after the first step has built the cross layers
+    scale = 1.0 / (b_local * (a.tables + 1) * a.dim)
+
+    k1_ev = []
+
+    def step(record=False):
+        nonlocal opt
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            emb_probe = model.embedding(pre)  # K1 alone, bracketed by events on the launch stream
+            e1.record()
+            k1_ev.append((e0, e1))
+            del emb_probe
+        xl, inter = model(dense, pre)
+        loss = xl.float().sum() * scale + inter.float().sum() * (scale * 0.1)
+        loss.backward()
+        if opt is None:
+            opt = torch.optim.Adagrad([p for layer in model.cross for p in layer.parameters()], lr=0.0034,
+                                      initial_accumulator_value=0.1, foreach=True)
+        if world > 1:
+            for p in opt.param_groups[0]["params"]:
+                torch.distributed.all_reduce(p.grad)
+                p.grad.div_(world)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # K1 launch duration, measured live (separate short loop so the probe does not sit in the timed region)
+    for _ in range(10):
+        step(record=True)
+    torch.cuda.synchronize()
+    k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
+
+    if rank != 0:
+        return
+    nnz_local = b_local * sum(hots)
+    lookups = a.batch * sum(hots)
+    ms = elapsed / a.steps * 1e3
+    achieved = k1_bytes(nnz_local, b_local * a.tables, a.dim, 2) / k1_s
+    out = {
+        "metric": "embedding lookups/sec + DCN fwd+bwd step time, 26-table DLRM batch 65 536",
+        "value": lookups / (elapsed / a.steps),
+        "unit": "lookups/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms,
+        "higher_is_better": True,
+        "scaling": "weak" if world == 1 else "strong",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": ("C3 DLRM-small: %d tables x %d rows x %d (bf16), global batch %d, %s, "
+                         "DotInteraction(F=%d) + %d x FeatureCross(d=%d, projection=%d), fused Adagrad on tables"
+                         % (a.tables, a.vocab, a.dim, a.batch,
+                            "multi-hot ml_perf lengths (sum L = %d)" % sum(hots) if a.multihot else "hotness L = 1",
+                            a.tables + 1, a.cross_layers, (a.tables + 1) * a.dim, a.projection)),
+            "global_batch": a.batch,
+            "parallelism": "single GPU" if world == 1 else f"tables MOD row-sharded over {world} GPUs, dense part DP",
+        },
+        "embed_fwd_lookups_per_s": nnz_local * world / k1_s,
+        "roofline": {
+            "kernel": "embed_bag_fwd_vec (krs_embed_bag_fwd, K1)", "bound": "hbm",
+            "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+            "traffic": None,
+            "launch_us": k1_s * 1e6,
+            "algorithmic_bytes": k1_bytes(nnz_local, b_local * a.tables, a.dim, 2),
+        },
+    }
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a, hots)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
