@@ -94,7 +94,7 @@ class Model(torch.nn.Module):
             self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16")
         else:
             self.embedding = kl.DistributedEmbedding(feats, dtype="bfloat16", name="embedding_layer")
-        self.dot = kl.DotInteraction()
+        self.dot = kl.DotInteraction(dtype="bfloat16")
         self.cross = torch.nn.ModuleList(
             kl.FeatureCross(projection_dim=a.projection, kernel_initializer=base.GlorotUniform(seed=1337 + i),
                             dtype="mixed_bfloat16") for i in range(a.cross_layers))

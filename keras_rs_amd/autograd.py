@@ -11,6 +11,30 @@ from keras_rs_amd import _lib as L
 from keras_rs_amd import dense_ops as D
 
 
+def _split_columns(out: torch.Tensor, n: int, dim: int):
+    """Per-feature [B, dim] column views of the fused [B, n*dim] lookup output."""
+    return tuple(out[:, i * dim:(i + 1) * dim] for i in range(n))
+
+
+def _gather_feature_grads(grads, batch: int, dim: int, dtype, device):
+    """The per-feature output gradients as ONE [B, n*dim] matrix for K2.  When autograd hands
+    back consecutive column slices of a single buffer (the gradient of a concat), that buffer is
+    used in place (zero copies); otherwise the pieces are concatenated once."""
+    n = len(grads)
+    if all(g is not None for g in grads):
+        g0 = grads[0]
+        es = g0.element_size()
+        ok = g0.dim() == 2 and g0.stride(1) == 1
+        for i, g in enumerate(grads):
+            ok = ok and g.dtype == g0.dtype and g.stride() == g0.stride() and \
+                g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr() and \
+                g.data_ptr() - g0.data_ptr() == i * dim * es
+        if ok and g0.stride(0) >= n * dim:
+            return torch.as_strided(g0, (batch, n * dim), (g0.stride(0), 1), g0.storage_offset())
+    parts = [g if g is not None else torch.zeros((batch, dim), dtype=dtype, device=device) for g in grads]
+    return torch.cat(parts, dim=1)
+
+
 class CrossLayerFn(torch.autograd.Function):
     """y = x0 * (act(h @ K + b) + diag * x) + x,  h = x (full rank) or x @ U (low rank).
 
@@ -25,13 +49,17 @@ class CrossLayerFn(torch.autograd.Function):
         cd = compute_dtype
         x0c = x0.to(cd).contiguous()
         xc = x0c if same else x.to(cd).contiguous()
+        # The forward contracts over the kernels' leading axis: hand the (small) weights to the MFMA
+        # kernel K-contiguous (one transposed copy per step, a few microseconds) so that both GEMM
+        # operands stream into LDS with row-wise 16-byte stores.
         kc = kernel.to(cd)
         h = xc
         dc = None
         if down is not None:
             dc = down.to(cd)
-            h, _ = D.gemm(xc, dc)
-        y, u = D.gemm(h, kc, bias=bias, act=act, diag_scale=diag_scale, x0=x0c, x=xc, want_u=True)
+            h, _ = D.gemm(xc, dc.t().contiguous(), b_is_nk=True)
+        y, u = D.gemm(h, kc.t().contiguous(), b_is_nk=True, bias=bias, act=act, diag_scale=diag_scale,
+                      x0=x0c, x=xc, want_u=True)
         ctx.save_for_backward(x0c, xc, h if down is not None else None, u, dc, kc)
         ctx.meta = (diag_scale, act, same, down is not None, bias is not None,
                     x0.dtype, x.dtype, None if down is None else down.dtype, kernel.dtype)
@@ -100,7 +128,8 @@ class DotInteractionFn(torch.autograd.Function):
 
 class EmbedBagFn(torch.autograd.Function):
     """Fused gather+pool over a FusedBags group with the reference's autodiff semantics:
-    dense [V, D] table gradients, computed by the sort-based K2."""
+    dense [V, D] table gradients, computed by the sort-based K2.
+    Returns one [B, D] tensor per feature (column views of one fused buffer)."""
 
     @staticmethod
     def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, check_ids, *tables):
@@ -113,12 +142,14 @@ class EmbedBagFn(torch.autograd.Function):
         ctx.bags, ctx.batch, ctx.hots = bags, batch, hots
         ctx.save_for_backward(ids, offsets, weights, scale)
         ctx.table_dtypes = [t.dtype for t in tables]
-        return out
+        ctx.out_meta = (out.dtype, out.device)
+        return _split_columns(out, len(bags.features), bags.dim)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         ids, offsets, weights, scale = ctx.saved_tensors
         bags = ctx.bags
+        g = _gather_feature_grads(gs, ctx.batch, bags.dim, *ctx.out_meta)
         ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
         grads = bags.backward_dense(ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                                     bag_scale=scale)
@@ -138,12 +169,14 @@ class EmbedBagFusedFn(torch.autograd.Function):
                                   out_dtype=out_dtype, want_scale=True)
         ctx.bags, ctx.batch, ctx.hots, ctx.optimizer = bags, batch, hots, optimizer
         ctx.save_for_backward(ids, offsets, weights, scale)
-        return out
+        ctx.out_meta = (out.dtype, out.device)
+        return _split_columns(out, len(bags.features), bags.dim)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         ids, offsets, weights, scale = ctx.saved_tensors
         bags = ctx.bags
+        g = _gather_feature_grads(gs, ctx.batch, bags.dim, *ctx.out_meta)
         ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
         bags.backward_fused(ctx.optimizer, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                             bag_scale=scale)

@@ -52,6 +52,7 @@ struct GemmParams {
   int has_ep;
   // split-K
   int splits; int64_t k_per_split; float* slabs;
+  int ep_vec;  // every epilogue operand allows 8-wide vector access
 };
 
 __device__ __forceinline__ float apply_act(int act, float v) {
@@ -81,6 +82,64 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t i, i
   st_elem(p.c, odt, i * p.ldc + j, v);
 }
 
+// 8 consecutive columns of one row; every pointer 16-byte aligned, every ld a multiple of 8
+__device__ __forceinline__ void load8(const void* base, int dt, int64_t off, float (&f)[8]) {
+  if (dt == KRS_BF16) {
+    const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + off);
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+    const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+}
+__device__ __forceinline__ void store8(void* base, int dt, int64_t off, const float (&f)[8]) {
+  if (dt == KRS_BF16) {
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + off) =
+        make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                   pack_bf16x2(f[6], f[7]));
+  } else {
+    float* d = reinterpret_cast<float*>(base) + off;
+    *reinterpret_cast<float4*>(d) = make_float4(f[0], f[1], f[2], f[3]);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
+  }
+}
+
+__device__ __forceinline__ void epilogue_store_vec8(const GemmParams& p, int64_t i, int64_t j, float (&v)[8]) {
+  const int odt = p.out_dtype;
+  if (p.has_ep) {
+    const krs_gemm_epilogue& e = p.ep;
+    if (e.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(e.bias + j);
+      const float4 b1 = *reinterpret_cast<const float4*>(e.bias + j + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+      v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (e.act != KRS_ACT_NONE) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = apply_act(e.act, v[q]);
+    }
+    if (e.x0) {
+      float xv[8], x0v[8];
+      load8(e.x, odt, i * e.ldx + j, xv);
+      load8(e.x0, odt, i * e.ldx + j, x0v);
+      if (e.u_out) store8(e.u_out, odt, i * e.ldu + j, v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = x0v[q] * (v[q] + e.diag_scale * xv[q]) + xv[q];
+    }
+    if (e.r) {
+      float rv[8];
+      load8(e.r, odt, i * e.ldr + j, rv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += e.beta * rv[q];
+    }
+  }
+  store8(p.c, odt, i * p.ldc + j, v);
+}
+
 // ---- staging: HBM -> registers -> LDS ([row][k] with 144-byte rows) ---------
 // ES = element size (2 | 4).  `row0` tile origin along the operand's row axis
 // (m for A, n for B), `k0` along K.  rows/kk are the operand extents.
@@ -100,12 +159,24 @@ __device__ __forceinline__ void load_kcontig(const char* base, int64_t ld, int64
     r[i] = v;
   }
 }
+// LDS address of 16-byte chunk `c` (0..7) of tile row `row`.
+//   K-contiguous staged operands: 144-byte rows, no swizzle: fragment reads (ds_read_b128) and
+//     the row-wise ds_write_b128 stores are both conflict-free;
+//   transposed-staged operands: 128-byte rows, chunk XOR (row >> 3): the column-wise
+//     ds_write_b64 / b128 stores drop from 16-way to the 2-way minimum of that access shape
+//     and fragment reads cost 2 cycles per lane group (scripts/lds_conflicts.py).
+template <bool KS>
+__device__ __forceinline__ int lds_chunk_off(int row, int c) {
+  if constexpr (KS) return row * ROW_BYTES + ((c ^ ((row >> 3) & 7)) << 4);
+  else return row * LDS_STRIDE + (c << 4);
+}
+
 __device__ __forceinline__ void store_kcontig(char* tile, const u32x4 (&r)[4]) {
   const int t = threadIdx.x;
   const int c = t & 7;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    *reinterpret_cast<u32x4*>(tile + ((t >> 3) + 32 * i) * LDS_STRIDE + c * 16) = r[i];
+    *reinterpret_cast<u32x4*>(tile + lds_chunk_off<false>((t >> 3) + 32 * i, c)) = r[i];
 }
 
 // operand stored K-strided: elem(row, k) at base + (k*ld + row)*ES.  A thread
@@ -140,7 +211,7 @@ __device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) 
     for (int jj = 0; jj < 4; ++jj) {
       const int j = jj;
       u32x4 o = {r[0][j], r[1][j], r[2][j], r[3][j]};
-      *reinterpret_cast<u32x4*>(tile + (rb * 4 + j) * LDS_STRIDE + kb * 16) = o;
+      *reinterpret_cast<u32x4*>(tile + lds_chunk_off<true>(rb * 4 + j, kb)) = o;
     }
   } else {
 #pragma unroll
@@ -155,7 +226,7 @@ __device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) 
         lo = (r[0][w] & 0xffffu) | (r[1][w] << 16);
         hi = (r[2][w] & 0xffffu) | (r[3][w] << 16);
       }
-      *reinterpret_cast<uint2*>(tile + (rb * 8 + j) * LDS_STRIDE + kb * 8) = make_uint2(lo, hi);
+      *reinterpret_cast<uint2*>(tile + lds_chunk_off<true>(rb * 8 + j, kb >> 1) + (kb & 1) * 8) = make_uint2(lo, hi);
     }
   }
 }
@@ -206,19 +277,19 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmParams p) {
   __syncthreads();
 
   const int frow = lane & 31;          // fragment row (m for A, n for B)
-  const int fk = (lane >> 5) * 16;     // byte offset of this lane's 16-byte K chunk
+  const int fhalf = lane >> 5;         // which 16-byte half of a 32-byte K step this lane feeds
   for (int64_t t = 0; t < ntiles; ++t) {
     const int cur = (int)(t & 1);
     if (t + 1 < ntiles) load_tiles(t + 1);  // in flight under the MFMAs below
-    const char* ta = tile_a(cur) + (wm * 64 + frow) * LDS_STRIDE + fk;
-    const char* tb = tile_b(cur) + (wn * 64 + frow) * LDS_STRIDE + fk;
+    const char* ta = tile_a(cur);
+    const char* tb = tile_b(cur);
 #pragma unroll
     for (int ks = 0; ks < ROW_BYTES / 32; ++ks) {  // 32 bytes of K per step (2 lane halves x 16 B)
       u32x4 fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        fa[i] = *reinterpret_cast<const u32x4*>(ta + i * 32 * LDS_STRIDE + ks * 32);
-        fb[i] = *reinterpret_cast<const u32x4*>(tb + i * 32 * LDS_STRIDE + ks * 32);
+        fa[i] = *reinterpret_cast<const u32x4*>(ta + lds_chunk_off<A_KM>(wm * 64 + i * 32 + frow, ks * 2 + fhalf));
+        fb[i] = *reinterpret_cast<const u32x4*>(tb + lds_chunk_off<!B_NK>(wn * 64 + i * 32 + frow, ks * 2 + fhalf));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -239,27 +310,45 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmParams p) {
     __syncthreads();
   }
 
-  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
-  const int ccol = lane & 31;
-  const int crow = 4 * (lane >> 5);
-  auto write_frag = [&](const f32x16& v, int i, int j) {
-    const int64_t gn = n0 + wn * 64 + j * 32 + ccol;
-    const int64_t gmb = m0 + wm * 64 + i * 32 + crow;
+  // Epilogue.  The accumulators go through LDS (the operand tiles are dead: every wave passed
+  // the loop's last barrier) so that each lane ends up with 8 consecutive columns of one row:
+  // x0 / x / R are then read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
+  // MFMA C/D layout: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+  constexpr int SST = 68;  // staging row stride in floats (64 + pad)
+  float* stage = reinterpret_cast<float*>(smem) + wave * (64 * SST);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t gm = gmb + (r & 3) + 8 * (r >> 2);
-      if (gm < p.m && gn < p.n) {
-        if (p.splits > 1)
-          p.slabs[((int64_t)split * p.m + gm) * p.n + gn] = v[r];
-        else
-          epilogue_store(p, gm, gn, v[r]);
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc[i][j][r];
+  __syncthreads();
+  const int ec = (lane & 7) * 8;
+  const int64_t gn = n0 + wn * 64 + ec;
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int er = it * 8 + (lane >> 3);
+    const int64_t gm = m0 + wm * 64 + er;
+    if (gm >= p.m || gn >= p.n) continue;
+    float v[8];
+    const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
+    const float4 v1 = *reinterpret_cast<const float4*>(stage + er * SST + ec + 4);
+    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    if (p.splits > 1) {
+      float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
+      if (p.ep_vec) {
+        *reinterpret_cast<float4*>(dst) = v0;
+        *reinterpret_cast<float4*>(dst + 4) = v1;
+      } else {
+        for (int q = 0; q < 8 && gn + q < p.n; ++q) dst[q] = v[q];
       }
+    } else if (p.ep_vec) {
+      epilogue_store_vec8(p, gm, gn, v);
+    } else {
+      for (int q = 0; q < 8 && gn + q < p.n; ++q) epilogue_store(p, gm, gn + q, v[q]);
     }
-  };
-  write_frag(acc[0][0], 0, 0);
-  write_frag(acc[0][1], 0, 1);
-  write_frag(acc[1][0], 1, 0);
-  write_frag(acc[1][1], 1, 1);
+  }
 }
 
 // fixed-order reduction of the split-K slabs + epilogue
@@ -523,6 +612,17 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
   p.has_ep = epilogue != nullptr;
   if (epilogue) p.ep = *epilogue; else memset(&p.ep, 0, sizeof(p.ep));
   p.splits = 1; p.k_per_split = k; p.slabs = nullptr;
+  {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool v = n % 8 == 0 && ldc % 8 == 0 && al16(c);
+    if (epilogue) {
+      if (epilogue->bias) v = v && al16(epilogue->bias);
+      if (epilogue->x0) v = v && al16(epilogue->x0) && al16(epilogue->x) && epilogue->ldx % 8 == 0;
+      if (epilogue->u_out) v = v && al16(epilogue->u_out) && epilogue->ldu % 8 == 0;
+      if (epilogue->r) v = v && al16(epilogue->r) && epilogue->ldr % 8 == 0;
+    }
+    p.ep_vec = v;
+  }
   const int es = in_dtype == KRS_BF16 ? 2 : 4;
   if (k > 0 && mfma_eligible(p, es) && !(p.a_km && p.b_nk)) {
     const int s = pick_splits(m, n, k);

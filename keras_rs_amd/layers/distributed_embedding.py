@@ -319,8 +319,8 @@ class DistributedEmbedding(base.Layer):
             else:
                 out = EmbedBagFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w, out_dtype,
                                        False, *g.bags.tables)
-            for i, path in enumerate(g.paths):
-                outputs[path] = out[:, i * g.dim:(i + 1) * g.dim]
+            for path, o in zip(g.paths, out):
+                outputs[path] = o
         return outputs
 
     def _sparsecore_call(self, inputs, weights=None, training=False):

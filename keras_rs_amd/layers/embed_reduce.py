@@ -108,7 +108,8 @@ class EmbedReduce(base.Layer):
                                      f"`inputs` ({ids.numel()} values).")
             out_dtype = self._out_dtype(w)
             return EmbedBagFn.apply(self._fused(self.combiner), ids, batch, None, offsets,
-                                    None if w is None else w.float().reshape(-1), out_dtype, True, self.embeddings)
+                                    None if w is None else w.float().reshape(-1), out_dtype, True,
+                                    self.embeddings)[0]
 
         ids = as_index_tensor(inputs, dev)
         if ids.dim() not in (1, 2):
@@ -134,7 +135,7 @@ class EmbedReduce(base.Layer):
             w = w.float().expand(ids.shape).contiguous().reshape(-1) if w.dim() < ids.dim() else \
                 w.float().contiguous().reshape(-1)
         return EmbedBagFn.apply(self._fused(combiner), ids.contiguous().reshape(-1), batch, (hot,), None, w,
-                                out_dtype, True, self.embeddings)
+                                out_dtype, True, self.embeddings)[0]
 
     def _out_dtype(self, w):
         cd = self.compute_dtype
