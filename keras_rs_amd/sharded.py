@@ -1,0 +1,284 @@
+"""Row-sharded embedding tables across the GPUs of one node (config C4 / SURVEY.md section 8e).
+
+Layout (the reference's own convention, sharding_strategy="MOD" at
+keras_rs/src/layers/embedding/jax/embedding_utils.py:194, reassembly code at
+tensorflow/distributed_embedding.py:316-328): global row r of every table lives on rank
+r % N at local row r // N.  Each rank keeps ONE stacked buffer [T * Vloc, D] (Vloc =
+ceil(V_max / N)) so that a lookup anywhere in the group is `t * Vloc + r // N`.
+
+Per step (one process per GPU, torch.distributed over RCCL/xGMI; xGMI is point-to-point, so the
+exchange is an all-to-all whose pairs each use their own link):
+  fwd  1. composite id c = t*Vloc*N + r  (c % N = owner, c // N = stacked local row)
+       2. K5 MOD-bucketise c (stable), all-to-all of bucket counts, all-to-all-v of local rows
+       3. owner: K1 row gather on its shard           -> one vector per lookup
+       4. all-to-all-v of the vectors back to the sample's home rank
+       5. home: K1 again, with the returned vectors as the "table" and the inverse bucket
+          permutation as ids -> weighted pooling (sum / mean / sqrtn) per bag
+  bwd  mirror image: K2 (dense form) on the returned-vector "table" gives d(vector) per lookup,
+       all-to-all-v to the owners, K2 fused SGD / Adagrad on the shard.  Every row has exactly
+       one owner, so table gradients need no cross-GPU reduction.
+
+The exchange logic is independent of the compute kernels: `kernels` is an object with the four
+methods of HipShardKernels.  The product default runs the HIP kernels; the CPU/gloo tests in
+tests/test_sharded_gloo.py inject an oracle-backed implementation to check the permutation and
+collective plumbing with world_size 2.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from keras_rs_amd.layers import base
+from keras_rs_amd.layers.distributed_embedding import resolve_fused_optimizer
+from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig
+
+
+class HipShardKernels:
+    """The compute side of the sharded path on MI355X (K1 / K2 / K5 through the C ABI)."""
+
+    def bucketize(self, ids: torch.Tensor, n_shards: int):
+        from keras_rs_amd import dense_ops as D
+
+        return D.mod_bucketize(ids, n_shards)
+
+    def gather_rows(self, table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        from keras_rs_amd.embedding_ops import FusedBags
+
+        n = rows.numel()
+        if n == 0:
+            return torch.empty((0, table.shape[1]), dtype=table.dtype, device=table.device)
+        out, _ = FusedBags([table], [(0, "sum", 0)]).forward(rows, n, hots=(1,))
+        return out
+
+    def pool(self, vectors: torch.Tensor, slot_of_pos: torch.Tensor, feats, batch, hots, offsets, weights, out_dtype):
+        from keras_rs_amd.embedding_ops import FusedBags
+
+        fb = FusedBags([vectors], feats)
+        out, scale = fb.forward(slot_of_pos, batch, hots=hots, offsets=offsets, weights=weights,
+                                out_dtype=out_dtype, want_scale=True)
+        return out, scale
+
+    def pool_backward(self, n_rows, dim, dtype, slot_of_pos, feats, batch, hots, offsets, weights, scale, grad):
+        from keras_rs_amd.embedding_ops import FusedBags
+
+        dummy = torch.empty((n_rows, dim), dtype=dtype, device=grad.device)
+        fb = FusedBags([dummy], feats)
+        ws = fb.plan_backward(slot_of_pos, batch, hots=hots, offsets=offsets)
+        (dv,) = fb.backward_dense(ws, grad, batch, slot_of_pos.numel(), hots=hots, weights=weights, bag_scale=scale)
+        return dv.to(dtype)
+
+    def apply_rows(self, table, slot, rows, grads, lr, kind):
+        from keras_rs_amd.embedding_ops import FusedBags
+
+        n = rows.numel()
+        if n == 0:
+            return
+        fb = FusedBags([table], [(0, "sum", 0)], slots=[slot], lrs=[lr])
+        ws = fb.plan_backward(rows, n, hots=(1,))
+        fb.backward_fused(kind, ws, grads, n, n, hots=(1,))
+
+
+class _ShardedLookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layer, ids, batch, hots, offsets, weights, anchor):
+        out, saved = layer._forward_impl(ids, batch, hots, offsets, weights)
+        ctx.layer, ctx.saved = layer, saved
+        n = len(layer._paths)
+        return tuple(out[:, i * layer.dim:(i + 1) * layer.dim] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        layer = ctx.layer
+        from keras_rs_amd.autograd import _gather_feature_grads
+
+        out_dtype, device = ctx.saved["out_meta"]
+        g = _gather_feature_grads(gs, ctx.saved["batch"], layer.dim, out_dtype, device)
+        layer._backward_impl(g, ctx.saved)
+        return (None, None, None, None, None, None, torch.zeros((), device=device))
+
+
+class ShardedDistributedEmbedding(base.Layer):
+    """DistributedEmbedding whose tables are MOD row-sharded over the ranks of `process_group`.
+
+    feature_configs: flat dict {name: FeatureConfig}; all tables share embedding_dim; the
+    per-table optimizer (SGD / Adagrad) is fused into the backward as on the single-GPU
+    'sparsecore' placement.  call(inputs) takes raw {name: ids} or the result of preprocess()."""
+
+    def __init__(self, feature_configs: dict[str, FeatureConfig], *, process_group=None, kernels=None,
+                 **kwargs: Any):
+        super().__init__(**kwargs)
+        self._pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.kernels = kernels or HipShardKernels()
+        self._feature_configs = feature_configs
+        self._paths = list(feature_configs.keys())
+        tcs: list = []
+        self._table_of_feature = []
+        for p in self._paths:
+            tc = feature_configs[p].table
+            idx = next((i for i, t in enumerate(tcs) if t is tc), None)
+            if idx is None:
+                idx = len(tcs)
+                tcs.append(tc)
+            self._table_of_feature.append(idx)
+        self._table_configs = tcs
+        dims = {tc.embedding_dim for tc in tcs}
+        if len(dims) != 1:
+            raise NotImplementedError("ShardedDistributedEmbedding: tables must share embedding_dim")
+        self.dim = dims.pop()
+        kinds = {resolve_fused_optimizer(tc.optimizer) for tc in tcs}
+        if None in kinds or len({k[0] for k in kinds}) != 1 or len({k[1] for k in kinds}) != 1:
+            raise NotImplementedError("ShardedDistributedEmbedding: one SGD/Adagrad setting for all tables")
+        self._opt_kind, self._lr, self._acc0 = next(iter(kinds))
+        self.vloc = max(math.ceil(tc.vocabulary_size / self.world) for tc in tcs)
+        self._combiners = [feature_configs[p].table.combiner for p in self._paths]
+        self.register_parameter("shard", None)
+        self._slot = None
+        self._anchor = None
+        self._offset_cache: dict = {}
+
+    # ---------------------------------------------------------------- tables
+    def build(self, *_):
+        if self.shard is not None:
+            self.built = True
+            return
+        rows = len(self._table_configs) * self.vloc
+        shard = torch.zeros((rows, self.dim), dtype=self.variable_dtype, device=self._device)
+        for t, tc in enumerate(self._table_configs):
+            # rank r holds global rows r, r+N, r+2N, ...: initialise the full table deterministically
+            # only when it is small; otherwise draw the local rows directly
+            n_local = len(range(self.rank, tc.vocabulary_size, self.world))
+            init = base.get_initializer(tc.initializer)
+            if tc.vocabulary_size * self.dim <= (1 << 24):
+                full = init((tc.vocabulary_size, self.dim), self.variable_dtype, self._device)
+                shard[t * self.vloc: t * self.vloc + n_local] = full[self.rank::self.world]
+            else:
+                shard[t * self.vloc: t * self.vloc + n_local] = init((n_local, self.dim), self.variable_dtype,
+                                                                     self._device)
+        self.shard = torch.nn.Parameter(shard, requires_grad=False)
+        self._weight_order.append(self.shard)
+        if self._opt_kind == "adagrad":
+            self._slot = torch.full((rows, self.dim), self._acc0, dtype=torch.float32, device=self._device)
+        self._anchor = torch.zeros((), device=self._device, requires_grad=True)
+        self.built = True
+
+    def get_embedding_tables(self) -> dict[str, torch.Tensor]:
+        """Unsharded [V, D] tables by name (all-gather + un-interleave), base:810-825 contract."""
+        if not self.built:
+            self.build()
+        parts = [torch.empty_like(self.shard.data) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(parts, self.shard.data.contiguous(), group=self._pg)
+        else:
+            parts = [self.shard.data]
+        out = {}
+        for t, tc in enumerate(self._table_configs):
+            full = torch.empty((tc.vocabulary_size, self.dim), dtype=self.shard.dtype, device=self.shard.device)
+            for r in range(self.world):
+                n_local = len(range(r, tc.vocabulary_size, self.world))
+                full[r::self.world] = parts[r][t * self.vloc: t * self.vloc + n_local]
+            out[tc.name] = full
+        return out
+
+    def set_embedding_tables(self, tables: dict) -> None:
+        if not self.built:
+            self.build()
+        with torch.no_grad():
+            for t, tc in enumerate(self._table_configs):
+                if tc.name in tables:
+                    full = torch.as_tensor(np.asarray(tables[tc.name])).to(self.shard.dtype).to(self.shard.device)
+                    mine = full[self.rank::self.world]
+                    self.shard[t * self.vloc: t * self.vloc + mine.shape[0]] = mine
+
+    # ---------------------------------------------------------------- inputs
+    def preprocess(self, inputs: dict, weights: dict | None = None, training: bool = False):
+        if not self.built:
+            self.build()
+        dev = self.shard.device
+        parts, wparts, hots, batch = [], [], [], None
+        for p in self._paths:
+            x = inputs[p]
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+            if t.dim() == 1:
+                t = t.reshape(-1, 1)
+            batch = t.shape[0] if batch is None else batch
+            if t.shape[0] != batch:
+                raise ValueError("all features must share the batch size")
+            hots.append(int(t.shape[1]))
+            parts.append(t.reshape(-1).to(torch.int64 if t.dtype == torch.int64 else torch.int32))
+            if weights is not None:
+                w = weights[p]
+                w = w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w))
+                wparts.append(w.reshape(-1).float())
+        ids = torch.cat(parts).to(dev, non_blocking=True)
+        w = torch.cat(wparts).to(dev, non_blocking=True) if weights is not None else None
+        return {"preprocessed_inputs_per_placement": {"sparsecore": {
+            "inputs": {"ids": ids, "hots": tuple(hots), "batch": batch, "offsets": None}, "weights": w}}}
+
+    def _composite_offsets(self, batch, hots, dtype, device):
+        key = (batch, hots, dtype, str(device))
+        off = self._offset_cache.get(key)
+        if off is None:
+            per_feat = torch.tensor([self._table_of_feature[i] * self.vloc * self.world for i in range(len(hots))],
+                                    dtype=dtype)
+            reps = torch.tensor([batch * h for h in hots])
+            off = torch.repeat_interleave(per_feat, reps).to(device)
+            self._offset_cache[key] = off
+        return off
+
+    # ---------------------------------------------------------------- step
+    def call(self, inputs, weights=None, training: bool = False):
+        if not (isinstance(inputs, dict) and "preprocessed_inputs_per_placement" in inputs):
+            inputs = self.preprocess(inputs, weights, training)
+        pre = inputs["preprocessed_inputs_per_placement"]["sparsecore"]
+        fi = pre["inputs"]
+        outs = _ShardedLookupFn.apply(self, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], pre.get("weights"),
+                                      self._anchor)
+        return {p: o for p, o in zip(self._paths, outs)}
+
+    def _a2a(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
+        recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if self.world == 1:
+            recv.copy_(send)
+        else:
+            dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts,
+                                   input_split_sizes=send_counts, group=self._pg)
+        return recv
+
+    def _forward_impl(self, ids, batch, hots, offsets, weights):
+        k, n = self.kernels, self.world
+        comp = ids + self._composite_offsets(batch, hots, ids.dtype, ids.device)
+        local_rows, perm, counts = k.bucketize(comp, n)
+        # bucket sizes -> every rank learns how much it receives (tiny all-to-all + one host sync)
+        recv_counts_t = torch.empty_like(counts)
+        if n > 1:
+            dist.all_to_all_single(recv_counts_t, counts, group=self._pg)
+        else:
+            recv_counts_t.copy_(counts)
+        send_counts = counts.tolist()
+        recv_counts = recv_counts_t.tolist()
+        recv_rows = self._a2a(local_rows, send_counts, recv_counts)             # owner side: rows to serve
+        vectors = k.gather_rows(self.shard.data, recv_rows)                     # [n_recv, D]
+        back = self._a2a(vectors, recv_counts, send_counts)                     # home side, bucket order
+        slot_of_pos = torch.empty_like(perm)
+        slot_of_pos[perm.long()] = torch.arange(perm.numel(), dtype=perm.dtype, device=perm.device)
+        feats = [(0, c, i * self.dim) for i, c in enumerate(self._combiners)]
+        out, scale = k.pool(back, slot_of_pos, feats, batch, hots, offsets, weights, self.compute_dtype)
+        saved = dict(batch=batch, hots=hots, offsets=offsets, weights=weights, scale=scale, feats=feats,
+                     slot_of_pos=slot_of_pos, send_counts=send_counts, recv_counts=recv_counts,
+                     recv_rows=recv_rows, n_back=back.shape[0], vec_dtype=back.dtype,
+                     out_meta=(out.dtype, out.device))
+        return out, saved
+
+    def _backward_impl(self, g, s):
+        k = self.kernels
+        dvec = k.pool_backward(s["n_back"], self.dim, s["vec_dtype"], s["slot_of_pos"], s["feats"], s["batch"],
+                               s["hots"], s["offsets"], s["weights"], s["scale"], g)
+        drows = self._a2a(dvec, s["send_counts"], s["recv_counts"])             # to the owners
+        k.apply_rows(self.shard.data, self._slot, s["recv_rows"], drows, self._lr, self._opt_kind)

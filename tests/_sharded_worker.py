@@ -1,0 +1,126 @@
+"""Worker of tests/test_sharded_gloo.py: world_size-2 gloo run of the sharded embedding exchange on
+CPU, with the compute kernels replaced by the CPU oracle (test infrastructure) so that only the
+bucketise / all-to-all / permutation plumbing of keras_rs_amd/sharded.py is under test."""
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import krs_oracle as ko  # noqa: E402
+
+
+class OracleShardKernels:
+    def bucketize(self, ids, n):
+        l, p, c = ko.mod_bucketize(ids.numpy(), n)
+        return torch.from_numpy(l), torch.from_numpy(p), torch.from_numpy(c)
+
+    def gather_rows(self, table, rows):
+        t = table.detach().numpy()
+        return torch.from_numpy(t[rows.numpy()].copy()) if rows.numel() else torch.zeros((0, t.shape[1]))
+
+    def pool(self, vectors, slot_of_pos, feats, batch, hots, offsets, weights, out_dtype):
+        v = np.ascontiguousarray(vectors.numpy())
+        if v.shape[0] == 0:
+            v = np.zeros((1, v.shape[1]), np.float32)
+        tabs = ko.make_tables([v])
+        f = ko.make_features([0] * len(feats), [c for _, c, _ in feats], [col for _, _, col in feats], hots=hots,
+                             batch=batch)
+        out = np.zeros((batch, len(feats) * v.shape[1]), np.float32)
+        scale = np.zeros(len(feats) * batch, np.float32)
+        ko.embed_bag_fwd_raw(tabs, ko.F32, f, slot_of_pos.numpy(), None,
+                             None if weights is None else weights.numpy(), batch, v.shape[1], out, scale)
+        return torch.from_numpy(out), torch.from_numpy(scale)
+
+    def pool_backward(self, n_rows, dim, dtype, slot_of_pos, feats, batch, hots, offsets, weights, scale, grad):
+        de = np.zeros((max(n_rows, 1), dim), np.float32)
+        f = ko.make_features([0] * len(feats), [c for _, c, _ in feats], [col for _, _, col in feats], hots=hots,
+                             batch=batch)
+        ko.embed_bag_bwd_dense(ko.make_tables([de]), f, slot_of_pos.numpy(), None,
+                               None if weights is None else weights.numpy(), scale.numpy(),
+                               np.ascontiguousarray(grad.numpy()), batch, dim)
+        return torch.from_numpy(de[:n_rows])
+
+    def apply_rows(self, table, slot, rows, grads, lr, kind):
+        t = table.numpy()
+        dense = np.zeros_like(t)
+        np.add.at(dense, rows.numpy(), grads.numpy())
+        touched = np.zeros(t.shape[0], np.uint8)
+        touched[rows.numpy()] = 1
+        ko.apply_optimizer(t, None if slot is None else slot.numpy(), dense, touched, lr, kind)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import keras_rs_amd.layers as kl
+    from keras_rs_amd.sharded import ShardedDistributedEmbedding
+
+    kind = sys.argv[1]
+    opt = kl.SGD(0.1) if kind == "sgd" else kl.Adagrad(0.1, 0.1)
+    V, D, B = [37, 10, 64], 8, 6
+    combs = ["sum", "mean", "sqrtn", "sum"]
+    tcs = [kl.TableConfig(f"t{i}", V[i], D, optimizer=opt, combiner="sum", placement="sparsecore") for i in range(3)]
+    feats = {}
+    hots = [1, 3, 2, 4]
+    tix = [0, 1, 2, 0]  # feature 3 shares table 0
+    for i in range(4):
+        tc = tcs[tix[i]]
+        # the combiner is a property of the table in the reference; give shared-table features the table's
+        feats[f"f{i}"] = kl.FeatureConfig(f"f{i}", tc, (B, hots[i]), (B, D))
+    for i, tc in enumerate(tcs):
+        tc.combiner = combs[i]
+    layer = ShardedDistributedEmbedding(feats, kernels=OracleShardKernels(), device="cpu")
+    rng = np.random.default_rng(7)
+    full = {f"t{i}": rng.uniform(-1, 1, (V[i], D)).astype(np.float32) for i in range(3)}
+    layer.set_embedding_tables(full)
+    got_tables = layer.get_embedding_tables()
+    for k in full:
+        np.testing.assert_array_equal(got_tables[k].numpy(), full[k])  # shard / unshard round trip
+
+    rng_r = np.random.default_rng(100 + rank)  # every rank has its own batch
+    ids = {f"f{i}": rng_r.integers(0, V[tix[i]], (B, hots[i])).astype(np.int32) for i in range(4)}
+    w = {f"f{i}": rng_r.uniform(0.1, 1, (B, hots[i])).astype(np.float32) for i in range(4)}
+    out = layer(ids, w)
+    g = {k: torch.from_numpy(rng_r.uniform(0, 1, (B, D)).astype(np.float32)) for k in out}
+    sum((o * g[k]).sum() for k, o in out.items()).backward()
+
+    # unsharded oracle: forward per rank, table update from the contributions of ALL ranks
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (ids, w, {k: v.numpy() for k, v in g.items()}))
+    for i in range(4):
+        comb = tcs[tix[i]].combiner
+        exp = ko.embed_reduce(full[f"t{tix[i]}"], ids[f"f{i}"], w[f"f{i}"], comb)
+        np.testing.assert_allclose(out[f"f{i}"].detach().numpy(), exp, rtol=1e-6, atol=1e-6)
+    dense = {k: np.zeros_like(v) for k, v in full.items()}
+    touched = {k: np.zeros(v.shape[0], np.uint8) for k, v in full.items()}
+    for r_ids, r_w, r_g in gathered:
+        for i in range(4):
+            comb = tcs[tix[i]].combiner
+            tabs = ko.make_tables([dense[f"t{tix[i]}"]])
+            f = ko.make_features([0], [comb], [0], hots=[hots[i]], batch=B)
+            scale = np.zeros(B, np.float32)
+            tmp = np.zeros((B, D), np.float32)
+            ko.embed_bag_fwd_raw(ko.make_tables([full[f"t{tix[i]}"]]), ko.F32, f, r_ids[f"f{i}"].reshape(-1), None,
+                                 r_w[f"f{i}"].reshape(-1), B, D, tmp, scale)
+            ko.embed_bag_bwd_dense(tabs, f, r_ids[f"f{i}"].reshape(-1), None, r_w[f"f{i}"].reshape(-1), scale,
+                                   r_g[f"f{i}"], B, D)
+            touched[f"t{tix[i]}"][r_ids[f"f{i}"].reshape(-1)] = 1
+    after = layer.get_embedding_tables()
+    for k in full:
+        exp = full[k].copy()
+        acc = np.full_like(exp, 0.1)
+        ko.apply_optimizer(exp, acc, dense[k], touched[k], 0.1, kind)
+        np.testing.assert_allclose(after[k].numpy(), exp, rtol=1e-5, atol=1e-6)
+    if rank == 0:
+        print("SHARDED_OK", kind)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

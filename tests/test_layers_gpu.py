@@ -295,3 +295,41 @@ def test_embedding_layer_and_readme_quickstart_shape():
     assert torch.equal(x0, emb.embeddings[ids.long()])
     seq = emb(torch.randint(0, 32, (3, 4), device=DEV))
     assert tuple(seq.shape) == (3, 4, 6)
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adagrad"])
+def test_sharded_layer_world1_on_hip_matches_unsharded_layer(optimizer):
+    """The sharded path (bucketise -> gather -> pool, K2 dense -> fused apply) on the HIP kernels,
+    degenerate world of 1: same outputs and same updated tables as DistributedEmbedding."""
+    kl = _layers()
+    from keras_rs_amd.sharded import ShardedDistributedEmbedding
+
+    opt = kl.SGD(0.1) if optimizer == "sgd" else kl.Adagrad(0.1, 0.1)
+    rng = np.random.default_rng(5)
+    V, D, B = [50, 31], 16, 24
+    hots = [1, 3, 2]
+    tix = [0, 1, 0]
+
+    def make(cls, **kw):
+        tcs = [kl.TableConfig(f"t{i}", V[i], D, optimizer=opt, combiner=["mean", "sum"][i], placement="sparsecore")
+               for i in range(2)]
+        fcs = {f"f{i}": kl.FeatureConfig(f"f{i}", tcs[tix[i]], (B, hots[i]), (B, D)) for i in range(3)}
+        return cls(fcs, **kw)
+
+    full = {f"t{i}": rng.uniform(-1, 1, (V[i], D)).astype(np.float32) for i in range(2)}
+    ids = {f"f{i}": rng.integers(0, V[tix[i]], (B, hots[i])).astype(np.int32) for i in range(3)}
+    w = {f"f{i}": rng.uniform(0.1, 1, (B, hots[i])).astype(np.float32) for i in range(3)}
+    g = {f"f{i}": torch.rand(B, D, device=DEV) for i in range(3)}
+    results = []
+    for layer in (make(kl.DistributedEmbedding), make(ShardedDistributedEmbedding)):
+        layer.build(None)
+        layer.set_embedding_tables(full)
+        out = layer(ids, w)
+        sum((out[k] * g[k]).sum() for k in out).backward()
+        results.append(({k: v.detach().cpu().numpy() for k, v in out.items()},
+                        {k: v.cpu().numpy() for k, v in layer.get_embedding_tables().items()}))
+    for k in results[0][0]:
+        np.testing.assert_allclose(results[1][0][k], results[0][0][k], rtol=1e-6, atol=1e-6)
+    for k in results[0][1]:
+        np.testing.assert_allclose(results[1][1][k], results[0][1][k], rtol=1e-5, atol=1e-6)
+        assert not np.allclose(results[0][1][k], full[k])

@@ -1,0 +1,27 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the MOD-sharded embedding exchange
+(keras_rs_amd/sharded.py) against the unsharded oracle, forward and fused-optimizer backward."""
+
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+def test_sharded_embedding_world2_matches_unsharded_oracle(kind):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_sharded_worker.py"), kind]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0 and f"SHARDED_OK {kind}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
