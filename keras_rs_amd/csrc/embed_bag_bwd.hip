@@ -18,6 +18,7 @@
 //   => run-to-run bit-identical.  The row write is the dense gradient row, or
 //   the SGD / Adagrad update of the table row in place.
 // Algorithmic bytes: bags*D*s_g + nnz*(4+8) + U*(2*D*s_t [+ 2*D*4 Adagrad]).
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -30,12 +31,14 @@ namespace {
 constexpr uint32_t kInvalidKey = 0xffffffffu;
 
 struct PlanLayout {
-  uint32_t* keys_in;
+  uint32_t* keys_in;      // dead after the sort -> reused as head flags
   uint32_t* keys_sorted;
-  uint64_t* vals_in;
+  uint64_t* vals_in;      // dead after the sort -> reused as [head_index | seg_start]
   uint64_t* vals_sorted;
-  uint32_t* head_flag;   // sparse form only
-  uint32_t* head_index;  // sparse form only
+  uint32_t* head_flag;    // = keys_in
+  uint32_t* head_index;   // = vals_in, first n words
+  uint32_t* seg_start;    // = vals_in, next n words: first sorted position of every segment
+  uint32_t* n_seg;        // number of segments (a trailing run of invalid keys counts as one)
   void* temp;
   size_t temp_bytes;
   size_t total_bytes;
@@ -63,10 +66,12 @@ PlanLayout plan_layout(void* ws, int64_t nnz, bool need_temp = false) {
   const size_t n = (size_t)(nnz > 0 ? nnz : 1);
   l.keys_in = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
   l.keys_sorted = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
-  l.vals_in = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8, 256);
+  l.vals_in = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8 + 8, 256);
   l.vals_sorted = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8, 256);
-  l.head_flag = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
-  l.head_index = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
+  l.n_seg = reinterpret_cast<uint32_t*>(p + o); o += 256;
+  l.head_flag = l.keys_in;
+  l.head_index = reinterpret_cast<uint32_t*>(l.vals_in);
+  l.seg_start = reinterpret_cast<uint32_t*>(l.vals_in) + n;
   l.temp = p + o;
   l.temp_bytes = need_temp ? sort_temp_bytes(nnz) : 0;
   l.total_bytes = o + l.temp_bytes;
@@ -126,6 +131,7 @@ struct ApplyParams {
   const krs_table* tables;  // dense: gradient buffers; fused: the tables themselves
   int n_tables;
   const krs_feature* feats;
+  int n_feats;
   const float* weights;
   const float* bag_scale;
   const void* grad;
@@ -135,10 +141,10 @@ struct ApplyParams {
   int64_t nnz;
   const uint32_t* keys;
   const uint64_t* vals;
-  const uint32_t* head_index;  // sparse
+  const uint32_t* seg_start;   // first sorted position of every segment
+  const uint32_t* n_seg;       // device scalar
   int64_t* unique_rows;        // sparse
   float* row_grads;            // sparse
-  int chunk;                   // sorted positions per group
 };
 
 template <typename T>
@@ -162,24 +168,59 @@ struct Piece<uint16_t> {
   }
 };
 
+// N consecutive elements <-> fp32; `aligned` = the address is a multiple of N*sizeof(TT)
+// (<= 32 bytes), in which case the access is one or two wide vector instructions.
 template <typename TT, int N>
-__device__ __forceinline__ void load_elems(const TT* src, float (&f)[N]) {
+__device__ __forceinline__ void load_elems(const TT* src, float (&f)[N], bool aligned = false) {
   if constexpr (sizeof(TT) == 4) {
+    if (aligned) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) f[i] = src[i];
+      for (int i = 0; i < N; i += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        f[i] = v.x; f[i + 1] = v.y; f[i + 2] = v.z; f[i + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) f[i] = src[i];
+    }
   } else {
+    if (aligned) {
+      if constexpr (N == 8) {
+        const uint4 r = *reinterpret_cast<const uint4*>(src);
+        Piece<uint16_t>::unpack(r, f);
+      } else {
+        const uint2 r = *reinterpret_cast<const uint2*>(src);
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < N; ++i) f[i] = bf16_to_f32(src[i]);
+      for (int i = 0; i < N; ++i) f[i] = bf16_to_f32(src[i]);
+    }
   }
 }
 template <typename TT, int N>
-__device__ __forceinline__ void store_elems(TT* dst, const float (&f)[N]) {
+__device__ __forceinline__ void store_elems(TT* dst, const float (&f)[N], bool aligned = false) {
   if constexpr (sizeof(TT) == 4) {
+    if (aligned) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) dst[i] = f[i];
+      for (int i = 0; i < N; i += 4)
+        *reinterpret_cast<float4*>(dst + i) = make_float4(f[i], f[i + 1], f[i + 2], f[i + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) dst[i] = f[i];
+    }
   } else {
+    if (aligned) {
+      if constexpr (N == 8)
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                                                    pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+      else
+        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+    } else {
 #pragma unroll
-    for (int i = 0; i < N; ++i) dst[i] = f32_to_bf16(f[i]);
+      for (int i = 0; i < N; ++i) dst[i] = f32_to_bf16(f[i]);
+    }
   }
 }
 
@@ -194,149 +235,167 @@ __device__ __forceinline__ int find_table(const krs_table* tables, int n_tables,
 }
 
 constexpr int kApplyUnroll = 4;
+constexpr int kSegsPerGroup = 4;  // segments each group walks (amortises the descriptor prologue)
+constexpr int kMaxLdsDesc = 512;  // features / tables whose descriptors are cached in LDS
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
 
 // GT: gradient element, TT: table element (fused modes), LPR lanes per row.
+//
+// One group of LPR lanes per SEGMENT (run of equal keys = one table row); the plan's segment
+// list makes the work dense: groups beyond the segment count leave at once.  A group first
+// issues the loads of the table row (and Adagrad accumulator row) it is going to update, so
+// they travel together with the gradient rows it then gathers four at a time; the loop has no
+// predicated loads (positions are clamped to the segment, contributions masked).  Feature /
+// table descriptors are cached in LDS per workgroup, so the dependent chain is
+// seg_start -> vals -> (LDS) -> gradient rows.  Consecutive segments are consecutive table
+// rows (the stream is sorted by row), so a workgroup's row updates are near-sequential in HBM.
 template <typename GT, typename TT, int LPR, int MODE, bool HAS_W>
 __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
   constexpr int N = Piece<GT>::N;
-  const int64_t group = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+  __shared__ int s_fcol[kMaxLdsDesc];
+  __shared__ int s_ftab[kMaxLdsDesc];
+  __shared__ krs_table s_tab[kMaxLdsDesc];
+  constexpr int GPB = 256 / LPR;         // groups per workgroup
+  const uint32_t n_seg = *p.n_seg;
+  const int64_t u_base = (int64_t)blockIdx.x * (GPB * kSegsPerGroup);
+  if (u_base >= n_seg) return;  // whole workgroup beyond the list
+  const bool lds_desc = p.n_feats <= kMaxLdsDesc && p.n_tables <= kMaxLdsDesc;
+  if (lds_desc) {
+    for (int f = threadIdx.x; f < p.n_feats; f += 256) {
+      s_fcol[f] = p.feats[f].out_col;
+      s_ftab[f] = p.feats[f].table;
+    }
+    if constexpr (MODE != kSparse)
+      for (int t = threadIdx.x; t < p.n_tables; t += 256) s_tab[t] = p.tables[t];
+  }
+  __syncthreads();
+
   const int sub = threadIdx.x % LPR;
   const int row_pieces = (int)(((int64_t)p.dim * sizeof(GT)) >> 4);
-  const int64_t i0 = group * p.chunk;
-  if (i0 >= p.nnz || sub >= row_pieces) return;
-  const int64_t i1 = min(i0 + (int64_t)p.chunk, p.nnz);
+  const bool col_live = sub < row_pieces;
+  const int csub = col_live ? sub : 0;
+  auto feat_col = [&](int f) { return lds_desc ? s_fcol[f] : p.feats[f].out_col; };
+  const char* grad = reinterpret_cast<const char*>(p.grad) + (int64_t)csub * 16;
+  const bool g_aligned = ((reinterpret_cast<uintptr_t>(p.grad) | (uintptr_t)(p.grad_ld * sizeof(GT))) & 15) == 0;
 
-  // segments that started before this chunk belong to an earlier group
-  int64_t i = i0;
-  if (i > 0) {
-    const uint32_t prev = p.keys[i - 1];
-    while (i < i1 && p.keys[i] == prev) ++i;
-    if (i == i1) return;
+  // the workgroup's segments are taken round-robin so that neighbouring groups update neighbouring rows
+#pragma unroll 1
+  for (int it = 0; it < kSegsPerGroup; ++it) {
+  const int64_t u = u_base + (int64_t)it * GPB + threadIdx.x / LPR;
+  if (u >= n_seg) return;
+  const int64_t s0 = p.seg_start[u];
+  const int64_t e0 = u + 1 < n_seg ? (int64_t)p.seg_start[u + 1] : p.nnz;
+  const uint32_t key = p.keys[s0];
+  if (key == kInvalidKey) return;  // the trailing run of out-of-range lookups (always the last segment)
+
+  // ---- the row this segment updates: issue its loads first ----
+  krs_table tb{};
+  int64_t off = 0;
+  if constexpr (MODE != kSparse) {
+    const uint64_t v0 = p.vals[s0];
+    const int f0 = (int)((uint32_t)(v0 >> 32) / (uint32_t)p.batch);
+    const int t = lds_desc ? s_ftab[f0] : p.feats[f0].table;
+    tb = lds_desc ? s_tab[t] : p.tables[t];
+    off = ((int64_t)key - tb.row_base) * p.dim + csub * N;
   }
-  uint32_t cur = p.keys[i];
-  if (cur == kInvalidKey) return;  // invalid keys sort last: nothing more to do
+  float wv[N], av[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) { wv[k] = 0.0f; av[k] = 0.0f; }
+  // dim % N == 0, so a 16-byte aligned buffer keeps every lane's piece naturally aligned
+  const bool t_al = ((reinterpret_cast<uintptr_t>(tb.weights) | reinterpret_cast<uintptr_t>(tb.slot)) & 15) == 0;
+  if constexpr (MODE == kSgd || MODE == kAdagrad)
+    load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
+  if constexpr (MODE == kAdagrad) load_elems<float, N>(tb.slot + off, av, t_al);
 
-  const GT* grad = reinterpret_cast<const GT*>(p.grad) + sub * N;
-  const bool g_aligned =
-      ((reinterpret_cast<uintptr_t>(grad) | (uintptr_t)(p.grad_ld * sizeof(GT))) & 15) == 0;
-
+  // ---- gather and sum the segment's gradient rows, four at a time ----
   float acc[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) acc[k] = 0.0f;
-  int64_t seg_start = i;
-
-  auto finish = [&](uint32_t key) {
-    if constexpr (MODE == kSparse) {
-      const uint32_t u = p.head_index[seg_start];
-      if (sub == 0) p.unique_rows[u] = (int64_t)key;
-      float* dst = p.row_grads + (int64_t)u * p.dim + sub * N;
+  for (int64_t j0 = s0; j0 < e0; j0 += kApplyUnroll) {
+    uint64_t vv[kApplyUnroll];
 #pragma unroll
-      for (int k = 0; k < N; ++k) dst[k] = acc[k];
-    } else {
-      const int t = find_table(p.tables, p.n_tables, (int64_t)key);
-      const krs_table tb = p.tables[t];
-      const int64_t off = ((int64_t)key - tb.row_base) * p.dim + sub * N;
-      if constexpr (MODE == kDense) {
-        float* dst = reinterpret_cast<float*>(tb.weights) + off;
-#pragma unroll
-        for (int k = 0; k < N; ++k) dst[k] = acc[k];
-      } else {
-        TT* w = reinterpret_cast<TT*>(tb.weights) + off;
-        float wv[N];
-        load_elems<TT, N>(w, wv);
-        if constexpr (MODE == kSgd) {
-#pragma unroll
-          for (int k = 0; k < N; ++k) wv[k] = wv[k] - tb.lr * acc[k];
-        } else {
-          float* a = tb.slot + off;
-#pragma unroll
-          for (int k = 0; k < N; ++k) {
-            const float av = fmaf(acc[k], acc[k], a[k]);
-            a[k] = av;
-            wv[k] = wv[k] - tb.lr * acc[k] / sqrtf(av);
-          }
-        }
-        store_elems<TT, N>(w, wv);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] = 0.0f;
-  };
-
-  // flat stream over sorted positions; runs past i1 only to finish the last segment
-  bool done = false;
-  while (!done) {
-    uint32_t kk[kApplyUnroll];
-    uint4 raw[kApplyUnroll];
+    for (int q = 0; q < kApplyUnroll; ++q) vv[q] = p.vals[min(j0 + q, e0 - 1)];
     float coef[kApplyUnroll];
+    u32x4 raw[kApplyUnroll];
 #pragma unroll
-    for (int u = 0; u < kApplyUnroll; ++u) {
-      const int64_t j = i + u;
-      kk[u] = j < p.nnz ? p.keys[j] : kInvalidKey;
-      raw[u] = make_uint4(0, 0, 0, 0);
-      coef[u] = 0.0f;
-      if (kk[u] != kInvalidKey) {
-        const uint64_t v = p.vals[j];
-        const uint32_t bag = (uint32_t)(v >> 32);
-        const uint32_t pos = (uint32_t)v;
-        const int f = (int)(bag / (uint32_t)p.batch);
-        const int b = (int)(bag - (uint32_t)f * (uint32_t)p.batch);
-        float c = 1.0f;
-        if constexpr (HAS_W) c = p.weights[pos];
-        if (p.bag_scale) c *= p.bag_scale[bag];
-        coef[u] = c;
-        const GT* src = grad + (int64_t)b * p.grad_ld + p.feats[f].out_col;
-        if (g_aligned) {
-          raw[u] = *reinterpret_cast<const uint4*>(src);
+    for (int q = 0; q < kApplyUnroll; ++q) {
+      const uint32_t bag = (uint32_t)(vv[q] >> 32);
+      const uint32_t pos = (uint32_t)vv[q];
+      const int f = (int)(bag / (uint32_t)p.batch);
+      const int b = (int)(bag - (uint32_t)f * (uint32_t)p.batch);
+      float c = 1.0f;
+      if constexpr (HAS_W) c = p.weights[pos];
+      if (p.bag_scale) c *= p.bag_scale[bag];
+      coef[q] = c;
+      const char* src = grad + ((int64_t)b * p.grad_ld + feat_col(f)) * (int64_t)sizeof(GT);
+      if (g_aligned) {
+        raw[q] = *(gvec_ptr)src;
+      } else {
+        const GT* e = reinterpret_cast<const GT*>(src);
+        if constexpr (sizeof(GT) == 4) {
+          raw[q] = u32x4{__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
         } else {
-          float tmp[N];
-          load_elems<GT, N>(src, tmp);
-          if constexpr (sizeof(GT) == 4) {
-            raw[u] = make_uint4(__float_as_uint(tmp[0]), __float_as_uint(tmp[1]), __float_as_uint(tmp[2]),
-                                __float_as_uint(tmp[3]));
-          } else {
-            raw[u] = make_uint4(src[0] | ((uint32_t)src[1] << 16), src[2] | ((uint32_t)src[3] << 16),
-                                src[4] | ((uint32_t)src[5] << 16), src[6] | ((uint32_t)src[7] << 16));
-          }
+          raw[q] = u32x4{e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16),
+                         e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16)};
         }
       }
     }
 #pragma unroll
-    for (int u = 0; u < kApplyUnroll; ++u) {
-      if (done) break;
-      const int64_t j = i + u;
-      if (kk[u] != cur) {
-        finish(cur);
-        // a new segment may only start inside this group's chunk
-        if (j >= i1 || kk[u] == kInvalidKey) {
-          done = true;
-          break;
-        }
-        cur = kk[u];
-        seg_start = j;
-      }
-      float gv[N];
-      Piece<GT>::unpack(raw[u], gv);
+    for (int q = 0; q < kApplyUnroll; ++q) {
+      if (j0 + q < e0) {
+        float gv[N];
+        Piece<GT>::unpack(make_uint4(raw[q].x, raw[q].y, raw[q].z, raw[q].w), gv);
 #pragma unroll
-      for (int k = 0; k < N; ++k) acc[k] = fmaf(coef[u], gv[k], acc[k]);
+        for (int k = 0; k < N; ++k) acc[k] = fmaf(coef[q], gv[k], acc[k]);
+      }
     }
-    i += kApplyUnroll;
   }
+  if (!col_live) continue;
+
+  // ---- write the finished row once ----
+  if constexpr (MODE == kSparse) {
+    if (sub == 0) p.unique_rows[u] = (int64_t)key;
+    float* dst = p.row_grads + (int64_t)u * p.dim + sub * N;
+#pragma unroll
+    for (int k = 0; k < N; ++k) dst[k] = acc[k];
+  } else if constexpr (MODE == kDense) {
+    store_elems<float, N>(reinterpret_cast<float*>(tb.weights) + off, acc, t_al);
+  } else {
+    if constexpr (MODE == kSgd) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) wv[k] = wv[k] - tb.lr * acc[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        av[k] = fmaf(acc[k], acc[k], av[k]);
+        wv[k] = wv[k] - tb.lr * acc[k] / sqrtf(av[k]);
+      }
+      store_elems<float, N>(tb.slot + off, av, t_al);
+    }
+    store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
+  }
+  }  // segments of this group
 }
 
-// Any dim / dtype: LPR lanes per segment head, one column per lane per pass.
+// Any dim / dtype: LPR lanes per segment, one column per lane per pass.
 template <int MODE>
 __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, int grad_dtype, int table_dtype,
                                                          int lpr) {
-  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
+  const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / lpr;
   const int sub = threadIdx.x % lpr;
-  if (i >= p.nnz) return;
-  const uint32_t key = p.keys[i];
-  if (key == kInvalidKey || (i > 0 && p.keys[i - 1] == key)) return;
+  const uint32_t n_seg = *p.n_seg;
+  if (u >= n_seg) return;
+  const int64_t s0 = p.seg_start[u];
+  const int64_t e0 = u + 1 < n_seg ? (int64_t)p.seg_start[u + 1] : p.nnz;
+  const uint32_t key = p.keys[s0];
+  if (key == kInvalidKey) return;
   const int t = MODE == kSparse ? 0 : find_table(p.tables, p.n_tables, (int64_t)key);
   for (int c = sub; c < p.dim; c += lpr) {
     float acc = 0.0f;
-    for (int64_t j = i; j < p.nnz && p.keys[j] == key; ++j) {
+    for (int64_t j = s0; j < e0; ++j) {
       const uint64_t v = p.vals[j];
       const uint32_t bag = (uint32_t)(v >> 32);
       const int f = (int)(bag / (uint32_t)p.batch);
@@ -346,7 +405,6 @@ __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, in
       acc = fmaf(coef, ld_elem(p.grad, grad_dtype, (int64_t)b * p.grad_ld + p.feats[f].out_col + c), acc);
     }
     if (MODE == kSparse) {
-      const uint32_t u = p.head_index[i];
       if (c == 0) p.unique_rows[u] = (int64_t)key;
       p.row_grads[(int64_t)u * p.dim + c] = acc;
     } else {
@@ -369,21 +427,29 @@ __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, in
   }
 }
 
+// ---- plan: segment list ---------------------------------------------------------
 __global__ void head_flags_kernel(const uint32_t* keys, int64_t nnz, uint32_t* flags) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nnz) return;
-  const uint32_t k = keys[i];
-  flags[i] = (k != kInvalidKey && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+  flags[i] = (i == 0 || keys[i - 1] != keys[i]) ? 1u : 0u;  // a trailing invalid run is one segment too
 }
-__global__ void count_unique_kernel(const uint32_t* flags, const uint32_t* index, int64_t nnz, int64_t* n_unique) {
-  *n_unique = nnz > 0 ? (int64_t)index[nnz - 1] + flags[nnz - 1] : 0;
+__global__ void seg_scatter_kernel(const uint32_t* flags, const uint32_t* index, int64_t nnz, uint32_t* seg_start,
+                                   uint32_t* n_seg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  if (flags[i]) seg_start[index[i]] = (uint32_t)i;
+  if (i == nnz - 1) *n_seg = index[i] + flags[i];
+}
+__global__ void count_unique_kernel(const uint32_t* keys, const uint32_t* n_seg, int64_t nnz, int64_t* n_unique) {
+  // segments minus the trailing run of invalid keys, if any
+  *n_unique = (int64_t)*n_seg - (nnz > 0 && keys[nnz - 1] == kInvalidKey ? 1 : 0);
 }
 
 template <typename GT, typename TT, int MODE>
 int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
   const int lpr = pieces <= 8 ? 8 : (pieces <= 16 ? 16 : (pieces <= 32 ? 32 : 64));
-  const int64_t groups = ceil_div(p.nnz, p.chunk);
-  const int64_t blocks = ceil_div(groups * lpr, 256);
+  const int64_t groups = p.nnz;  // upper bound of the segment count (device-side n_seg trims it)
+  const int64_t blocks = ceil_div(groups, (256 / lpr) * kSegsPerGroup);
   if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_bwd: grid too large");
 #define KRS_LAUNCH_APPLY(L)                                                                             \
   if (p.weights)                                                                                        \
@@ -406,7 +472,6 @@ int run_apply(ApplyParams p, int grad_dtype, int table_dtype, hipStream_t st) {
   // the per-lane piece must also map to whole table / accumulator elements: N elements each
   if (gbytes % 16 == 0 && gbytes <= 1024) {
     const int pieces = (int)(gbytes / 16);
-    p.chunk = 8;
     if (grad_dtype == KRS_F32)
       return table_dtype == KRS_F32 ? launch_apply_lpr<float, float, MODE>(p, pieces, st)
                                     : launch_apply_lpr<float, uint16_t, MODE>(p, pieces, st);
@@ -432,15 +497,17 @@ int check_apply_args(const void* tables_or_null, int need_tables, const krs_feat
   return KRS_OK;
 }
 
-ApplyParams make_apply(const krs_table* tables, int n_tables, const krs_feature* feats, const float* weights,
+ApplyParams make_apply(const krs_table* tables, int n_tables, const krs_feature* feats, int n_feats,
+                       const float* weights,
                        const float* bag_scale, const void* grad, int64_t grad_ld, int batch, int dim, int64_t nnz,
                        const void* workspace) {
   ApplyParams p;
   const PlanLayout l = plan_layout(const_cast<void*>(workspace), nnz);
-  p.tables = tables; p.n_tables = n_tables; p.feats = feats; p.weights = weights; p.bag_scale = bag_scale;
+  p.tables = tables; p.n_tables = n_tables; p.feats = feats; p.n_feats = n_feats; p.weights = weights;
+  p.bag_scale = bag_scale;
   p.grad = grad; p.grad_ld = grad_ld; p.batch = batch; p.dim = dim; p.nnz = nnz;
-  p.keys = l.keys_sorted; p.vals = l.vals_sorted; p.head_index = l.head_index;
-  p.unique_rows = nullptr; p.row_grads = nullptr; p.chunk = 8;
+  p.keys = l.keys_sorted; p.vals = l.vals_sorted; p.seg_start = l.seg_start; p.n_seg = l.n_seg;
+  p.unique_rows = nullptr; p.row_grads = nullptr;
   return p;
 }
 
@@ -484,6 +551,16 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
   size_t temp = l.temp_bytes;
   KRS_HIP(rocprim::radix_sort_pairs(l.temp, temp, l.keys_in, l.keys_sorted, l.vals_in, l.vals_sorted, (size_t)nnz,
                                     0u, bits, st));
+  // segment list: head flags -> exclusive scan -> scatter of the head positions
+  const unsigned nb = (unsigned)ceil_div(nnz, 256);
+  hipLaunchKernelGGL(head_flags_kernel, dim3(nb), dim3(256), 0, st, l.keys_sorted, nnz, l.head_flag);
+  KRS_CHECK_LAUNCH("head_flags_kernel");
+  temp = l.temp_bytes;
+  KRS_HIP(rocprim::exclusive_scan(l.temp, temp, l.head_flag, l.head_index, 0u, (size_t)nnz,
+                                  rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(seg_scatter_kernel, dim3(nb), dim3(256), 0, st, l.head_flag, l.head_index, nnz, l.seg_start,
+                     l.n_seg);
+  KRS_CHECK_LAUNCH("seg_scatter_kernel");
   return KRS_OK;
 }
 
@@ -491,9 +568,8 @@ extern "C" int krs_embed_bag_bwd_dense(const krs_table* grad_tables, int n_table
                                        int n_feats, const float* weights, const float* bag_scale,
                                        const void* grad, int grad_dtype, int64_t grad_ld, int batch, int dim,
                                        int64_t nnz, const void* workspace, void* stream) {
-  (void)n_feats;
   if (int rc = check_apply_args(grad_tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
-  ApplyParams p = make_apply(grad_tables, n_tables, feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  ApplyParams p = make_apply(grad_tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kDense>(p, grad_dtype, KRS_F32, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -501,9 +577,8 @@ extern "C" int krs_embed_bag_bwd_fused_sgd(const krs_table* tables, int n_tables
                                            int n_feats, const float* weights, const float* bag_scale,
                                            const void* grad, int grad_dtype, int64_t grad_ld, int batch, int dim,
                                            int table_dtype, int64_t nnz, const void* workspace, void* stream) {
-  (void)n_feats;
   if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
-  ApplyParams p = make_apply(tables, n_tables, feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kSgd>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -512,9 +587,8 @@ extern "C" int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_ta
                                                const void* grad, int grad_dtype, int64_t grad_ld, int batch,
                                                int dim, int table_dtype, int64_t nnz, const void* workspace,
                                                void* stream) {
-  (void)n_feats;
   if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
-  ApplyParams p = make_apply(tables, n_tables, feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kAdagrad>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -522,7 +596,6 @@ extern "C" int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats, c
                                         const float* bag_scale, const void* grad, int grad_dtype,
                                         int64_t grad_ld, int batch, int dim, int64_t nnz, const void* workspace,
                                         int64_t* unique_rows, float* row_grads, int64_t* n_unique, void* stream) {
-  (void)n_feats;
   if (int rc = check_apply_args(nullptr, 0, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
   KRS_REQUIRE(unique_rows && row_grads && n_unique, "embed_bag_bwd_sparse: null outputs");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -530,16 +603,10 @@ extern "C" int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats, c
     KRS_HIP(hipMemsetAsync(n_unique, 0, sizeof(int64_t), st));
     return KRS_OK;
   }
-  const PlanLayout l = plan_layout(const_cast<void*>(workspace), nnz, true);
-  hipLaunchKernelGGL(head_flags_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, l.keys_sorted, nnz,
-                     l.head_flag);
-  KRS_CHECK_LAUNCH("head_flags_kernel");
-  size_t temp = l.temp_bytes;
-  KRS_HIP(rocprim::exclusive_scan(l.temp, temp, l.head_flag, l.head_index, 0u, (size_t)nnz,
-                                  rocprim::plus<uint32_t>(), st));
-  hipLaunchKernelGGL(count_unique_kernel, dim3(1), dim3(1), 0, st, l.head_flag, l.head_index, nnz, n_unique);
+  const PlanLayout l = plan_layout(const_cast<void*>(workspace), nnz);
+  hipLaunchKernelGGL(count_unique_kernel, dim3(1), dim3(1), 0, st, l.keys_sorted, l.n_seg, nnz, n_unique);
   KRS_CHECK_LAUNCH("count_unique_kernel");
-  ApplyParams p = make_apply(nullptr, 0, feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  ApplyParams p = make_apply(nullptr, 0, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   p.unique_rows = unique_rows;
   p.row_grads = row_grads;
   return run_apply<kSparse>(p, grad_dtype, KRS_F32, st);

@@ -22,11 +22,8 @@
 
 #include "krs_common.h"
 
-#ifndef KRS_K1_UNROLL
-#define KRS_K1_UNROLL 4
-#endif
 #ifndef KRS_K1_NT
-#define KRS_K1_NT 0  // bit0: nontemporal row loads, bit1: nontemporal output stores
+#define KRS_K1_NT 2  // bit1: nontemporal output stores (the pooled rows are written once, read later)
 #endif
 
 namespace krs {
@@ -34,7 +31,6 @@ namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kUnroll = KRS_K1_UNROLL;
 constexpr int NT = KRS_K1_NT;
 
 struct EmbedFwdParams {
@@ -112,17 +108,37 @@ __device__ __forceinline__ void store_row_piece(OT* dst, const float (&v)[N], bo
 
 
 // TT: table element (float | uint16_t=bf16), OT: output element, LPR: lanes per row.
-template <typename TT, typename OT, int LPR, bool HAS_W>
+//
+// Two phases per window of a group's lookup stream, so that the hot loop has no type / format
+// branches and no predicated loads (those made the compiler fence every load with vmcnt(0)):
+//   A. the group's lanes load the next WIN ids (+ weights) of the stream coalesced (clamped
+//      addresses, no predication), validate them and park them in LDS as int32 row numbers
+//      (-1 = out of range); every slot also gets a flag: 0, or bag+1 when it is the LAST lookup
+//      of a bag.  Empty bags are written (zeros) here, so the hot loop never sees them.
+//   B. the flat loop: id / flag / weight come from LDS, kUnroll row loads are issued
+//      unconditionally (row 0 stands in for invalid and padding slots and is masked after the
+//      load) and consumed in order; a set flag flushes the finished bag.
+// STREAM: bags of ~1 lookup -> no row reuse to protect: 8 row loads in flight, non-temporal.
+template <typename TT, typename OT, int LPR, bool HAS_W, bool STREAM>
 __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p) {
   constexpr int G = 64 / LPR;
   constexpr int N = Vec16<TT>::N;
+  constexpr int kUnroll = STREAM ? 8 : 4;
+  constexpr int WIN = 8 * LPR;  // ids per window per group (8 coalesced loads per lane)
+  constexpr int MAXB = 16;      // bags per group (host keeps bpg <= 16)
+  __shared__ int s_ids[4 * G * WIN];
+  __shared__ int s_flag[4 * G * WIN];
+  __shared__ float s_w[HAS_W ? 4 * G * WIN : 1];
+  __shared__ int s_end[4 * G * (MAXB + 1)];
+
   const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int g = lane / LPR;
   const int sub = lane % LPR;
 
   const int bags_per_wave = G * p.bpg;
   const int waves_per_feat = (p.batch + bags_per_wave - 1) / bags_per_wave;
-  const int64_t wave_unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wave_unit = (int64_t)blockIdx.x * 4 + wave;
   if (wave_unit >= (int64_t)waves_per_feat * p.n_feats) return;
   const int f = __builtin_amdgcn_readfirstlane((int)(wave_unit / waves_per_feat));
   const int wave_b0 = __builtin_amdgcn_readfirstlane((int)(wave_unit - (int64_t)f * waves_per_feat)) * bags_per_wave;
@@ -134,36 +150,59 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p)
   const int comb = ft.combiner;
   const int64_t row_bytes = (int64_t)p.dim * sizeof(TT);
   const int row_pieces = (int)(row_bytes >> 4);
-  const char* table = reinterpret_cast<const char*>(tb.weights);
-  const bool tab_aligned = (reinterpret_cast<uintptr_t>(table) & 15) == 0;
+  const bool col_live = sub < row_pieces;  // LPR is the next power of two >= row_pieces
+  const char* table = reinterpret_cast<const char*>(tb.weights) + (col_live ? sub : 0) * 16;
 
   const int b_lo = wave_b0 + g * p.bpg;
   const int b_hi = min(b_lo + p.bpg, p.batch);
-  if (b_lo >= b_hi || sub >= row_pieces) return;  // no cross-lane ops below: safe to leave
+  if (b_lo >= b_hi) return;  // whole groups only: the lanes of a live group stay together
+  const int nb = b_hi - b_lo;
 
+  int* ids_l = s_ids + (wave * G + g) * WIN;
+  int* flag_l = s_flag + (wave * G + g) * WIN;
+  float* w_l = s_w + (HAS_W ? (wave * G + g) * WIN : 0);
+  int* end_l = s_end + (wave * G + g) * (MAXB + 1);  // end_l[b] = start of bag b, end_l[b+1] = its end
+
+  // ---- stream bounds and bag boundaries (relative to the stream start) ----
   const bool dense = p.offsets == nullptr;
-  const int64_t bag0 = (int64_t)f * p.batch;
-  auto bag_end = [&](int j) -> int64_t {
-    return dense ? ft.ids_base + (int64_t)(j + 1) * ft.hot : ld_index(p.offsets, p.off64, bag0 + j + 1);
-  };
-  int64_t q = dense ? ft.ids_base + (int64_t)b_lo * ft.hot : ld_index(p.offsets, p.off64, bag0 + b_lo);
-  const int64_t qe = bag_end(b_hi - 1);
+  const int64_t bag0 = (int64_t)f * p.batch + b_lo;
+  int64_t qs;
+  if (dense) {
+    qs = ft.ids_base + (int64_t)b_lo * ft.hot;
+    for (int b = sub; b <= nb; b += LPR) end_l[b] = b * ft.hot;
+  } else {
+    qs = ld_index(p.offsets, p.off64, bag0);
+    for (int b = sub; b <= nb; b += LPR) end_l[b] = (int)(ld_index(p.offsets, p.off64, bag0 + b) - qs);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int len = end_l[nb];  // lookups in this group's stream
 
   OT* out = reinterpret_cast<OT*>(p.out) + ft.out_col + sub * N;
   constexpr unsigned kStoreAlign = N * sizeof(OT) < 16 ? N * sizeof(OT) : 16;
   const bool out_aligned =
       ((reinterpret_cast<uintptr_t>(out) | (uintptr_t)(p.out_ld * sizeof(OT))) & (kStoreAlign - 1)) == 0;
 
-  int j = b_lo;
-  int64_t endj = bag_end(j);
+  // empty bags: zeros (and scale 1 / 0) straight away -- the stream below never reaches them
+  if (!dense || ft.hot == 0) {
+    for (int b = 0; b < nb; ++b) {
+      if (end_l[b + 1] == end_l[b]) {
+        float z[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) z[i] = 0.0f;
+        if (col_live) store_row_piece<OT, N>(out + (int64_t)(b_lo + b) * p.out_ld, z, out_aligned);
+        if (p.bag_scale && sub == 0) p.bag_scale[bag0 + b] = comb == KRS_SUM ? 1.0f : 0.0f;
+      }
+    }
+  }
+
   float acc[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) acc[i] = 0.0f;
   float sw = 0.0f, sw2 = 0.0f;
   int oob = 0;
 
-  auto flush = [&]() {
-    float den = comb == KRS_MEAN ? sw : (comb == KRS_SQRTN ? sqrtf(sw2) : 1.0f);
+  auto flush = [&](int b) {
+    const float den = comb == KRS_MEAN ? sw : (comb == KRS_SQRTN ? sqrtf(sw2) : 1.0f);
     float o[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -172,89 +211,189 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p)
       o[i] = v;
       acc[i] = 0.0f;
     }
-    store_row_piece<OT, N>(out + (int64_t)j * p.out_ld, o, out_aligned);
+    if (col_live) store_row_piece<OT, N>(out + (int64_t)(b_lo + b) * p.out_ld, o, out_aligned);
     if (p.bag_scale && sub == 0)
-      p.bag_scale[bag0 + j] = comb == KRS_SUM ? 1.0f : (den == 0.0f ? 0.0f : 1.0f / den);
+      p.bag_scale[bag0 + b] = comb == KRS_SUM ? 1.0f : (den == 0.0f ? 0.0f : 1.0f / den);
     sw = 0.0f;
     sw2 = 0.0f;
   };
 
-  int idn[kUnroll];
-  float wn[kUnroll];
-  auto fetch_ids = [&](int64_t q0) {
+  for (int w0 = 0; w0 < len; w0 += WIN) {
+    const int wn = min(WIN, len - w0);
+    // ---- phase A: stage ids, flags (+ weights) of this window; addresses clamped, no predication ----
+    int staged[8];
+    if (p.id64) {
+      const int64_t* src = reinterpret_cast<const int64_t*>(p.ids) + qs + w0;
+      int64_t raw[8];
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {
-      const int64_t pos = q0 + k;
-      int id = -2;  // -2: past the end of this group's stream
-      float w = 1.0f;
-      if (pos < qe) {
-        const int64_t raw = ld_index(p.ids, p.id64, pos);
-        id = (raw >= 0 && raw < vocab) ? (int)raw : -1;  // -1: out of range, flagged, never clamped
-        if constexpr (HAS_W) w = p.weights[pos];
-      }
-      idn[k] = id;
-      wn[k] = w;
+      for (int i = 0; i < 8; ++i) raw[i] = src[min(sub + LPR * i, wn - 1)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) staged[i] = (raw[i] >= 0 && raw[i] < vocab) ? (int)raw[i] : -1;
+    } else {
+      const int32_t* src = reinterpret_cast<const int32_t*>(p.ids) + qs + w0;
+      int raw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) raw[i] = src[min(sub + LPR * i, wn - 1)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) staged[i] = (raw[i] >= 0 && raw[i] < vocab) ? raw[i] : -1;
     }
-  };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ids_l[sub + LPR * i] = staged[i];
+      flag_l[sub + LPR * i] = 0;
+      oob |= (staged[i] < 0) & (sub + LPR * i < wn);
+    }
+    if constexpr (HAS_W) {
+      const float* src = p.weights + qs + w0;
+      float raw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) raw[i] = src[min(sub + LPR * i, wn - 1)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w_l[sub + LPR * i] = raw[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // last lookup of every non-empty bag that ends inside this window
+    for (int b = sub; b < nb; b += LPR) {
+      const int e = end_l[b + 1];
+      if (e > end_l[b] && e - 1 >= w0 && e - 1 < w0 + wn) flag_l[e - 1 - w0] = b + 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-  fetch_ids(q);
-  while (q < qe) {
-    int idc[kUnroll];
-    float wc[kUnroll];
-    uint4 raw[kUnroll];
+    // ---- phase B: the flat loop over the staged window ----
+    for (int wq = 0; wq < wn; wq += kUnroll) {
+      int idc[kUnroll], flg[kUnroll];
+      float wc[kUnroll];
+      u32x4 raw[kUnroll];
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {
-      idc[k] = idn[k];
-      wc[k] = wn[k];
-      raw[k] = make_uint4(0, 0, 0, 0);
-      if (idc[k] >= 0) {
-        const char* src = table + (int64_t)idc[k] * row_bytes + sub * 16;
-        if (tab_aligned) {
-          u32x4 t4;
-          if constexpr (NT & 1) t4 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
-          else t4 = *reinterpret_cast<const u32x4*>(src);
-          raw[k] = make_uint4(t4.x, t4.y, t4.z, t4.w);
-        } else {
-          const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
-          if constexpr (sizeof(TT) == 4) {
-            raw[k] = make_uint4(s4[0], s4[1], s4[2], s4[3]);
-          } else {
-            const uint16_t* s2 = reinterpret_cast<const uint16_t*>(src);
-            raw[k] = make_uint4(s2[0] | ((uint32_t)s2[1] << 16), s2[2] | ((uint32_t)s2[3] << 16),
-                                s2[4] | ((uint32_t)s2[5] << 16), s2[6] | ((uint32_t)s2[7] << 16));
-          }
-        }
+      for (int k = 0; k < kUnroll; ++k) {
+        const int slot = min(wq + k, WIN - 1);
+        const bool live = wq + k < wn;
+        idc[k] = live ? ids_l[slot] : -1;
+        flg[k] = live ? flag_l[slot] : 0;
+        if constexpr (HAS_W) wc[k] = live ? w_l[slot] : 0.0f; else wc[k] = live ? 1.0f : 0.0f;
       }
-    }
-    fetch_ids(q + kUnroll);  // next step's ids travel under this step's rows
 #pragma unroll
-    for (int k = 0; k < kUnroll; ++k) {
-      if (idc[k] != -2) {
-        const int64_t pos = q + k;
-        while (pos >= endj && j < b_hi - 1) {  // bounded even for malformed offsets
-          flush();
-          ++j;
-          endj = bag_end(j);
-        }
+      for (int k = 0; k < kUnroll; ++k) {
+        const int row = idc[k] < 0 ? 0 : idc[k];
+        // global address space made explicit: a generic pointer would become flat_load (+ lgkmcnt waits)
+        typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
+        gvec_ptr src = (gvec_ptr)(table + (int64_t)row * row_bytes);
+        if constexpr (STREAM) raw[k] = __builtin_nontemporal_load(src); else raw[k] = *src;
+      }
+#pragma unroll
+      for (int k = 0; k < kUnroll; ++k) {
         sw += wc[k];
         sw2 = fmaf(wc[k], wc[k], sw2);
-        if (idc[k] == -1) {
-          oob = 1;
-        } else {
-          float fv[N];
-          Vec16<TT>::unpack(raw[k], fv);
+        float fv[N];
+        Vec16<TT>::unpack(make_uint4(raw[k].x, raw[k].y, raw[k].z, raw[k].w), fv);
+        const float wk = idc[k] >= 0 ? wc[k] : 0.0f;
 #pragma unroll
-          for (int i = 0; i < N; ++i) acc[i] = fmaf(wc[k], fv[i], acc[i]);
+        for (int i = 0; i < N; ++i) acc[i] = fmaf(wk, idc[k] >= 0 ? fv[i] : 0.0f, acc[i]);
+        if (flg[k]) flush(flg[k] - 1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // window consumed before it is restaged
+  }
+  if (oob && p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);  // any lane that staged a bad id
+}
+
+// Pure row gather: dense bags of exactly one lookup, no weights (the L = 1 headline shape).
+// out[b] = table[ids[b]] for every combiner (sum, x/1, x/sqrt(1)), so the rows are moved as raw
+// 16-byte pieces when TT == OT.  A wave takes 64 consecutive bags of one feature: one coalesced
+// id load per lane, ids broadcast with ds_bpermute (__shfl), 8 non-temporal row loads in flight
+// per lane, non-temporal stores.  Features whose `hot` is not 1 take the slow loop at the end.
+template <typename TT, typename OT, int LPR>
+__global__ __launch_bounds__(256) void embed_gather_hot1(const EmbedFwdParams p) {
+  constexpr int G = 64 / LPR;
+  constexpr int N = Vec16<TT>::N;
+  constexpr int STEPS = 64 / G;  // = LPR
+  constexpr int U = 8;
+  typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR;
+  const int sub = lane % LPR;
+  const int waves_per_feat = (p.batch + 63) / 64;
+  const int64_t wave_unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave_unit >= (int64_t)waves_per_feat * p.n_feats) return;
+  const int f = __builtin_amdgcn_readfirstlane((int)(wave_unit / waves_per_feat));
+  const int b0 = __builtin_amdgcn_readfirstlane((int)(wave_unit - (int64_t)f * waves_per_feat)) * 64;
+  const krs_feature ft = p.feats[f];
+  const krs_table tb = p.tables[ft.table];
+  const int64_t row_bytes = (int64_t)p.dim * sizeof(TT);
+  const int row_pieces = (int)(row_bytes >> 4);
+  const bool col_live = sub < row_pieces;
+  const char* table = reinterpret_cast<const char*>(tb.weights) + (col_live ? sub : 0) * 16;
+  OT* out = reinterpret_cast<OT*>(p.out) + ft.out_col + sub * N;
+  constexpr unsigned kStoreAlign = N * sizeof(OT) < 16 ? N * sizeof(OT) : 16;
+  const bool out_aligned =
+      ((reinterpret_cast<uintptr_t>(out) | (uintptr_t)(p.out_ld * sizeof(OT))) & (kStoreAlign - 1)) == 0;
+
+  if (ft.hot == 1) {
+    const int nb = min(64, p.batch - b0);
+    const int64_t q = ft.ids_base + b0 + min(lane, nb - 1);
+    const int64_t rawid = p.id64 ? reinterpret_cast<const int64_t*>(p.ids)[q] : (int64_t)reinterpret_cast<const int32_t*>(p.ids)[q];
+    const int myid = (rawid >= 0 && rawid < tb.vocab) ? (int)rawid : -1;
+    if (lane < nb && myid < 0 && p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
+    if (p.bag_scale && lane < nb) p.bag_scale[(int64_t)f * p.batch + b0 + lane] = 1.0f;
+#pragma unroll 1
+    for (int s0 = 0; s0 < STEPS; s0 += U) {
+      int id[U];
+      u32x4 raw[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        id[k] = __shfl(myid, (s0 + k) * G + g, 64);
+        gvec_ptr src = (gvec_ptr)(table + (int64_t)(id[k] < 0 ? 0 : id[k]) * row_bytes);
+        raw[k] = __builtin_nontemporal_load(src);
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int b = b0 + (s0 + k) * G + g;
+        if (b < p.batch && col_live) {
+          if (id[k] < 0) raw[k] = u32x4{0, 0, 0, 0};
+          OT* dst = out + (int64_t)b * p.out_ld;
+          if constexpr (sizeof(TT) == sizeof(OT)) {
+            if (out_aligned) {
+              __builtin_nontemporal_store(raw[k], reinterpret_cast<u32x4*>(dst));
+              continue;
+            }
+          }
+          float fv[N];
+          Vec16<TT>::unpack(make_uint4(raw[k].x, raw[k].y, raw[k].z, raw[k].w), fv);
+          store_row_piece<OT, N>(dst, fv, out_aligned);
         }
       }
     }
-    q += kUnroll;
+    return;
   }
-  while (j < b_hi) {  // the last bag, and any trailing empty ones
-    flush();
-    ++j;
+  // slow loop for the odd feature whose hot != 1 in an otherwise one-hot call
+  for (int b = b0 + g; b < min(b0 + 64, p.batch); b += G) {
+    float acc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0.0f;
+    int cnt = 0;
+    for (int l = 0; l < ft.hot; ++l) {
+      const int64_t raw = ld_index(p.ids, p.id64, ft.ids_base + (int64_t)b * ft.hot + l);
+      ++cnt;
+      if (raw < 0 || raw >= tb.vocab) {
+        if (p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
+        continue;
+      }
+      gvec_ptr src = (gvec_ptr)(table + raw * row_bytes);
+      const u32x4 r = *src;
+      float fv[N];
+      Vec16<TT>::unpack(make_uint4(r.x, r.y, r.z, r.w), fv);
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc[i] += fv[i];
+    }
+    const int comb = ft.combiner;
+    const float den = comb == KRS_MEAN ? (float)cnt : (comb == KRS_SQRTN ? sqrtf((float)cnt) : 1.0f);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (comb != KRS_SUM) acc[i] = den == 0.0f ? 0.0f : acc[i] / den;
+    if (col_live) store_row_piece<OT, N>(out + (int64_t)b * p.out_ld, acc, out_aligned);
+    if (p.bag_scale && sub == 0)
+      p.bag_scale[(int64_t)f * p.batch + b] = comb == KRS_SUM ? 1.0f : (den == 0.0f ? 0.0f : 1.0f / den);
   }
-  if (oob && p.err_flag && sub == 0) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
 }
 
 // Any dim / any alignment / any dtype pair: one LPR-lane group per bag, one
@@ -307,26 +446,34 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_generic(const EmbedFwdParam
 }
 
 template <typename TT, typename OT, int LPR>
-int launch_vec(const EmbedFwdParams& p, hipStream_t stream) {
+int launch_vec(const EmbedFwdParams& p, bool one_hot, bool stream, hipStream_t st) {
   constexpr int G = 64 / LPR;
+  if (one_hot) {
+    const int64_t blocks = ceil_div(ceil_div(p.batch, 64) * p.n_feats, 4);
+    if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_fwd: grid too large");
+    hipLaunchKernelGGL((embed_gather_hot1<TT, OT, LPR>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    KRS_CHECK_LAUNCH("embed_gather_hot1");
+    return KRS_OK;
+  }
   const int64_t waves_per_feat = ceil_div(p.batch, (int64_t)G * p.bpg);
   const int64_t blocks = ceil_div(waves_per_feat * p.n_feats, 4);
   if (blocks == 0) return KRS_OK;
   if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_fwd: grid too large");
-  if (p.weights)
-    hipLaunchKernelGGL((embed_bag_fwd_vec<TT, OT, LPR, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
-  else
-    hipLaunchKernelGGL((embed_bag_fwd_vec<TT, OT, LPR, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+#define KRS_K1_LAUNCH(W, S) \
+  hipLaunchKernelGGL((embed_bag_fwd_vec<TT, OT, LPR, W, S>), dim3((unsigned)blocks), dim3(256), 0, st, p)
+  if (p.weights) { if (stream) KRS_K1_LAUNCH(true, true); else KRS_K1_LAUNCH(true, false); }
+  else { if (stream) KRS_K1_LAUNCH(false, true); else KRS_K1_LAUNCH(false, false); }
+#undef KRS_K1_LAUNCH
   KRS_CHECK_LAUNCH("embed_bag_fwd_vec");
   return KRS_OK;
 }
 
 template <typename TT, typename OT>
-int dispatch_lpr(const EmbedFwdParams& p, int row_pieces, hipStream_t stream) {
-  if (row_pieces <= 8) return launch_vec<TT, OT, 8>(p, stream);
-  if (row_pieces <= 16) return launch_vec<TT, OT, 16>(p, stream);
-  if (row_pieces <= 32) return launch_vec<TT, OT, 32>(p, stream);
-  return launch_vec<TT, OT, 64>(p, stream);
+int dispatch_lpr(const EmbedFwdParams& p, int row_pieces, bool one_hot, bool stream_mode, hipStream_t stream) {
+  if (row_pieces <= 8) return launch_vec<TT, OT, 8>(p, one_hot, stream_mode, stream);
+  if (row_pieces <= 16) return launch_vec<TT, OT, 16>(p, one_hot, stream_mode, stream);
+  if (row_pieces <= 32) return launch_vec<TT, OT, 32>(p, one_hot, stream_mode, stream);
+  return launch_vec<TT, OT, 64>(p, one_hot, stream_mode, stream);
 }
 
 }  // namespace
@@ -359,18 +506,21 @@ extern "C" int krs_embed_bag_fwd(const krs_table* tables, const krs_feature* fea
   // making one group's stream long (nnz / bags = mean bag length).
   const int64_t n_bags = (int64_t)n_feats * batch;
   const int64_t mean_hot = nnz / n_bags > 0 ? nnz / n_bags : 1;
-  int bpg = (int)(16 / mean_hot);
+  int bpg = (int)(32 / mean_hot);
   p.bpg = bpg < 1 ? 1 : (bpg > 16 ? 16 : bpg);
   if (const char* e = getenv("KRS_BPG")) p.bpg = atoi(e);  // development override
 
   const int64_t row_bytes = (int64_t)dim * (table_dtype == KRS_BF16 ? 2 : 4);
   if (row_bytes % 16 == 0 && row_bytes <= 1024) {
     const int pieces = (int)(row_bytes / 16);
+    // every bag has exactly one lookup (dense, unweighted): the pure-gather kernel
+    const bool one_hot = offsets == nullptr && weights == nullptr && nnz == n_bags;
+    const bool stream_mode = nnz < 2 * n_bags;
     if (table_dtype == KRS_F32)
-      return out_dtype == KRS_F32 ? dispatch_lpr<float, float>(p, pieces, st)
-                                  : dispatch_lpr<float, uint16_t>(p, pieces, st);
-    return out_dtype == KRS_F32 ? dispatch_lpr<uint16_t, float>(p, pieces, st)
-                                : dispatch_lpr<uint16_t, uint16_t>(p, pieces, st);
+      return out_dtype == KRS_F32 ? dispatch_lpr<float, float>(p, pieces, one_hot, stream_mode, st)
+                                  : dispatch_lpr<float, uint16_t>(p, pieces, one_hot, stream_mode, st);
+    return out_dtype == KRS_F32 ? dispatch_lpr<uint16_t, float>(p, pieces, one_hot, stream_mode, st)
+                                : dispatch_lpr<uint16_t, uint16_t>(p, pieces, one_hot, stream_mode, st);
   }
   int lpr = 1;
   while (lpr < dim && lpr < 64) lpr <<= 1;

@@ -103,3 +103,23 @@ def test_out_of_range_ids_raise_flag_and_contribute_nothing():
     out, _ = FusedBags([tab], [(0, "sum", 0)]).forward(ids, 3, hots=[2], err_flag=flag)
     assert int(flag.item()) & L.FLAG_ID_OUT_OF_RANGE
     assert torch.equal(out[:, 0].cpu(), torch.tensor([1.0, 1.0, 2.0]))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_one_lookup_per_bag_on_average_but_uneven_hots(dt):
+    """nnz == bags selects the pure-gather kernel; features whose hot is not 1 must still be right."""
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    rng = np.random.default_rng(9)
+    dev = torch.device("cuda:0")
+    batch, dim = 70, 64
+    tables = [torch.from_numpy(rng.uniform(-1, 1, (40, dim)).astype(np.float32)).to(TORCH_DT[dt]).to(dev)
+              for _ in range(3)]
+    hots = [2, 0, 1]
+    specs = [(0, "mean", 0), (1, "sum", dim), (2, "sqrtn", 2 * dim)]
+    ids = np.concatenate([rng.integers(0, 40, batch * h) for h in hots]).astype(np.int32)
+    out, scale = FusedBags(tables, specs).forward(torch.from_numpy(ids).to(dev), batch, hots=hots, want_scale=True)
+    bags = dict(ids=ids, offsets=None, hots=hots, weights=None, nnz=len(ids))
+    exp, exp_scale, _ = oracle_embed_fwd([to_np(t) for t in tables], specs, bags, batch, dim, 3 * dim, NP_DT[dt], False)
+    np.testing.assert_allclose(to_f32(to_np(out)), to_f32(exp), rtol=2 ** -7 if dt == "bf16" else 1e-6, atol=1e-6)
+    np.testing.assert_allclose(scale.cpu().numpy(), exp_scale, rtol=1e-6)
