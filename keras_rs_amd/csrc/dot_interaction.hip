@@ -353,7 +353,7 @@ extern "C" int krs_dot_interaction_bwd(const void* const* feats, const int64_t* 
     p.n_feats = n_feats; p.batch = batch; p.dim = dim; p.self_inter = self_interaction != 0;
     p.skip_gather = skip_gather != 0; p.out = const_cast<void*>(grad_out); p.out_ld = grad_ld;
     const size_t lds = (size_t)(32 * (dim + 4) + 32 * 33 + 2) * sizeof(float) + 32 * 4 * 8;
-    const unsigned blocks = (unsigned)std::min<int64_t>(batch, 256 * 8);
+    const unsigned blocks = (unsigned)std::min<int64_t>(batch, 256 * 32);
     const int nblk = (dim + 31) / 32;
 #define KRS_DOT_BWD(ES, NB)                                                                     \
   hipLaunchKernelGGL((dot_bwd_mfma_kernel<ES, NB>), dim3(blocks), dim3(64), lds, st, p)

@@ -232,18 +232,34 @@ __device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) 
 }
 
 template <int ES, bool A_KM, bool B_NK>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 3) void gemm_mfma_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = ROW_BYTES / ES;  // K elements per tile
-  // buffer b: A tile at smem + 2b*TILE_BYTES, B tile right behind it
-  auto tile_a = [&](int buf) -> char* { return smem + (2 * buf) * TILE_BYTES; };
-  auto tile_b = [&](int buf) -> char* { return smem + (2 * buf + 1) * TILE_BYTES; };
+  // ONE operand buffer (A tile, then B tile): 36 KB of LDS per workgroup, so three workgroups
+  // share a CU and one's staging / epilogue phases hide under the others' MFMA phases.
+  auto tile_a = [&](int) -> char* { return smem; };
+  auto tile_b = [&](int) -> char* { return smem + TILE_BYTES; };
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM;
-  const int64_t n0 = (int64_t)blockIdx.x * BN;
+  // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (observed: id % 8),
+  // each with a private L2.  The N tiles of one M panel re-read the same A rows, so they are
+  // mapped to ONE XCD, back to back: (xcd, slot) -> panel (slot / Nt) * 8 + xcd, tile slot % Nt.
+  // A wrong placement guess only costs speed.  grid.x = ceil(Mt / 8) * 8 * Nt; surplus panels exit.
+  const int64_t nt = (p.n + BN - 1) / BN;
+  int64_t m_tile, n_tile;
+  if constexpr (A_KM) {  // weight-gradient shapes: few tiles, split along K instead
+    m_tile = blockIdx.x / nt;
+    n_tile = blockIdx.x % nt;
+  } else {
+    const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    m_tile = (slot / nt) * 8 + xcd;
+    n_tile = slot % nt;
+  }
+  if (m_tile * BM >= p.m) return;
+  const int64_t m0 = m_tile * BM;
+  const int64_t n0 = n_tile * BN;
   const int split = blockIdx.z;
   const int64_t kbeg = (int64_t)split * p.k_per_split;
   const int64_t kend = min(p.k, kbeg + p.k_per_split);
@@ -270,16 +286,15 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmParams p) {
     if constexpr (B_NK) store_kcontig(tile_b(buf), rb); else store_kstrided<ES>(tile_b(buf), rb);
   };
 
-  if (ntiles > 0) {
-    load_tiles(0);
-    store_tiles(0);
-  }
-  __syncthreads();
+  if (ntiles > 0) load_tiles(0);
 
   const int frow = lane & 31;          // fragment row (m for A, n for B)
   const int fhalf = lane >> 5;         // which 16-byte half of a 32-byte K step this lane feeds
   for (int64_t t = 0; t < ntiles; ++t) {
-    const int cur = (int)(t & 1);
+    const int cur = 0;
+    __syncthreads();          // every wave is done reading the previous tile
+    store_tiles(0);
+    __syncthreads();
     if (t + 1 < ntiles) load_tiles(t + 1);  // in flight under the MFMAs below
     const char* ta = tile_a(cur);
     const char* tb = tile_b(cur);
@@ -306,48 +321,49 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmParams p) {
           }
         }
     }
-    if (t + 1 < ntiles) store_tiles(cur ^ 1);
-    __syncthreads();
   }
+  __syncthreads();  // operand tiles are dead from here on
 
   // Epilogue.  The accumulators go through LDS (the operand tiles are dead: every wave passed
   // the loop's last barrier) so that each lane ends up with 8 consecutive columns of one row:
   // x0 / x / R are then read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
   // MFMA C/D layout: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
   constexpr int SST = 68;  // staging row stride in floats (64 + pad)
-  float* stage = reinterpret_cast<float*>(smem) + wave * (64 * SST);
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SST);  // 32 rows x 64 cols per wave
+  const int ec = (lane & 7) * 8;
+  const int64_t gn = n0 + wn * 64 + ec;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {  // the wave's upper / lower 32 rows
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc[i][j][r];
-  __syncthreads();
-  const int ec = (lane & 7) * 8;
-  const int64_t gn = n0 + wn * 64 + ec;
+        stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private staging: no workgroup barrier
 #pragma unroll 2
-  for (int it = 0; it < 8; ++it) {
-    const int er = it * 8 + (lane >> 3);
-    const int64_t gm = m0 + wm * 64 + er;
-    if (gm >= p.m || gn >= p.n) continue;
-    float v[8];
-    const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
-    const float4 v1 = *reinterpret_cast<const float4*>(stage + er * SST + ec + 4);
-    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-    if (p.splits > 1) {
-      float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
-      if (p.ep_vec) {
-        *reinterpret_cast<float4*>(dst) = v0;
-        *reinterpret_cast<float4*>(dst + 4) = v1;
+    for (int it = 0; it < 4; ++it) {
+      const int er = it * 8 + (lane >> 3);
+      const int64_t gm = m0 + wm * 64 + i * 32 + er;
+      if (gm >= p.m || gn >= p.n) continue;
+      float v[8];
+      const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
+      const float4 v1 = *reinterpret_cast<const float4*>(stage + er * SST + ec + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      if (p.splits > 1) {
+        float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
+        if (p.ep_vec) {
+          *reinterpret_cast<float4*>(dst) = v0;
+          *reinterpret_cast<float4*>(dst + 4) = v1;
+        } else {
+          for (int q = 0; q < 8 && gn + q < p.n; ++q) dst[q] = v[q];
+        }
+      } else if (p.ep_vec) {
+        epilogue_store_vec8(p, gm, gn, v);
       } else {
-        for (int q = 0; q < 8 && gn + q < p.n; ++q) dst[q] = v[q];
+        for (int q = 0; q < 8 && gn + q < p.n; ++q) epilogue_store(p, gm, gn + q, v[q]);
       }
-    } else if (p.ep_vec) {
-      epilogue_store_vec8(p, gm, gn, v);
-    } else {
-      for (int q = 0; q < 8 && gn + q < p.n; ++q) epilogue_store(p, gm, gn + q, v[q]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 }
 
@@ -397,8 +413,9 @@ bool mfma_eligible(const GemmParams& p, int es) {
 
 template <int ES>
 int launch_mfma(const GemmParams& p, hipStream_t st) {
-  const dim3 grid((unsigned)ceil_div(p.n, BN), (unsigned)ceil_div(p.m, BM), (unsigned)p.splits);
-  const size_t lds = 4 * TILE_BYTES;
+  const int64_t mt = p.a_km ? ceil_div(p.m, BM) : ceil_div(ceil_div(p.m, BM), 8) * 8;
+  const dim3 grid((unsigned)(mt * ceil_div(p.n, BN)), 1, (unsigned)p.splits);
+  const size_t lds = 2 * TILE_BYTES;
 #define KRS_GEMM_CASE(AK, BK_)                                                                      \
   {                                                                                                 \
     auto kern = gemm_mfma_kernel<ES, AK, BK_>;                                                      \
