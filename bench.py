@@ -13,8 +13,11 @@ A "step" is one pass of the hot path over one synthetic batch, through the drop-
        Adagrad row update (K2) and an Adagrad step on the FeatureCross weights.
 
 Workload C3 (DLRM-small): 26 tables x 1,000,000 rows x 128, batch 65,536 global, bf16 tables
-and activations with fp32 accumulation, fp32 master weights for the dense kernels.
-`--multihot` switches the bag lengths from L = 1 to the ml_perf list (sum L = 214).
+and activations with fp32 accumulation, fp32 master weights for the dense kernels.  SURVEY.md
+section 8d defines C3 with two bag-length lists; both are measured in one run: the primary one
+(`value`, `ms_per_step`, `roofline`) uses the ml_perf DLRM lengths (sum L = 214, i.e. a real
+gather+POOL; examples/ml_perf/configs/v6e_8.py), the L = 1 variant is reported under `also`
+(`--hotness 1` swaps them).
 With N > 1 the tables are MOD row-sharded over the ranks (C4), B_local = 65,536 / N.
 
 Prints ONE JSON line (rank 0) with `value` = whole-job embedding lookups/s, `ms_per_step` =
@@ -52,7 +55,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=65536, help="global batch")
     ap.add_argument("--projection", type=int, default=512)
     ap.add_argument("--cross-layers", type=int, default=3)
-    ap.add_argument("--multihot", action="store_true", help="ml_perf bag lengths (sum L = 214) instead of L = 1")
+    ap.add_argument("--hotness", choices=["mlperf", "1"], default="mlperf",
+                    help="primary bag lengths: the ml_perf list (sum L = 214, default) or L = 1; the other one is reported under `also`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=2048)
     return ap.parse_args()
@@ -164,61 +168,43 @@ def cpu_baseline(a, hots):
     }
 
 
-def main():
-    a = parse()
-    rank, world, local = dist_setup(a.gpus)
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-    hots = (ML_PERF_HOTS * 8)[: a.tables] if a.multihot else [1] * a.tables
-    b_local = a.batch // world
-
-    from keras_rs_amd.build import build
-
-    if rank == 0:
-        build()
-    if world > 1:
-        torch.distributed.barrier()
-
-    model = Model(a, hots, world, rank)
+def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
+    """Times `steps` steps of the hot path for one bag-length list; returns (seconds, K1 seconds)."""
     ids, dense = make_inputs(a, hots, b_local, rank, dev)
-    model.embedding.build(None)
     pre = model.embedding.preprocess(ids)
-    opt = None  # created after the first step has built the cross layers
     scale = 1.0 / (b_local * (a.tables + 1) * a.dim)
-
     k1_ev = []
 
     def step(record=False):
-        nonlocal opt
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            emb_probe = model.embedding(pre)  # K1 alone, bracketed by events on the launch stream
+            probe = model.embedding(pre)  # K1 alone, bracketed by events on the launch stream
             e1.record()
             k1_ev.append((e0, e1))
-            del emb_probe
+            del probe
         xl, inter = model(dense, pre)
         loss = xl.float().sum() * scale + inter.float().sum() * (scale * 0.1)
         loss.backward()
-        if opt is None:
-            opt = torch.optim.Adagrad([p for layer in model.cross for p in layer.parameters()], lr=0.0034,
-                                      initial_accumulator_value=0.1, foreach=True)
+        if opt_box[0] is None:  # the first step has built the cross layers
+            opt_box[0] = torch.optim.Adagrad([p for layer in model.cross for p in layer.parameters()], lr=0.0034,
+                                             initial_accumulator_value=0.1, foreach=True)
+        opt = opt_box[0]
         if world > 1:
             for p in opt.param_groups[0]["params"]:
                 torch.distributed.all_reduce(p.grad)
                 p.grad.div_(world)
         opt.step()
         opt.zero_grad(set_to_none=True)
-        return loss
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
@@ -229,25 +215,82 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    # K1 launch duration, measured live in a separate short loop (the probe stays out of the timed region).
+    # Single GPU only: in the sharded run the embedding call also contains the all-to-alls.
+    k1_s = None
+    if world == 1:
+        for _ in range(10):
+            step(record=True)
+        torch.cuda.synchronize()
+        k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
+    return elapsed, k1_s
 
-    # K1 launch duration, measured live (separate short loop so the probe does not sit in the timed region)
-    for _ in range(10):
-        step(record=True)
-    torch.cuda.synchronize()
-    k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
 
+def k1_roofline(a, hots, b_local, k1_s, kernel):
+    nnz = b_local * sum(hots)
+    alg = k1_bytes(nnz, b_local * a.tables, a.dim, 2)
+    achieved = alg / k1_s
+    return {"kernel": kernel, "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(kernel), "launch_us": k1_s * 1e6,
+            "algorithmic_bytes": alg}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/k1_pmc.json,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE), or None when no counter run is recorded."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "k1_pmc.json")) as f:
+            rec = json.load(f)
+        for name, v in rec.items():
+            if name in kernel:
+                return v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def main():
+    a = parse()
+    rank, world, local = dist_setup(a.gpus)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    b_local = a.batch // world
+    hots_multi = (ML_PERF_HOTS * 8)[: a.tables]
+    hots_one = [1] * a.tables
+    primary = hots_one if a.hotness == "1" else hots_multi
+    secondary = hots_multi if a.hotness == "1" else hots_one
+
+    from keras_rs_amd.build import build
+
+    if rank == 0:
+        build()
+    if world > 1:
+        torch.distributed.barrier()
+
+    model = Model(a, primary, world, rank)
+    model.embedding.build(None)
+    opt_box = [None]
+    elapsed, k1_s = measure(model, a, primary, world, rank, dev, b_local, a.steps, a.warmup, opt_box)
+    # the other C3 bag-length list (SURVEY.md section 8d lists both), same tables and model, shorter run
+    sec_steps = max(3, a.steps // 2)
+    elapsed2, k1_s2 = measure(model, a, secondary, world, rank, dev, b_local, sec_steps, 2, opt_box)
     if rank != 0:
         return
-    nnz_local = b_local * sum(hots)
-    lookups = a.batch * sum(hots)
-    ms = elapsed / a.steps * 1e3
-    achieved = k1_bytes(nnz_local, b_local * a.tables, a.dim, 2) / k1_s
+
+    def describe(hots):
+        return "multi-hot ml_perf lengths (sum L = %d)" % sum(hots) if sum(hots) > len(hots) else "hotness L = 1"
+
+    def k1_name(hots):
+        return "embed_bag_fwd_vec (K1, krs_embed_bag_fwd)" if sum(hots) > len(hots) else \
+            "embed_gather_hot1 (K1 one-hot form, krs_embed_bag_fwd)"
+
+    lookups = a.batch * sum(primary)
     out = {
         "metric": "embedding lookups/sec + DCN fwd+bwd step time, 26-table DLRM batch 65 536",
         "value": lookups / (elapsed / a.steps),
         "unit": "lookups/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms,
+        "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None,
@@ -256,23 +299,23 @@ def main():
         "config": {
             "workload": ("C3 DLRM-small: %d tables x %d rows x %d (bf16), global batch %d, %s, "
                          "DotInteraction(F=%d) + %d x FeatureCross(d=%d, projection=%d), fused Adagrad on tables"
-                         % (a.tables, a.vocab, a.dim, a.batch,
-                            "multi-hot ml_perf lengths (sum L = %d)" % sum(hots) if a.multihot else "hotness L = 1",
-                            a.tables + 1, a.cross_layers, (a.tables + 1) * a.dim, a.projection)),
+                         % (a.tables, a.vocab, a.dim, a.batch, describe(primary), a.tables + 1, a.cross_layers,
+                            (a.tables + 1) * a.dim, a.projection)),
             "global_batch": a.batch,
             "parallelism": "single GPU" if world == 1 else f"tables MOD row-sharded over {world} GPUs, dense part DP",
         },
-        "embed_fwd_lookups_per_s": nnz_local * world / k1_s,
-        "roofline": {
-            "kernel": "embed_bag_fwd_vec (krs_embed_bag_fwd, K1)", "bound": "hbm",
-            "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-            "traffic": None,
-            "launch_us": k1_s * 1e6,
-            "algorithmic_bytes": k1_bytes(nnz_local, b_local * a.tables, a.dim, 2),
-        },
     }
+    second = {"workload": "same tables / model, " + describe(secondary),
+              "value": a.batch * sum(secondary) / (elapsed2 / sec_steps), "unit": "lookups/s",
+              "ms_per_step": elapsed2 / sec_steps * 1e3, "steps": sec_steps}
+    if k1_s is not None:
+        out["embed_fwd_lookups_per_s"] = b_local * sum(primary) / k1_s
+        out["roofline"] = k1_roofline(a, primary, b_local, k1_s, k1_name(primary))
+        second["embed_fwd_lookups_per_s"] = b_local * sum(secondary) / k1_s2
+        second["roofline"] = k1_roofline(a, secondary, b_local, k1_s2, k1_name(secondary))
+    out["also"] = second
     if not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a, hots)
+        out["cpu_baseline"] = cpu_baseline(a, primary)
     print(json.dumps(out))
 
 
