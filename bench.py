@@ -179,7 +179,8 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            probe = model.embedding(pre)  # K1 alone, bracketed by events on the launch stream
+            with torch.no_grad():  # forward only: K1 alone, bracketed by events on the launch stream
+                probe = model.embedding(pre)
             e1.record()
             k1_ev.append((e0, e1))
             del probe

@@ -11,6 +11,17 @@ from keras_rs_amd import _lib as L
 from keras_rs_amd import dense_ops as D
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = str(device)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _split_columns(out: torch.Tensor, n: int, dim: int):
     """Per-feature [B, dim] column views of the fused [B, n*dim] lookup output."""
     return tuple(out[:, i * dim:(i + 1) * dim] for i in range(n))
@@ -170,6 +181,21 @@ class EmbedBagFusedFn(torch.autograd.Function):
         ctx.bags, ctx.batch, ctx.hots, ctx.optimizer = bags, batch, hots, optimizer
         ctx.save_for_backward(ids, offsets, weights, scale)
         ctx.out_meta = (out.dtype, out.device)
+        # The backward's plan (sort of the lookups by row) depends only on the ids: start it now on
+        # a side stream so that it runs under the dense part of the step instead of in front of K2.
+        ctx.plan = None
+        if ctx.needs_input_grad[8]:  # a backward will follow (not under torch.no_grad())
+            main = torch.cuda.current_stream()
+            side = _side_stream(ids.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ws = bags.plan_backward(ids, batch, hots=hots, offsets=offsets)
+                done = torch.cuda.Event()
+                done.record(side)
+            for t in (ws, ids, offsets):
+                if t is not None:
+                    t.record_stream(side)
+            ctx.plan = (ws, done)
         return _split_columns(out, len(bags.features), bags.dim)
 
     @staticmethod
@@ -177,7 +203,12 @@ class EmbedBagFusedFn(torch.autograd.Function):
         ids, offsets, weights, scale = ctx.saved_tensors
         bags = ctx.bags
         g = _gather_feature_grads(gs, ctx.batch, bags.dim, *ctx.out_meta)
-        ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
+        if ctx.plan is not None:
+            ws, done = ctx.plan
+            torch.cuda.current_stream().wait_event(done)
+            ws.record_stream(torch.cuda.current_stream())
+        else:
+            ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
         bags.backward_fused(ctx.optimizer, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                             bag_scale=scale)
         return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device))
