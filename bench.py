@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--hotness", choices=["mlperf", "1"], default="mlperf",
                     help="primary bag lengths: the ml_perf list (sum L = 214, default) or L = 1; the other one is reported under `also`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the MOD-sharded embedding path even at N = 1 (dry run of the multi-GPU code)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2048)
     return ap.parse_args()
 
@@ -92,7 +94,7 @@ class Model(torch.nn.Module):
                                 combiner="sum", placement="sparsecore")
             feats[f"cat_{t:02d}_id"] = kl.FeatureConfig(f"cat_{t}", tc, (a.batch // world, hots[t]),
                                                        (a.batch // world, a.dim))
-        if world > 1:
+        if world > 1 or a.force_sharded:
             from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
             self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16")
@@ -219,7 +221,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
     # K1 launch duration, measured live in a separate short loop (the probe stays out of the timed region).
     # Single GPU only: in the sharded run the embedding call also contains the all-to-alls.
     k1_s = None
-    if world == 1:
+    if world == 1 and not a.force_sharded:
         for _ in range(10):
             step(record=True)
         torch.cuda.synchronize()

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(64) void dot_bwd_mfma_kernel(const DotParams p) {
   int64_t* t_ld = reinterpret_cast<int64_t*>(t_feat + 32);
   char** t_gfeat = reinterpret_cast<char**>(t_ld + 32);
   int64_t* t_gld = reinterpret_cast<int64_t*>(t_gfeat + 32);
+  float* g_l = reinterpret_cast<float*>(t_gld + 32);  // the sample's gradient row (<= 1024 entries)
+  const int n_gcols = p.skip_gather ? F * F : (p.self_inter ? F * (F + 1) / 2 : F * (F - 1) / 2);
   if (lane < 32) {
     const char* fp = nullptr; int64_t fl = 0; char* gp = nullptr; int64_t gl = 0;
 #pragma unroll
@@ -140,37 +142,50 @@ __global__ __launch_bounds__(64) void dot_bwd_mfma_kernel(const DotParams p) {
   const int pieces = p.dim / VE;  // 16-byte pieces per feature row
 
   for (int64_t b = blockIdx.x; b < p.batch; b += gridDim.x) {
-    // stage X (zero rows for f >= F)
-    for (int idx = lane; idx < 32 * pieces; idx += 64) {
-      const int f = idx / pieces, pc = idx - f * pieces;
-      float v[VE];
+    // stage X (zero rows for f >= F): loads are issued in batches of 8 before any is consumed
+    const int total = 32 * pieces;
+    for (int base = 0; base < total; base += 64 * 8) {
+      u32x4 raw[8];
 #pragma unroll
-      for (int q = 0; q < VE; ++q) v[q] = 0.0f;
-      if (f < F) {
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(t_feat[f] + (b * t_ld[f] + (int64_t)pc * VE) * ES);
-        if constexpr (ES == 2) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            v[2 * q] = __uint_as_float(raw[q] << 16);
-            v[2 * q + 1] = __uint_as_float(raw[q] & 0xffff0000u);
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = __uint_as_float(raw[q]);
-        }
+      for (int q = 0; q < 8; ++q) {
+        const int idx = base + q * 64 + lane;
+        const int f = min(idx / pieces, F - 1);            // clamped: always a real row
+        const int pc = idx % pieces;
+        raw[q] = *reinterpret_cast<const u32x4*>(t_feat[f] + (b * t_ld[f] + (int64_t)pc * VE) * ES);
       }
 #pragma unroll
-      for (int q = 0; q < VE; ++q) X[f * xs + pc * VE + q] = v[q];
+      for (int q = 0; q < 8; ++q) {
+        const int idx = base + q * 64 + lane;
+        if (idx < total) {
+          const int f = idx / pieces, pc = idx % pieces;
+          const bool live = f < F;
+          float* dst = X + f * xs + pc * VE;
+          if constexpr (ES == 2) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              dst[2 * w] = live ? __uint_as_float(raw[q][w] << 16) : 0.0f;
+              dst[2 * w + 1] = live ? __uint_as_float(raw[q][w] & 0xffff0000u) : 0.0f;
+            }
+          } else {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) dst[w] = live ? __uint_as_float(raw[q][w]) : 0.0f;
+          }
+        }
+      }
     }
-    // Gs[i][j] = G[i][j]*kept(i,j) + G[j][i]*kept(j,i)
+    // the sample's gradient row goes to LDS with coalesced loads first ...
+    for (int c = lane; c < n_gcols; c += 64) g_l[c] = ld_elem(p.out, dt, b * p.out_ld + c);
+    __syncthreads();
+    // ... then Gs[i][j] = G[i][j]*kept(i,j) + G[j][i]*kept(j,i) is built from LDS
     for (int e = lane; e < 1024; e += 64) {
       const int i = e >> 5, j = e & 31;
       float g = 0.0f;
       if (i < F && j < F) {
-        if (pair_kept(i, j, p.self_inter))
-          g += ld_elem(p.out, dt, b * p.out_ld + pair_col(i, j, F, p.self_inter, p.skip_gather));
-        if (pair_kept(j, i, p.self_inter))
-          g += ld_elem(p.out, dt, b * p.out_ld + pair_col(j, i, F, p.self_inter, p.skip_gather));
+        const int cij = (int)pair_col(i, j, F, p.self_inter, p.skip_gather);
+        const int cji = (int)pair_col(j, i, F, p.self_inter, p.skip_gather);
+        const float gij = g_l[pair_kept(i, j, p.self_inter) ? cij : 0];
+        const float gji = g_l[pair_kept(j, i, p.self_inter) ? cji : 0];
+        g = (pair_kept(i, j, p.self_inter) ? gij : 0.0f) + (pair_kept(j, i, p.self_inter) ? gji : 0.0f);
       }
       Gs[i * 33 + j] = g;
     }
@@ -352,7 +367,7 @@ extern "C" int krs_dot_interaction_bwd(const void* const* feats, const int64_t* 
     }
     p.n_feats = n_feats; p.batch = batch; p.dim = dim; p.self_inter = self_interaction != 0;
     p.skip_gather = skip_gather != 0; p.out = const_cast<void*>(grad_out); p.out_ld = grad_ld;
-    const size_t lds = (size_t)(32 * (dim + 4) + 32 * 33 + 2) * sizeof(float) + 32 * 4 * 8;
+    const size_t lds = (size_t)(32 * (dim + 4) + 32 * 33 + 2) * sizeof(float) + 32 * 4 * 8 + 1024 * sizeof(float);
     const unsigned blocks = (unsigned)std::min<int64_t>(batch, 256 * 32);
     const int nblk = (dim + 31) / 32;
 #define KRS_DOT_BWD(ES, NB)                                                                     \
