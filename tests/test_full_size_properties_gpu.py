@@ -1,0 +1,122 @@
+"""Parity at BASELINE.json's full sizes (C3: 26 tables x 1M rows x 128, batch 65,536) through
+size-independent properties -- the oracle would need minutes there, these need seconds:
+exact gathers, linearity in the weights, gradient checksums, optimizer round trips, permutation
+checks of the MOD bucketise, algebraic identities of DotInteraction / FeatureCross."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T, V, D, B = 26, 1_000_000, 128, 65536
+HOTS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
+
+
+@pytest.fixture(scope="module")
+def c3():
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    g = torch.Generator(device=DEV).manual_seed(1337)
+    tables = [(torch.rand(V, D, device=DEV, generator=g) * 0.1 - 0.05).to(torch.bfloat16) for _ in range(T)]
+    fb = FusedBags(tables, [(t, "sum", t * D) for t in range(T)])
+    return tables, fb, g
+
+
+def test_one_hot_lookup_is_an_exact_gather_at_full_size(c3):
+    tables, fb, g = c3
+    ids = torch.randint(0, V, (T, B), device=DEV, generator=g, dtype=torch.int32)
+    out, _ = fb.forward(ids.reshape(-1), B, hots=[1] * T)
+    for t in (0, 7, 25):
+        assert torch.equal(out[:, t * D:(t + 1) * D], tables[t][ids[t].long()])
+    # checksum of checksums over all tables: bit patterns of the gathered rows
+    ref = torch.stack([tables[t][ids[t].long()].view(torch.int16).sum(dtype=torch.int64) for t in range(T)])
+    got = torch.stack([out[:, t * D:(t + 1) * D].contiguous().view(torch.int16).sum(dtype=torch.int64) for t in range(T)])
+    assert torch.equal(ref, got)
+
+
+def test_multi_hot_pooling_is_linear_in_the_weights_and_matches_torch_on_a_slice(c3):
+    tables, fb, g = c3
+    ids = torch.cat([torch.randint(0, V, (B * h,), device=DEV, generator=g, dtype=torch.int32) for h in HOTS])
+    nnz = ids.numel()
+    w1 = torch.rand(nnz, device=DEV, generator=g)
+    w2 = torch.rand(nnz, device=DEV, generator=g)
+    o1, _ = fb.forward(ids, B, hots=HOTS, weights=w1, out_dtype=torch.float32)
+    o2, _ = fb.forward(ids, B, hots=HOTS, weights=w2, out_dtype=torch.float32)
+    o12, _ = fb.forward(ids, B, hots=HOTS, weights=w1 + w2, out_dtype=torch.float32)
+    torch.testing.assert_close(o1 + o2, o12, rtol=1e-5, atol=1e-5)
+    # the heaviest feature (hot = 100) against a plain torch composition on the first 512 samples
+    f = 20
+    base = B * sum(HOTS[:f])
+    sl = ids[base: base + 512 * 100].reshape(512, 100).long()
+    ws = w1[base: base + 512 * 100].reshape(512, 100)
+    ref = (tables[f][sl].float() * ws[..., None]).sum(1)
+    torch.testing.assert_close(o1[:512, f * D:(f + 1) * D], ref, rtol=1e-5, atol=1e-5)
+
+
+def test_gradient_checksum_and_sgd_round_trip_at_full_size(c3):
+    tables, fb, g = c3
+    hots = [1] * T
+    ids = torch.randint(0, V, (T * B,), device=DEV, generator=g, dtype=torch.int32)
+    grad = (torch.rand(B, T * D, device=DEV, generator=g) - 0.5).to(torch.bfloat16)
+    ws = fb.plan_backward(ids, B, hots=hots)
+    # sparse form: every lookup's gradient lands in exactly one unique row; column sums are preserved
+    rows, vals = fb.backward_sparse(ws, grad, B, ids.numel(), hots=hots)
+    assert torch.all(rows[1:] > rows[:-1])
+    uniq = torch.unique(ids.reshape(T, B).long() + torch.arange(T, device=DEV)[:, None] * V)
+    assert torch.equal(rows, uniq)
+    per_table = vals.sum(0, dtype=torch.float64)  # [D]: sum over tables of the column sums
+    ref = grad.float().reshape(B, T, D).sum((0, 1), dtype=torch.float64)
+    torch.testing.assert_close(per_table, ref, rtol=1e-6, atol=1e-3)
+    # fused SGD with lr then -lr restores the tables up to bf16 rounding of the intermediate
+    fb.lrs = [0.5] * T
+    before = [t.clone() for t in tables[:2]]
+    fb.backward_fused("sgd", ws, grad, B, ids.numel(), hots=hots)
+    assert not torch.equal(tables[0], before[0])
+    fb.lrs = [-0.5] * T
+    fb.backward_fused("sgd", ws, grad, B, ids.numel(), hots=hots)
+    for t, b in zip(tables[:2], before):
+        torch.testing.assert_close(t.float(), b.float(), rtol=0, atol=2 ** -8)
+    fb.lrs = [0.0] * T
+
+
+def test_mod_bucketize_is_a_stable_partition_at_full_size():
+    from keras_rs_amd import dense_ops as Dn
+
+    g = torch.Generator(device=DEV).manual_seed(3)
+    ids = torch.randint(0, V, (B * sum(HOTS),), device=DEV, generator=g, dtype=torch.int32)
+    for n in (2, 8):
+        local, perm, counts = Dn.mod_bucketize(ids, n)
+        assert int(counts.sum()) == ids.numel()
+        src = ids[perm.long()]
+        shard = torch.repeat_interleave(torch.arange(n, device=DEV), counts)
+        assert torch.equal(src % n, shard.to(src.dtype))           # grouped by owner
+        assert torch.equal(local * n + shard.to(local.dtype), src)  # local row + shard reconstruct the id
+        assert torch.equal(torch.sort(perm.long()).values, torch.arange(ids.numel(), device=DEV))
+        for s in range(n):  # stable: source positions ascend inside every bucket
+            lo = int(counts[:s].sum())
+            seg = perm[lo: lo + int(counts[s])]
+            assert torch.all(seg[1:] > seg[:-1])
+
+
+def test_dot_interaction_and_feature_cross_identities_at_full_size():
+    import keras_rs_amd.layers as kl
+
+    g = torch.Generator(device=DEV).manual_seed(5)
+    F = 27
+    x0 = (torch.rand(B, F * D, device=DEV, generator=g) - 0.5).to(torch.bfloat16)
+    feats = [x0[:, f * D:(f + 1) * D] for f in range(F)]
+    full = kl.DotInteraction(self_interaction=True, skip_gather=True, dtype="bfloat16")(feats).reshape(B, F, F)
+    packed = kl.DotInteraction(dtype="bfloat16")(feats)
+    idx = [(i, j) for i in range(F) for j in range(i)]
+    ii, jj = torch.tensor([i for i, _ in idx], device=DEV), torch.tensor([j for _, j in idx], device=DEV)
+    assert torch.equal(packed, full[:, ii, jj])                       # same dots, two packings
+    assert torch.all(full[:, jj, ii] == 0)                            # strictly-upper part is masked
+    diag = torch.stack([(f.float() ** 2).sum(1) for f in feats], 1)   # P[i][i] = |x_i|^2
+    torch.testing.assert_close(full[:, range(F), range(F)].float(), diag, rtol=2 ** -7, atol=1e-2)
+    # FeatureCross with a zero kernel: y = x0 * bias + x exactly (one fp32 fma, one rounding)
+    layer = kl.FeatureCross(projection_dim=512, kernel_initializer="zeros", bias_initializer="ones",
+                            dtype="mixed_bfloat16")
+    x = (torch.rand(B, F * D, device=DEV, generator=g) - 0.5).to(torch.bfloat16)
+    y = layer(x0, x)
+    assert torch.equal(y, (x0.float() + x.float()).to(torch.bfloat16))
