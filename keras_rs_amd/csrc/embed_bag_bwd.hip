@@ -29,6 +29,7 @@ namespace krs {
 namespace {
 
 constexpr uint32_t kInvalidKey = 0xffffffffu;
+constexpr int kLongSeg = 512;  // segments longer than this are summed by a whole workgroup
 
 struct PlanLayout {
   uint32_t* keys_in;      // dead after the sort -> reused as head flags
@@ -39,6 +40,8 @@ struct PlanLayout {
   uint32_t* head_index;   // = vals_in, first n words
   uint32_t* seg_start;    // = vals_in, next n words: first sorted position of every segment
   uint32_t* n_seg;        // number of segments (a trailing run of invalid keys counts as one)
+  uint32_t* n_long;       // number of segments longer than kLongSeg
+  uint32_t* long_list;    // their segment indices (any order)
   void* temp;
   size_t temp_bytes;
   size_t total_bytes;
@@ -68,7 +71,9 @@ PlanLayout plan_layout(void* ws, int64_t nnz, bool need_temp = false) {
   l.keys_sorted = reinterpret_cast<uint32_t*>(p + o); o += align_up(n * 4, 256);
   l.vals_in = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8 + 8, 256);
   l.vals_sorted = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8, 256);
-  l.n_seg = reinterpret_cast<uint32_t*>(p + o); o += 256;
+  l.n_seg = reinterpret_cast<uint32_t*>(p + o);
+  l.n_long = l.n_seg + 1; o += 256;
+  l.long_list = reinterpret_cast<uint32_t*>(p + o); o += align_up((n / kLongSeg + 2) * 4, 256);
   l.head_flag = l.keys_in;
   l.head_index = reinterpret_cast<uint32_t*>(l.vals_in);
   l.seg_start = reinterpret_cast<uint32_t*>(l.vals_in) + n;
@@ -143,6 +148,8 @@ struct ApplyParams {
   const uint64_t* vals;
   const uint32_t* seg_start;   // first sorted position of every segment
   const uint32_t* n_seg;       // device scalar
+  const uint32_t* n_long;      // device scalar
+  const uint32_t* long_list;
   int64_t* unique_rows;        // sparse
   float* row_grads;            // sparse
 };
@@ -290,6 +297,7 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
   const int64_t e0 = u + 1 < n_seg ? (int64_t)p.seg_start[u + 1] : p.nnz;
   const uint32_t key = p.keys[s0];
   if (key == kInvalidKey) return;  // the trailing run of out-of-range lookups (always the last segment)
+  if (e0 - s0 > kLongSeg) continue;  // hot row: summed by a whole workgroup in bag_apply_long_kernel
 
   // ---- the row this segment updates: issue its loads first ----
   krs_table tb{};
@@ -380,6 +388,122 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
   }  // segments of this group
 }
 
+// Hot rows (segments longer than kLongSeg, e.g. power-law ids or tiny vocabularies): one
+// workgroup per segment.  Its 256/LPR groups sum interleaved positions of the segment (four
+// gradient rows in flight each), the partial rows meet in LDS and are added in a fixed order
+// (group 0, 1, 2, ...), so the result stays run-to-run bit-identical.
+template <typename GT, typename TT, int LPR, int MODE, bool HAS_W>
+__global__ __launch_bounds__(256) void bag_apply_long_kernel(const ApplyParams p) {
+  constexpr int N = Piece<GT>::N;
+  constexpr int GPB = 256 / LPR;
+  extern __shared__ __attribute__((aligned(16))) char smem_long[];
+  float* part = reinterpret_cast<float*>(smem_long);  // [GPB][dim]
+  const uint32_t n_long = *p.n_long;
+  const uint32_t n_seg = *p.n_seg;
+  const int g = threadIdx.x / LPR;
+  const int sub = threadIdx.x % LPR;
+  const int row_pieces = (int)(((int64_t)p.dim * sizeof(GT)) >> 4);
+  const bool col_live = sub < row_pieces;
+  const int csub = col_live ? sub : 0;
+  const char* grad = reinterpret_cast<const char*>(p.grad) + (int64_t)csub * 16;
+  const bool g_aligned = ((reinterpret_cast<uintptr_t>(p.grad) | (uintptr_t)(p.grad_ld * sizeof(GT))) & 15) == 0;
+  for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) {
+    const uint32_t u = p.long_list[li];
+    const int64_t s0 = p.seg_start[u];
+    const int64_t e0 = u + 1 < n_seg ? (int64_t)p.seg_start[u + 1] : p.nnz;
+    const uint32_t key = p.keys[s0];
+    if (key == kInvalidKey) continue;
+    float acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = 0.0f;
+    for (int64_t j0 = s0 + g; j0 < e0; j0 += (int64_t)GPB * kApplyUnroll) {
+      uint64_t vv[kApplyUnroll];
+#pragma unroll
+      for (int q = 0; q < kApplyUnroll; ++q) vv[q] = p.vals[min(j0 + (int64_t)q * GPB, e0 - 1)];
+      float coef[kApplyUnroll];
+      u32x4 raw[kApplyUnroll];
+#pragma unroll
+      for (int q = 0; q < kApplyUnroll; ++q) {
+        const uint32_t bag = (uint32_t)(vv[q] >> 32);
+        const uint32_t pos = (uint32_t)vv[q];
+        const int f = (int)(bag / (uint32_t)p.batch);
+        const int b = (int)(bag - (uint32_t)f * (uint32_t)p.batch);
+        float c = 1.0f;
+        if constexpr (HAS_W) c = p.weights[pos];
+        if (p.bag_scale) c *= p.bag_scale[bag];
+        coef[q] = c;
+        const char* src = grad + ((int64_t)b * p.grad_ld + p.feats[f].out_col) * (int64_t)sizeof(GT);
+        if (g_aligned) {
+          raw[q] = *(gvec_ptr)src;
+        } else {
+          const GT* e = reinterpret_cast<const GT*>(src);
+          if constexpr (sizeof(GT) == 4) {
+            raw[q] = u32x4{__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
+          } else {
+            raw[q] = u32x4{e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16),
+                           e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16)};
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kApplyUnroll; ++q) {
+        if (j0 + (int64_t)q * GPB < e0) {
+          float gv[N];
+          Piece<GT>::unpack(make_uint4(raw[q].x, raw[q].y, raw[q].z, raw[q].w), gv);
+#pragma unroll
+          for (int k = 0; k < N; ++k) acc[k] = fmaf(coef[q], gv[k], acc[k]);
+        }
+      }
+    }
+    if (col_live) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) part[g * p.dim + sub * N + k] = acc[k];
+    }
+    __syncthreads();
+    if (g == 0 && col_live) {
+      float tot[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) tot[k] = 0.0f;
+      for (int gg = 0; gg < GPB; ++gg)
+#pragma unroll
+        for (int k = 0; k < N; ++k) tot[k] += part[gg * p.dim + sub * N + k];
+      if constexpr (MODE == kSparse) {
+        if (sub == 0) p.unique_rows[u] = (int64_t)key;
+        float* dst = p.row_grads + (int64_t)u * p.dim + sub * N;
+#pragma unroll
+        for (int k = 0; k < N; ++k) dst[k] = tot[k];
+      } else {
+        const uint64_t v0 = p.vals[s0];
+        const int f0 = (int)((uint32_t)(v0 >> 32) / (uint32_t)p.batch);
+        const krs_table tb = p.tables[p.feats[f0].table];
+        const int64_t off = ((int64_t)key - tb.row_base) * p.dim + sub * N;
+        const bool t_al = ((reinterpret_cast<uintptr_t>(tb.weights) | reinterpret_cast<uintptr_t>(tb.slot)) & 15) == 0;
+        if constexpr (MODE == kDense) {
+          store_elems<float, N>(reinterpret_cast<float*>(tb.weights) + off, tot, t_al);
+        } else {
+          float wv[N];
+          load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
+          if constexpr (MODE == kSgd) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) wv[k] = wv[k] - tb.lr * tot[k];
+          } else {
+            float av[N];
+            load_elems<float, N>(tb.slot + off, av, t_al);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              av[k] = fmaf(tot[k], tot[k], av[k]);
+              wv[k] = wv[k] - tb.lr * tot[k] / sqrtf(av[k]);
+            }
+            store_elems<float, N>(tb.slot + off, av, t_al);
+          }
+          store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Any dim / dtype: LPR lanes per segment, one column per lane per pass.
 template <int MODE>
 __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, int grad_dtype, int table_dtype,
@@ -440,6 +564,14 @@ __global__ void seg_scatter_kernel(const uint32_t* flags, const uint32_t* index,
   if (flags[i]) seg_start[index[i]] = (uint32_t)i;
   if (i == nnz - 1) *n_seg = index[i] + flags[i];
 }
+__global__ void long_list_kernel(const uint32_t* seg_start, const uint32_t* n_seg, int64_t nnz, uint32_t* n_long,
+                                 uint32_t* long_list) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ns = *n_seg;
+  if (u >= ns) return;
+  const int64_t e = u + 1 < ns ? (int64_t)seg_start[u + 1] : nnz;
+  if (e - (int64_t)seg_start[u] > kLongSeg) long_list[atomicAdd(n_long, 1u)] = (uint32_t)u;
+}
 __global__ void count_unique_kernel(const uint32_t* keys, const uint32_t* n_seg, int64_t nnz, int64_t* n_unique) {
   // segments minus the trailing run of invalid keys, if any
   *n_unique = (int64_t)*n_seg - (nnz > 0 && keys[nnz - 1] == kInvalidKey ? 1 : 0);
@@ -462,6 +594,23 @@ int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
   else { KRS_LAUNCH_APPLY(64) }
 #undef KRS_LAUNCH_APPLY
   KRS_CHECK_LAUNCH("bag_apply_kernel");
+  // hot rows: upper bound of the list length is nnz / kLongSeg; surplus workgroups leave at once
+  const int64_t max_long = p.nnz / kLongSeg;
+  if (max_long > 0) {
+    const unsigned lb = (unsigned)(max_long < 4096 ? max_long : 4096);
+    const size_t lds = (size_t)(256 / lpr) * p.dim * sizeof(float);
+#define KRS_LAUNCH_LONG(L)                                                                              \
+  if (p.weights)                                                                                        \
+    hipLaunchKernelGGL((bag_apply_long_kernel<GT, TT, L, MODE, true>), dim3(lb), dim3(256), lds, st, p); \
+  else                                                                                                  \
+    hipLaunchKernelGGL((bag_apply_long_kernel<GT, TT, L, MODE, false>), dim3(lb), dim3(256), lds, st, p);
+    if (lpr == 8) { KRS_LAUNCH_LONG(8) }
+    else if (lpr == 16) { KRS_LAUNCH_LONG(16) }
+    else if (lpr == 32) { KRS_LAUNCH_LONG(32) }
+    else { KRS_LAUNCH_LONG(64) }
+#undef KRS_LAUNCH_LONG
+    KRS_CHECK_LAUNCH("bag_apply_long_kernel");
+  }
   return KRS_OK;
 }
 
@@ -507,6 +656,7 @@ ApplyParams make_apply(const krs_table* tables, int n_tables, const krs_feature*
   p.bag_scale = bag_scale;
   p.grad = grad; p.grad_ld = grad_ld; p.batch = batch; p.dim = dim; p.nnz = nnz;
   p.keys = l.keys_sorted; p.vals = l.vals_sorted; p.seg_start = l.seg_start; p.n_seg = l.n_seg;
+  p.n_long = l.n_long; p.long_list = l.long_list;
   p.unique_rows = nullptr; p.row_grads = nullptr;
   return p;
 }
@@ -561,6 +711,10 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
   hipLaunchKernelGGL(seg_scatter_kernel, dim3(nb), dim3(256), 0, st, l.head_flag, l.head_index, nnz, l.seg_start,
                      l.n_seg);
   KRS_CHECK_LAUNCH("seg_scatter_kernel");
+  // segments too long for one lane group (at most nnz / kLongSeg of them)
+  KRS_HIP(hipMemsetAsync(l.n_long, 0, sizeof(uint32_t), st));
+  hipLaunchKernelGGL(long_list_kernel, dim3(nb), dim3(256), 0, st, l.seg_start, l.n_seg, nnz, l.n_long, l.long_list);
+  KRS_CHECK_LAUNCH("long_list_kernel");
   return KRS_OK;
 }
 

@@ -111,3 +111,32 @@ def test_fused_optimizers(kind, tdt, gdt, dim):
             np.testing.assert_allclose(got, exp_tables[t], rtol=1e-6, atol=1e-6)
         if kind == "adagrad":
             np.testing.assert_allclose(s["slots"][t].cpu().numpy(), exp_slots[t], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tdt,gdt,dim", [("f32", "f32", 128), ("bf16", "bf16", 64)])
+def test_hot_rows_take_the_workgroup_path(tdt, gdt, dim):
+    """Tiny vocabularies / skewed ids: segments far longer than kLongSeg (512) are summed by a whole
+    workgroup (bag_apply_long_kernel); dense, sparse and fused forms must still match the oracle."""
+    s = _setup(dim, tdt, gdt, False, use_w=True, combiners=["sum", "mean"], n_tables=2, batch=4000, max_hot=5,
+               vocab_hi=6, shared=True)
+    fb = s["fb"]
+    dense = fb.backward_dense(s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                              bag_scale=s["scale"])
+    again = fb.backward_dense(s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                              bag_scale=s["scale"])
+    for g, g2, e in zip(dense, again, s["de"]):
+        assert torch.equal(g, g2)  # still deterministic
+        np.testing.assert_allclose(g.cpu().numpy(), e, rtol=2e-5, atol=1e-3 if gdt == "bf16" else 2e-4)
+    rows, vals = fb.backward_sparse(s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                                    bag_scale=s["scale"])
+    np.testing.assert_allclose(vals.cpu().numpy(), np.concatenate(s["de"], 0)[rows.cpu().numpy()], rtol=2e-5,
+                               atol=1e-3 if gdt == "bf16" else 2e-4)
+    exp_tables = [to_np(t).copy() for t in s["tables"]]
+    exp_slots = [x.cpu().numpy().copy() for x in s["slots"]]
+    fb.backward_fused("adagrad", s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                      bag_scale=s["scale"])
+    for t in range(len(exp_tables)):
+        ko.apply_optimizer(exp_tables[t], exp_slots[t], s["de"][t], None, fb.lrs[t], "adagrad")
+        np.testing.assert_allclose(to_f32(to_np(s["tables"][t])), to_f32(exp_tables[t]),
+                                   rtol=2 ** -7 if tdt == "bf16" else 1e-5, atol=1e-5)
+        np.testing.assert_allclose(s["slots"][t].cpu().numpy(), exp_slots[t], rtol=1e-4, atol=1e-3)
