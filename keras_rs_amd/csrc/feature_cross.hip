@@ -108,6 +108,13 @@ __device__ __forceinline__ void store8(void* base, int dt, int64_t off, const fl
   }
 }
 
+__device__ __forceinline__ void unpack_bf16x8(const uint4& r, float (&f)[8]) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
 __device__ __forceinline__ void epilogue_store_vec8(const GemmParams& p, int64_t i, int64_t j, float (&v)[8]) {
   const int odt = p.out_dtype;
   if (p.has_ep) {
@@ -231,7 +238,10 @@ __device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) 
   }
 }
 
-template <int ES, bool A_KM, bool B_NK>
+// EPI: 0 = general epilogue, 1 = cross (bf16, vector access), 2 = residual add (bf16, vector access).
+// The specialised forms issue all their x0 / x / R loads for a 32-row half before the accumulators
+// are staged, so the epilogue is one memory latency deep instead of one per row group.
+template <int ES, bool A_KM, bool B_NK, int EPI>
 __global__ __launch_bounds__(256, 3) void gemm_mfma_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BK = ROW_BYTES / ES;  // K elements per tile
@@ -334,13 +344,28 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_kernel(const GemmParams p) {
   const int64_t gn = n0 + wn * 64 + ec;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {  // the wave's upper / lower 32 rows
+    // operands of the specialised epilogues: in flight while the accumulators are staged
+    uint4 ex[4], ex0[4];
+    if constexpr (EPI == 1 || EPI == 2) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t gmc = min(m0 + wm * 64 + i * 32 + it * 8 + (lane >> 3), p.m - 1);
+        const int64_t gnc = min(gn, p.n - 8);
+        if constexpr (EPI == 1) {
+          ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x) + gmc * p.ep.ldx + gnc);
+          ex0[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x0) + gmc * p.ep.ldx + gnc);
+        } else {
+          ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.r) + gmc * p.ep.ldr + gnc);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc[i][j][r];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private staging: no workgroup barrier
-#pragma unroll 2
+#pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int er = it * 8 + (lane >> 3);
       const int64_t gm = m0 + wm * 64 + i * 32 + er;
@@ -349,7 +374,31 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_kernel(const GemmParams p) {
       const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
       const float4 v1 = *reinterpret_cast<const float4*>(stage + er * SST + ec + 4);
       v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-      if (p.splits > 1) {
+      if constexpr (EPI == 1) {
+        if (p.ep.bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.ep.bias + gn);
+          const float4 b1 = *reinterpret_cast<const float4*>(p.ep.bias + gn + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (p.ep.act != KRS_ACT_NONE) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = apply_act(p.ep.act, v[q]);
+        }
+        if (p.ep.u_out) store8(p.ep.u_out, KRS_BF16, gm * p.ep.ldu + gn, v);
+        float xv[8], x0v[8];
+        unpack_bf16x8(ex[it], xv);
+        unpack_bf16x8(ex0[it], x0v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x0v[q] * (v[q] + p.ep.diag_scale * xv[q]) + xv[q];
+        store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
+      } else if constexpr (EPI == 2) {
+        float rv[8];
+        unpack_bf16x8(ex[it], rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
+        store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
+      } else if (p.splits > 1) {
         float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
         if (p.ep_vec) {
           *reinterpret_cast<float4*>(dst) = v0;
@@ -416,9 +465,15 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   const int64_t mt = p.a_km ? ceil_div(p.m, BM) : ceil_div(ceil_div(p.m, BM), 8) * 8;
   const dim3 grid((unsigned)(mt * ceil_div(p.n, BN)), 1, (unsigned)p.splits);
   const size_t lds = 2 * TILE_BYTES;
-#define KRS_GEMM_CASE(AK, BK_)                                                                      \
+  // specialised epilogues: bf16 output, vector access everywhere, no split-K
+  int epi = 0;
+  if (p.has_ep && p.ep_vec && p.splits == 1 && p.out_dtype == KRS_BF16 && p.n >= 8) {
+    if (p.ep.x0 && !p.ep.r) epi = 1;
+    else if (p.ep.r && !p.ep.x0 && !p.ep.bias && p.ep.act == KRS_ACT_NONE) epi = 2;
+  }
+#define KRS_GEMM_LAUNCH(AK, BK_, EP)                                                                \
   {                                                                                                 \
-    auto kern = gemm_mfma_kernel<ES, AK, BK_>;                                                      \
+    auto kern = gemm_mfma_kernel<ES, AK, BK_, EP>;                                                  \
     static bool attr_set = false;                                                                   \
     if (!attr_set) {                                                                                \
       KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                              \
@@ -427,10 +482,17 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     }                                                                                               \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);                                          \
   }
+#define KRS_GEMM_CASE(AK, BK_)                                                                      \
+  {                                                                                                 \
+    if (epi == 1) KRS_GEMM_LAUNCH(AK, BK_, 1)                                                       \
+    else if (epi == 2) KRS_GEMM_LAUNCH(AK, BK_, 2)                                                  \
+    else KRS_GEMM_LAUNCH(AK, BK_, 0)                                                                \
+  }
   if (p.a_km && p.b_nk) return fail(KRS_ERR_UNSUPPORTED, "krs_gemm: A^T . B^T layout is not used by the layer");
   if (p.a_km) KRS_GEMM_CASE(true, false)
   else if (p.b_nk) KRS_GEMM_CASE(false, true)
   else KRS_GEMM_CASE(false, false)
+#undef KRS_GEMM_LAUNCH
 #undef KRS_GEMM_CASE
   KRS_CHECK_LAUNCH("gemm_mfma_kernel");
   return KRS_OK;
