@@ -25,6 +25,7 @@
 // Shapes that do not meet the alignment rules take a plain one-thread-per-
 // output kernel (the reference's toy shapes, d = 3).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 
@@ -238,6 +239,99 @@ __device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) 
   }
 }
 
+// Epilogue shared by the GEMM kernels.  The accumulators go through LDS (the operand tiles are
+// dead by now) so that each lane ends up with 8 consecutive columns of one row: x0 / x / R are
+// read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], char* smem, int64_t m0,
+                                              int64_t n0, int split) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  // Epilogue.  The accumulators go through LDS (the operand tiles are dead: every wave passed
+  // the loop's last barrier) so that each lane ends up with 8 consecutive columns of one row:
+  // x0 / x / R are then read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
+  // MFMA C/D layout: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+  constexpr int SST = 68;  // staging row stride in floats (64 + pad)
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SST);  // 32 rows x 64 cols per wave
+  const int ec = (lane & 7) * 8;
+  const int64_t gn = n0 + wn * 64 + ec;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // the wave's upper / lower 32 rows
+    // operands of the specialised epilogues: in flight while the accumulators are staged
+    uint4 ex[4], ex0[4];
+    if constexpr (EPI == 1 || EPI == 2) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int64_t gmc = min(m0 + wm * 64 + i * 32 + it * 8 + (lane >> 3), p.m - 1);
+        const int64_t gnc = min(gn, p.n - 8);
+        if constexpr (EPI == 1) {
+          ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x) + gmc * p.ep.ldx + gnc);
+          ex0[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x0) + gmc * p.ep.ldx + gnc);
+        } else {
+          ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.r) + gmc * p.ep.ldr + gnc);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private staging: no workgroup barrier
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int er = it * 8 + (lane >> 3);
+      const int64_t gm = m0 + wm * 64 + i * 32 + er;
+      if (gm >= p.m || gn >= p.n) continue;
+      float v[8];
+      const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
+      const float4 v1 = *reinterpret_cast<const float4*>(stage + er * SST + ec + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      if constexpr (EPI == 1) {
+        if (p.ep.bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.ep.bias + gn);
+          const float4 b1 = *reinterpret_cast<const float4*>(p.ep.bias + gn + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (p.ep.act != KRS_ACT_NONE) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = apply_act(p.ep.act, v[q]);
+        }
+        if (p.ep.u_out) store8(p.ep.u_out, KRS_BF16, gm * p.ep.ldu + gn, v);
+        float xv[8], x0v[8];
+        unpack_bf16x8(ex[it], xv);
+        unpack_bf16x8(ex0[it], x0v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x0v[q] * (v[q] + p.ep.diag_scale * xv[q]) + xv[q];
+        store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
+      } else if constexpr (EPI == 2) {
+        float rv[8];
+        unpack_bf16x8(ex[it], rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
+        store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
+      } else if (p.splits > 1) {
+        float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
+        if (p.ep_vec) {
+          *reinterpret_cast<float4*>(dst) = v0;
+          *reinterpret_cast<float4*>(dst + 4) = v1;
+        } else {
+          for (int q = 0; q < 8 && gn + q < p.n; ++q) dst[q] = v[q];
+        }
+      } else if (p.ep_vec) {
+        epilogue_store_vec8(p, gm, gn, v);
+      } else {
+        for (int q = 0; q < 8 && gn + q < p.n; ++q) epilogue_store(p, gm, gn + q, v[q]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
 // EPI: 0 = general epilogue, 1 = cross (bf16, vector access), 2 = residual add (bf16, vector access).
 // The specialised forms issue all their x0 / x / R loads for a 32-row half before the accumulators
 // are staged, so the epilogue is one memory latency deep instead of one per row group.
@@ -334,86 +428,113 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma_kernel(const GemmParams p) {
   }
   __syncthreads();  // operand tiles are dead from here on
 
-  // Epilogue.  The accumulators go through LDS (the operand tiles are dead: every wave passed
-  // the loop's last barrier) so that each lane ends up with 8 consecutive columns of one row:
-  // x0 / x / R are then read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
-  // MFMA C/D layout: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
-  constexpr int SST = 68;  // staging row stride in floats (64 + pad)
-  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SST);  // 32 rows x 64 cols per wave
-  const int ec = (lane & 7) * 8;
-  const int64_t gn = n0 + wn * 64 + ec;
+  gemm_epilogue<EPI>(p, acc, smem, m0, n0, split);
+}
+
+// Forward / data-gradient shapes (both operands K-contiguous, K a multiple of the 64-element tile):
+// the operand tiles are written straight into LDS by the memory pipeline
+// (global_load_lds_dwordx4: no staging registers, no ds_write traffic), two stages deep:
+//   issue tile t+1 -> MFMA on tile t -> vmcnt(0) + one barrier.
+// An LDS-DMA instruction writes 64 lanes x 16 B = 1 KB contiguous (8 tile rows of 128 B), so the
+// tile cannot be padded; the conflict-free read layout is produced on the SOURCE side instead:
+// lane (row r, physical chunk pc) fetches the logical chunk pc ^ ((r >> 1) & 7), and fragment
+// reads apply the same XOR (scripts/lds_conflicts.py: 4 cycles per ds_read_b128, the minimum).
+// Rows beyond M / N are clamped (their results are never stored).
+template <int ES, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = ROW_BYTES / ES;
+  constexpr int OP_BYTES = BM * ROW_BYTES;   // 16 KB per operand tile
+  constexpr int STAGE_BYTES = 2 * OP_BYTES;  // A then B
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t nt = (p.n + BN - 1) / BN;
+  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int64_t m_tile = (slot / nt) * 8 + xcd;
+  if (m_tile * BM >= p.m) return;
+  const int64_t m0 = m_tile * BM;
+  const int64_t n0 = (slot % nt) * BN;
+  const int64_t ntiles = p.k / BK;
+
+  // per-lane source rows / chunks of the 4 DMA pieces this wave issues per operand and tile
+  const char* asrc[4];
+  const char* bsrc[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {  // the wave's upper / lower 32 rows
-    // operands of the specialised epilogues: in flight while the accumulators are staged
-    uint4 ex[4], ex0[4];
-    if constexpr (EPI == 1 || EPI == 2) {
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);            // tile row this lane fills
+    const int c = (lane & 7) ^ ((r >> 1) & 7);                  // logical 16-byte chunk it must fetch
+    const int64_t ar = min(m0 + r, p.m - 1);
+    const int64_t br = min(n0 + r, p.n - 1);
+    asrc[i] = p.a + (ar * p.lda) * ES + c * 16;
+    bsrc[i] = p.b + (br * p.ldb) * ES + c * 16;
+  }
+  auto issue = [&](int64_t t, int stage) {
+    char* sa = smem + stage * STAGE_BYTES + (wave * 4) * 1024;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int64_t gmc = min(m0 + wm * 64 + i * 32 + it * 8 + (lane >> 3), p.m - 1);
-        const int64_t gnc = min(gn, p.n - 8);
-        if constexpr (EPI == 1) {
-          ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x) + gmc * p.ep.ldx + gnc);
-          ex0[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x0) + gmc * p.ep.ldx + gnc);
-        } else {
-          ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.r) + gmc * p.ep.ldr + gnc);
-        }
-      }
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr)(asrc[i] + t * ROW_BYTES), (lptr)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(bsrc[i] + t * ROW_BYTES), (lptr)(sa + OP_BYTES + i * 1024), 16, 0, 0);
     }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc[i][j][r];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private staging: no workgroup barrier
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (ntiles > 0) issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  // fragment row offsets (bytes) and swizzle keys are loop invariant
+  int aoff[2], boff[2], akey[2], bkey[2];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int er = it * 8 + (lane >> 3);
-      const int64_t gm = m0 + wm * 64 + i * 32 + er;
-      if (gm >= p.m || gn >= p.n) continue;
-      float v[8];
-      const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
-      const float4 v1 = *reinterpret_cast<const float4*>(stage + er * SST + ec + 4);
-      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-      if constexpr (EPI == 1) {
-        if (p.ep.bias) {
-          const float4 b0 = *reinterpret_cast<const float4*>(p.ep.bias + gn);
-          const float4 b1 = *reinterpret_cast<const float4*>(p.ep.bias + gn + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (p.ep.act != KRS_ACT_NONE) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = apply_act(p.ep.act, v[q]);
-        }
-        if (p.ep.u_out) store8(p.ep.u_out, KRS_BF16, gm * p.ep.ldu + gn, v);
-        float xv[8], x0v[8];
-        unpack_bf16x8(ex[it], xv);
-        unpack_bf16x8(ex0[it], x0v);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = x0v[q] * (v[q] + p.ep.diag_scale * xv[q]) + xv[q];
-        store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
-      } else if constexpr (EPI == 2) {
-        float rv[8];
-        unpack_bf16x8(ex[it], rv);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
-        store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
-      } else if (p.splits > 1) {
-        float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
-        if (p.ep_vec) {
-          *reinterpret_cast<float4*>(dst) = v0;
-          *reinterpret_cast<float4*>(dst + 4) = v1;
-        } else {
-          for (int q = 0; q < 8 && gn + q < p.n; ++q) dst[q] = v[q];
-        }
-      } else if (p.ep_vec) {
-        epilogue_store_vec8(p, gm, gn, v);
-      } else {
-        for (int q = 0; q < 8 && gn + q < p.n; ++q) epilogue_store(p, gm, gn + q, v[q]);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + frow, rb = wn * 64 + i * 32 + frow;
+    aoff[i] = ra * ROW_BYTES; akey[i] = (ra >> 1) & 7;
+    boff[i] = OP_BYTES + rb * ROW_BYTES; bkey[i] = (rb >> 1) & 7;
   }
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
+    const char* st = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < ROW_BYTES / 32; ++ks) {
+      const int c = ks * 2 + fhalf;
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *reinterpret_cast<const u32x4*>(st + aoff[i] + ((c ^ akey[i]) << 4));
+        fb[i] = *reinterpret_cast<const u32x4*>(st + boff[i] + ((c ^ bkey[i]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (ES == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i][q]),
+                                                               __uint_as_float(fb[j][q]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
+    __syncthreads();                                   // and every wave is done with tile t
+  }
+  gemm_epilogue<EPI>(p, acc, smem, m0, n0, 0);
 }
 
 // fixed-order reduction of the split-K slabs + epilogue
@@ -489,6 +610,31 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     else KRS_GEMM_LAUNCH(AK, BK_, 0)                                                                \
   }
   if (p.a_km && p.b_nk) return fail(KRS_ERR_UNSUPPORTED, "krs_gemm: A^T . B^T layout is not used by the layer");
+  // Long contractions: the LDS-DMA pipeline (no staging registers, no ds_write traffic).  Short ones
+  // (K = 512: eight tiles, then a heavy epilogue) run better on the register-staged kernel, whose
+  // 36 KB of LDS lets three workgroups share a CU and hide each other's epilogues.
+  const bool use_glds = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0 && p.k >= 1024 &&
+                        getenv("KRS_GEMM_NO_GLDS") == nullptr;
+  if (use_glds) {
+    const size_t glds_lds = 4 * BM * ROW_BYTES;  // 2 stages x (A + B) x 16 KB
+#define KRS_GLDS_LAUNCH(EP)                                                                          \
+  {                                                                                                  \
+    auto kern = gemm_glds_kernel<ES, EP>;                                                            \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) {                                                                                 \
+      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds_lds));       \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(256), glds_lds, st, p);                                      \
+  }
+    if (epi == 1) KRS_GLDS_LAUNCH(1)
+    else if (epi == 2) KRS_GLDS_LAUNCH(2)
+    else KRS_GLDS_LAUNCH(0)
+#undef KRS_GLDS_LAUNCH
+    KRS_CHECK_LAUNCH("gemm_glds_kernel");
+    return KRS_OK;
+  }
   if (p.a_km) KRS_GEMM_CASE(true, false)
   else if (p.b_nk) KRS_GEMM_CASE(false, true)
   else KRS_GEMM_CASE(false, false)
