@@ -28,7 +28,7 @@ def _tol(dt, k):
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 3, 3), (5, 7, 9), (128, 128, 64), (130, 200, 72), (256, 512, 512),
-                                   (300, 136, 1000), (64, 3456, 512)])
+                                   (300, 136, 1000), (64, 3456, 512), (130, 200, 1088), (257, 512, 3456)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
 def test_gemm_layouts(m, n, k, dt, layout):
@@ -46,7 +46,7 @@ def test_gemm_layouts(m, n, k, dt, layout):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", [None, "relu", "sigmoid", "tanh"])
-@pytest.mark.parametrize("m,d,p", [(64, 128, 128), (200, 256, 64), (33, 24, 24)])
+@pytest.mark.parametrize("m,d,p", [(64, 128, 128), (200, 256, 64), (33, 24, 24), (200, 256, 1024)])
 def test_gemm_cross_epilogue(dt, act, m, d, p):
     from keras_rs_amd import dense_ops as D
 
