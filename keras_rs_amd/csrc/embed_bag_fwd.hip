@@ -509,6 +509,7 @@ extern "C" int krs_embed_bag_fwd(const krs_table* tables, const krs_feature* fea
   int bpg = (int)(32 / mean_hot);
   p.bpg = bpg < 1 ? 1 : (bpg > 16 ? 16 : bpg);
   if (const char* e = getenv("KRS_BPG")) p.bpg = atoi(e);  // development override
+  p.bpg = p.bpg < 1 ? 1 : (p.bpg > 16 ? 16 : p.bpg);          // the kernel stages at most 16 bag ends per group
 
   const int64_t row_bytes = (int64_t)dim * (table_dtype == KRS_BF16 ? 2 : 4);
   if (row_bytes % 16 == 0 && row_bytes <= 1024) {

@@ -123,3 +123,39 @@ def test_one_lookup_per_bag_on_average_but_uneven_hots(dt):
     exp, exp_scale, _ = oracle_embed_fwd([to_np(t) for t in tables], specs, bags, batch, dim, 3 * dim, NP_DT[dt], False)
     np.testing.assert_allclose(to_f32(to_np(out)), to_f32(exp), rtol=2 ** -7 if dt == "bf16" else 1e-6, atol=1e-6)
     np.testing.assert_allclose(scale.cpu().numpy(), exp_scale, rtol=1e-6)
+
+
+@pytest.mark.parametrize("dt,dim", [("bf16", 128), ("f32", 64), ("f32", 256)])
+def test_bags_longer_than_one_staging_window(dt, dim):
+    """A group's lookup stream is staged in LDS windows of 8*LPR ids: bags of 300 / 700 lookups span
+    several windows (dense and CSR, with weights, mean combiner so the divisor crosses windows too)."""
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    rng = np.random.default_rng(21)
+    dev = torch.device("cuda:0")
+    batch = 9
+    tables = [torch.from_numpy(rng.uniform(-1, 1, (500, dim)).astype(np.float32)).to(TORCH_DT[dt]).to(dev)
+              for _ in range(2)]
+    specs = [(0, "mean", 0), (1, "sum", dim), (0, "sqrtn", 2 * dim)]
+    tol = dict(rtol=2 ** -7, atol=1e-4) if dt == "bf16" else dict(rtol=2e-6, atol=2e-6)
+    # dense: hots 1, 300, 700
+    hots = [1, 300, 700]
+    ids = np.concatenate([rng.integers(0, 500, batch * h) for h in hots]).astype(np.int32)
+    w = rng.uniform(0, 1, ids.shape[0]).astype(np.float32)
+    out, _ = FusedBags(tables, specs).forward(torch.from_numpy(ids).to(dev), batch, hots=hots,
+                                              weights=torch.from_numpy(w).to(dev))
+    bags = dict(ids=ids, offsets=None, hots=hots, weights=w, nnz=len(ids))
+    exp, _, _ = oracle_embed_fwd([to_np(t) for t in tables], specs, bags, batch, dim, 3 * dim, NP_DT[dt], True)
+    np.testing.assert_allclose(to_f32(to_np(out)), to_f32(exp), **tol)
+    # CSR: ragged lengths up to 900, some empty
+    lens = rng.integers(0, 900, size=(3, batch))
+    lens[0, 3] = 0
+    offsets = np.concatenate([[0], np.cumsum(lens.reshape(-1))]).astype(np.int32)
+    ids = rng.integers(0, 500, int(lens.sum())).astype(np.int32)
+    w = rng.uniform(0, 1, ids.shape[0]).astype(np.float32)
+    out, _ = FusedBags(tables, specs).forward(torch.from_numpy(ids).to(dev), batch,
+                                              offsets=torch.from_numpy(offsets).to(dev),
+                                              weights=torch.from_numpy(w).to(dev))
+    bags = dict(ids=ids, offsets=offsets, hots=None, weights=w, nnz=len(ids))
+    exp, _, _ = oracle_embed_fwd([to_np(t) for t in tables], specs, bags, batch, dim, 3 * dim, NP_DT[dt], True)
+    np.testing.assert_allclose(to_f32(to_np(out)), to_f32(exp), **tol)
