@@ -198,6 +198,22 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
 
     for _ in range(warmup):
         step()
+    # K1 launch duration, measured live with events on the launch stream: forward-only calls of the
+    # embedding layer (one K1 launch each), between the warm-up and the timed steps.  Single GPU only: in the sharded
+    # run the embedding call also contains the all-to-alls.
+    k1_s = None
+    if world == 1 and not a.force_sharded:
+        with torch.no_grad():
+            for _ in range(3):
+                model.embedding(pre)
+            for _ in range(20):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                model.embedding(pre)
+                e1.record()
+                k1_ev.append((e0, e1))
+        torch.cuda.synchronize()
+        k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -214,22 +230,6 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    # K1 launch duration, measured live with events on the launch stream: forward-only calls of the
-    # embedding layer (one K1 launch each), after the timed region.  Single GPU only: in the sharded
-    # run the embedding call also contains the all-to-alls.
-    k1_s = None
-    if world == 1 and not a.force_sharded:
-        with torch.no_grad():
-            for _ in range(3):
-                model.embedding(pre)
-            for _ in range(20):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                model.embedding(pre)
-                e1.record()
-                k1_ev.append((e0, e1))
-        torch.cuda.synchronize()
-        k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
     return elapsed, k1_s
 
 

@@ -24,6 +24,7 @@ ap.add_argument("--stacked", action="store_true")
 ap.add_argument("--copyref", action="store_true")
 ap.add_argument("--idmode", default="rand")
 ap.add_argument("--fmajor_out", action="store_true")
+ap.add_argument("--scale", action="store_true")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -67,7 +68,7 @@ for bpg in (a.bpgs.split(",") if a.bpgs else [""]):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
     ev[0].record()
     for i in range(a.iters):
-        fb.forward(ids, a.batch, hots=hots, out=out)
+        fb.forward(ids, a.batch, hots=hots, out=out, want_scale=a.scale)
         ev[i + 1].record()
     torch.cuda.synchronize()
     ts = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters)]) * 1e-3
