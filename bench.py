@@ -202,6 +202,22 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
     # embedding layer (one K1 launch each), between the warm-up and the timed steps.  Single GPU only: in the sharded
     # run the embedding call also contains the all-to-alls.
     k1_s = None
+    if world > 1 or a.force_sharded:
+        # sharded run: the embedding call contains the all-to-alls, so K1 is timed on its own in the form
+        # the owner side runs it (row gather of this rank's share of the lookups from its shard)
+        emb = model.embedding
+        nloc = b_local * sum(hots)
+        rows = torch.randint(0, emb.shard.shape[0], (nloc,), device=dev, dtype=torch.int32)
+        for _ in range(3):
+            emb.kernels.gather_rows(emb.shard.data, rows)
+        for _ in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            emb.kernels.gather_rows(emb.shard.data, rows)
+            e1.record()
+            k1_ev.append((e0, e1))
+        torch.cuda.synchronize()
+        k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
     if world == 1 and not a.force_sharded:
         with torch.no_grad():
             for _ in range(3):
@@ -233,12 +249,14 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
     return elapsed, k1_s
 
 
-def k1_roofline(a, hots, b_local, k1_s, kernel):
+def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False):
     nnz = b_local * sum(hots)
-    alg = k1_bytes(nnz, b_local * a.tables, a.dim, 2)
+    # gather form (sharded owner side): one output vector per lookup, i.e. `bags` = nnz
+    alg = k1_bytes(nnz, nnz if gather_form else b_local * a.tables, a.dim, 2)
     achieved = alg / k1_s
     return {"kernel": kernel, "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": pmc_traffic(kernel), "launch_us": k1_s * 1e6,
+            "frac": achieved / HBM_PEAK, "traffic": None if gather_form else pmc_traffic(kernel),
+            "launch_us": k1_s * 1e6,
             "algorithmic_bytes": alg}
 
 
@@ -281,6 +299,9 @@ def main():
     # the other C3 bag-length list (SURVEY.md section 8d lists both), same tables and model, shorter run
     sec_steps = max(3, a.steps // 2)
     elapsed2, k1_s2 = measure(model, a, secondary, world, rank, dev, b_local, sec_steps, 2, opt_box)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
 
@@ -316,10 +337,13 @@ def main():
               "value": a.batch * sum(secondary) / (elapsed2 / sec_steps), "unit": "lookups/s",
               "ms_per_step": elapsed2 / sec_steps * 1e3, "steps": sec_steps}
     if k1_s is not None:
-        out["embed_fwd_lookups_per_s"] = b_local * sum(primary) / k1_s
-        out["roofline"] = k1_roofline(a, primary, b_local, k1_s, k1_name(primary))
-        second["embed_fwd_lookups_per_s"] = b_local * sum(secondary) / k1_s2
-        second["roofline"] = k1_roofline(a, secondary, b_local, k1_s2, k1_name(secondary))
+        sharded = world > 1 or a.force_sharded
+        n1 = "embed_gather_hot1 (K1 owner-side row gather of the sharded path, rank 0)" if sharded else k1_name(primary)
+        n2 = n1 if sharded else k1_name(secondary)
+        out["embed_fwd_lookups_per_s"] = world * b_local * sum(primary) / k1_s
+        out["roofline"] = k1_roofline(a, primary, b_local, k1_s, n1, sharded)
+        second["embed_fwd_lookups_per_s"] = world * b_local * sum(secondary) / k1_s2
+        second["roofline"] = k1_roofline(a, secondary, b_local, k1_s2, n2, sharded)
     out["also"] = second
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, primary)
