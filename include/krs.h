@@ -263,6 +263,7 @@ int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
  *   out [batch, out_cols], out_cols = F*F (skip_gather) | F(F+1)/2 | F(F-1)/2
  * Backward: dX[b,i,:] = sum_j (G[b,i,j] + G[b,j,i]) X[b,j,:], G = the gradient
  * scattered back to [F,F] (zero above / on the masked part).
+ * F <= 64 (KRS_ERR_UNSUPPORTED above; the MFMA path covers F <= 32, 16-B aligned rows).
  * ------------------------------------------------------------------------- */
 int krs_dot_interaction_fwd(const void* const* feats, const int64_t* ld, int n_feats,
                             int64_t batch, int dim, int dtype,

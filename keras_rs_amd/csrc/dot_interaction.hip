@@ -13,7 +13,7 @@
 // row -> contiguous stores).  No LDS, no stack copy.
 // Backward: dX = (G + G^T) X per sample; G+G^T (32x32) and X are staged in LDS
 // as fp32 and contracted with v_mfma_f32_32x32x2_f32.
-// Shapes outside the fast path (F > 32, odd D, unaligned) use plain kernels.
+// Shapes outside the fast path (32 < F <= 64, odd D, unaligned) use plain kernels.
 #include <algorithm>
 
 #include "krs_common.h"
@@ -223,12 +223,13 @@ __global__ __launch_bounds__(64) void dot_bwd_mfma_kernel(const DotParams p) {
   }
 }
 
-// ---- plain kernels (any F, D, alignment); feature pointer tables in device memory ----
+// ---- plain kernels (any D / alignment, F <= 64); the pointer tables travel as kernel arguments ----
+constexpr int kMaxGeneric = 64;
 struct DotGenericParams {
-  const void* const* feat;
-  const int64_t* ld;
-  void* const* gfeat;
-  const int64_t* gld;
+  const void* feat[kMaxGeneric];
+  int64_t ld[kMaxGeneric];
+  void* gfeat[kMaxGeneric];
+  int64_t gld[kMaxGeneric];
   int n_feats;
   int64_t batch;
   int dim;
@@ -296,22 +297,6 @@ int check_args(const void* const* feats, const int64_t* ld, int n_feats, int64_t
   return KRS_OK;
 }
 
-// Device pointer tables for the plain kernels live in a small per-thread pinned-free path:
-// they are passed through a stream-ordered copy from a host staging buffer the caller never sees.
-int upload_tables(const void* const* feats, const int64_t* ld, void* const* gfeats, const int64_t* gld, int n,
-                  void** dev_block, hipStream_t st) {
-  const size_t bytes = (size_t)n * 4 * 8;
-  KRS_HIP(hipMallocAsync(dev_block, bytes, st));
-  char* d = reinterpret_cast<char*>(*dev_block);
-  KRS_HIP(hipMemcpyAsync(d, feats, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  KRS_HIP(hipMemcpyAsync(d + (size_t)n * 8, ld, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  if (gfeats) {
-    KRS_HIP(hipMemcpyAsync(d + (size_t)n * 16, gfeats, (size_t)n * 8, hipMemcpyHostToDevice, st));
-    KRS_HIP(hipMemcpyAsync(d + (size_t)n * 24, gld, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  }
-  return KRS_OK;
-}
-
 }  // namespace
 }  // namespace krs
 
@@ -335,18 +320,15 @@ extern "C" int krs_dot_interaction_fwd(const void* const* feats, const int64_t* 
     KRS_CHECK_LAUNCH("dot_fwd_mfma_kernel");
     return KRS_OK;
   }
-  void* tab = nullptr;
-  if (int rc = upload_tables(feats, ld, nullptr, nullptr, n_feats, &tab, st)) return rc;
+  if (n_feats > kMaxGeneric)
+    return fail(KRS_ERR_UNSUPPORTED, "dot_interaction: at most %d features (got %d)", kMaxGeneric, n_feats);
   DotGenericParams g{};
-  char* d = reinterpret_cast<char*>(tab);
-  g.feat = reinterpret_cast<const void* const*>(d);
-  g.ld = reinterpret_cast<const int64_t*>(d + (size_t)n_feats * 8);
+  for (int f = 0; f < n_feats; ++f) { g.feat[f] = feats[f]; g.ld[f] = ld[f]; }
   g.n_feats = n_feats; g.batch = batch; g.dim = dim; g.self_inter = self_interaction != 0;
   g.skip_gather = skip_gather != 0; g.out = out; g.out_ld = out_ld; g.dtype = dtype;
   const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(batch * n_feats * n_feats, 256), 65536);
   hipLaunchKernelGGL(dot_fwd_generic_kernel, dim3(blocks), dim3(256), 0, st, g);
   KRS_CHECK_LAUNCH("dot_fwd_generic_kernel");
-  KRS_HIP(hipFreeAsync(tab, st));
   return KRS_OK;
 }
 
@@ -389,19 +371,16 @@ extern "C" int krs_dot_interaction_bwd(const void* const* feats, const int64_t* 
     KRS_CHECK_LAUNCH("dot_bwd_mfma_kernel");
     return KRS_OK;
   }
-  void* tab = nullptr;
-  if (int rc = upload_tables(feats, ld, grad_feats, grad_feat_ld, n_feats, &tab, st)) return rc;
+  if (n_feats > kMaxGeneric)
+    return fail(KRS_ERR_UNSUPPORTED, "dot_interaction: at most %d features (got %d)", kMaxGeneric, n_feats);
   DotGenericParams g{};
-  char* d = reinterpret_cast<char*>(tab);
-  g.feat = reinterpret_cast<const void* const*>(d);
-  g.ld = reinterpret_cast<const int64_t*>(d + (size_t)n_feats * 8);
-  g.gfeat = reinterpret_cast<void* const*>(d + (size_t)n_feats * 16);
-  g.gld = reinterpret_cast<const int64_t*>(d + (size_t)n_feats * 24);
+  for (int f = 0; f < n_feats; ++f) {
+    g.feat[f] = feats[f]; g.ld[f] = ld[f]; g.gfeat[f] = grad_feats[f]; g.gld[f] = grad_feat_ld[f];
+  }
   g.n_feats = n_feats; g.batch = batch; g.dim = dim; g.self_inter = self_interaction != 0;
   g.skip_gather = skip_gather != 0; g.out = const_cast<void*>(grad_out); g.out_ld = grad_ld; g.dtype = dtype;
   const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(batch * n_feats * dim, 256), 65536);
   hipLaunchKernelGGL(dot_bwd_generic_kernel, dim3(blocks), dim3(256), 0, st, g);
   KRS_CHECK_LAUNCH("dot_bwd_generic_kernel");
-  KRS_HIP(hipFreeAsync(tab, st));
   return KRS_OK;
 }

@@ -18,20 +18,15 @@
 //   * ids / offsets are read by all lanes of a group from one address
 //     (a single broadcast transaction per group), sequentially along the bag.
 // Algorithmic bytes per lookup: D*s_t + 4 (+4 with weights); per bag D*s_o + 4.
-#include <cstdlib>
-
 #include "krs_common.h"
 
-#ifndef KRS_K1_NT
-#define KRS_K1_NT 2  // bit1: nontemporal output stores (the pooled rows are written once, read later)
-#endif
 
 namespace krs {
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int NT = KRS_K1_NT;
+constexpr int NT = 2;  // bit 1: non-temporal output stores (pooled rows are written once, read by the next kernel)
 
 struct EmbedFwdParams {
   const krs_table* tables;
@@ -508,7 +503,6 @@ extern "C" int krs_embed_bag_fwd(const krs_table* tables, const krs_feature* fea
   const int64_t mean_hot = nnz / n_bags > 0 ? nnz / n_bags : 1;
   int bpg = (int)(32 / mean_hot);
   p.bpg = bpg < 1 ? 1 : (bpg > 16 ? 16 : bpg);
-  if (const char* e = getenv("KRS_BPG")) p.bpg = atoi(e);  // development override
   p.bpg = p.bpg < 1 ? 1 : (p.bpg > 16 ? 16 : p.bpg);          // the kernel stages at most 16 bag ends per group
 
   const int64_t row_bytes = (int64_t)dim * (table_dtype == KRS_BF16 ? 2 : 4);

@@ -25,7 +25,6 @@
 // Shapes that do not meet the alignment rules take a plain one-thread-per-
 // output kernel (the reference's toy shapes, d = 3).
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 
@@ -613,8 +612,7 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   // Long contractions: the LDS-DMA pipeline (no staging registers, no ds_write traffic).  Short ones
   // (K = 512: eight tiles, then a heavy epilogue) run better on the register-staged kernel, whose
   // 36 KB of LDS lets three workgroups share a CU and hide each other's epilogues.
-  const bool use_glds = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0 && p.k >= 1024 &&
-                        getenv("KRS_GEMM_NO_GLDS") == nullptr;
+  const bool use_glds = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0 && p.k >= 1024;
   if (use_glds) {
     const size_t glds_lds = 4 * BM * ROW_BYTES;  // 2 stages x (A + B) x 16 KB
 #define KRS_GLDS_LAUNCH(EP)                                                                          \

@@ -72,12 +72,5 @@ __device__ __forceinline__ int64_t ld_index(const void* p, int is64, int64_t i) 
 
 __host__ __device__ __forceinline__ int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// wave64 sum over all lanes (result in every lane)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 }  // namespace krs
 #endif

@@ -41,18 +41,29 @@ from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig
 class HipShardKernels:
     """The compute side of the sharded path on MI355X (K1 / K2 / K5 through the C ABI)."""
 
+    def __init__(self):
+        self._shard_bags: dict = {}
+
+    def _bags_for(self, table, slot, lr):
+        """One FusedBags (device descriptors) per shard storage, re-used across steps."""
+        from keras_rs_amd.embedding_ops import FusedBags
+
+        key = (table.data_ptr(), 0 if slot is None else slot.data_ptr(), float(lr))
+        fb = self._shard_bags.get(key)
+        if fb is None:
+            fb = self._shard_bags[key] = FusedBags([table], [(0, "sum", 0)], slots=[slot], lrs=[lr])
+        return fb
+
     def bucketize(self, ids: torch.Tensor, n_shards: int):
         from keras_rs_amd import dense_ops as D
 
         return D.mod_bucketize(ids, n_shards)
 
     def gather_rows(self, table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
-        from keras_rs_amd.embedding_ops import FusedBags
-
         n = rows.numel()
         if n == 0:
             return torch.empty((0, table.shape[1]), dtype=table.dtype, device=table.device)
-        out, _ = FusedBags([table], [(0, "sum", 0)]).forward(rows, n, hots=(1,))
+        out, _ = self._bags_for(table, None, 0.0).forward(rows, n, hots=(1,))
         return out
 
     def pool(self, vectors: torch.Tensor, slot_of_pos: torch.Tensor, feats, batch, hots, offsets, weights, out_dtype):
@@ -73,12 +84,10 @@ class HipShardKernels:
         return dv.to(dtype)
 
     def apply_rows(self, table, slot, rows, grads, lr, kind):
-        from keras_rs_amd.embedding_ops import FusedBags
-
         n = rows.numel()
         if n == 0:
             return
-        fb = FusedBags([table], [(0, "sum", 0)], slots=[slot], lrs=[lr])
+        fb = self._bags_for(table, slot, lr)
         ws = fb.plan_backward(rows, n, hots=(1,))
         fb.backward_fused(kind, ws, grads, n, n, hots=(1,))
 

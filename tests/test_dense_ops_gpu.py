@@ -157,6 +157,15 @@ def test_dot_interaction_fwd_bwd(dt, F, D_, B, si, sg):
         np.testing.assert_allclose(to_f32(to_np(a)), to_f32(e), **tol)
 
 
+def test_dot_interaction_feature_limit_is_loud():
+    from keras_rs_amd import dense_ops as D
+    from keras_rs_amd._lib import KrsError
+
+    feats = [_t(np.ones((2, 4), np.float32)) for _ in range(65)]
+    with pytest.raises(KrsError, match="at most 64 features"):
+        D.dot_interaction_fwd(feats, False, False)
+
+
 @pytest.mark.parametrize("n_shards", [1, 2, 4, 8, 5])
 @pytest.mark.parametrize("idt", [np.int32, np.int64])
 @pytest.mark.parametrize("nnz", [0, 1, 255, 2048, 100_003])
