@@ -236,6 +236,8 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
  *   bwd: given g = dL/dy and u = act(z) (z = h@K+b):
  *        dx0 (+)= g * (u + diag_scale*x)
  *        dxd = g + diag_scale * g*x0      (the non-GEMM part of dL/dx)
+ *              dxd == dx0 (same pointer) is the case "x is x0": dx0 then
+ *              receives the sum of both lines and nothing else is written
  *        du  = dz = g*x0 * act'(z), act' written through u (relu: u>0,
  *              sigmoid: u(1-u), tanh: 1-u^2)
  *        dbias[n] = sum_m dz[m,n]         (optional) */

@@ -81,10 +81,12 @@ class CrossLayerFn(torch.autograd.Function):
         x0c, xc, h, u, dc, kc = ctx.saved_tensors
         diag, act, same, low_rank, has_bias, x0_dt, x_dt, down_dt, k_dt = ctx.meta
         g = g.to(x0c.dtype).contiguous()
-        need_dxd = bool(diag)
+        need_dxd = bool(diag) and not same
+        # x is x0 (the first layer of a stack): both halves of dL/dx0 go through one buffer, which
+        # the data-gradient GEMM then takes as its residual -- no separate add.
         dz, dx0, dxd, dbias = D.cross_epilogue_bwd(g, u, x0c, xc, diag, act=act, want_dxd=need_dxd,
-                                                   want_dbias=has_bias)
-        direct = dxd if need_dxd else g  # dL/dx through "+ x" and "diag * x"
+                                                   want_dbias=has_bias, fold_direct=same)
+        direct = dx0 if same else (dxd if need_dxd else g)  # dL/dx through "+ x" and "diag * x"
         if low_rank:
             dk, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)      # dK = h^T dz     [p, d]
             dh, _ = D.gemm(dz, kc, b_is_nk=True)                               # dh = dz K^T     [B, p]
@@ -95,8 +97,7 @@ class CrossLayerFn(torch.autograd.Function):
             dd = None
             dx, _ = D.gemm(dz, kc, b_is_nk=True, r=direct, beta=1.0)           # dx = dz K^T + direct
         if same:
-            dx0 = dx0 + dx
-            gx0, gx = dx0.to(x0_dt), None
+            gx0, gx = dx.to(x0_dt), None
         else:
             gx0, gx = dx0.to(x0_dt), dx.to(x_dt)
         return (gx0, gx, None if dd is None else dd.to(down_dt), dk.to(k_dt),

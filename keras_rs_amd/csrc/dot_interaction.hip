@@ -11,10 +11,10 @@
 // registers), one 32x32 accumulator tile per sample, and the lower triangle is
 // written from the accumulator layout (lanes 0..31 = consecutive columns of one
 // row -> contiguous stores).  No LDS, no stack copy.
-// Backward: dX = (G + G^T) X per sample; G+G^T (32x32) and X are staged in LDS
-// as fp32 and contracted with v_mfma_f32_32x32x2_f32.
+// Backward: dX = (G + G^T) X per sample on the vector ALU (see dot_bwd_valu_kernel).
 // Shapes outside the fast path (32 < F <= 64, odd D, unaligned) use plain kernels.
 #include <algorithm>
+#include <type_traits>
 
 #include "krs_common.h"
 
@@ -109,118 +109,171 @@ __global__ __launch_bounds__(256) void dot_fwd_mfma_kernel(const DotParams p) {
   }
 }
 
-// Backward fast path: one wave (64-thread workgroup) per sample at a time.
-// LDS: X as fp32 [32][dim + 4], Gs = G + G^T as fp32 [32][33].
-template <int ES, int NBLK>  // NBLK = ceil(dim / 32) column blocks of the output
-__global__ __launch_bounds__(64) void dot_bwd_mfma_kernel(const DotParams p) {
+// Backward fast path (F <= 32, even D, 4-byte aligned rows, < 2 GiB per operand): fp32 FMAs, no MFMA.
+// dX[i] = sum_j Gs[i][j] X[j] is 2*F^2*D flops per sample against 2*F*D*s bytes: ~27 flop/B at
+// F = 27, far below the VALU ridge, and the contraction index (the feature) is the strided one in
+// memory, so feeding MFMA would need a transposing LDS pass.  Instead every lane owns two adjacent
+// columns d of ONE sample (a wave covers 128 columns: one sample at D = 128, 128/D samples for
+// smaller D), keeps the sample's rows x[j] and accumulators as float2 registers straight from
+// coalesced global loads, and walks the pairs j < i: one LDS broadcast read of G[i][j] (the
+// sample's gradient row, staged as fp32 in lower-triangle order whatever the output layout was)
+// feeds acc[i] += g x[j] and acc[j] += g x[i] as two v_pk_fma_f32.
+// The pair loops are fully unrolled over FR >= F rows (template), so registers AND the LDS offsets
+// are static; rows F..FR-1 are skipped by wave-uniform branches.
+// One iteration = (group of spw samples, 128-column chunk); the loads of iteration n+1 are issued
+// before the FMAs of iteration n, so HBM latency hides under the arithmetic.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int tri_cols(int rows, bool self) { return self ? rows * (rows + 1) / 2 : rows * (rows - 1) / 2; }
+
+template <int ES, int FR, bool SELF, bool MULTI>  // MULTI: several samples per wave (D < 128)
+__global__ __launch_bounds__(64) void dot_bwd_valu_kernel(const DotParams p, int lps_log2, int spw) {
+  constexpr int GSTRIDE = tri_cols(FR, SELF) + 1;                    // LDS floats per sample
+  constexpr int NG = MULTI ? 16 : (tri_cols(FR, SELF) + 63) / 64;    // gradient elements per lane in flight
+  // LDS: [64] {pointer, row stride in bytes} of the F inputs and F outputs, then [2][spw][GSTRIDE]
+  // gradient rows.  The pointer table lives in LDS (not in SGPRs) on purpose: 4 * FR kernel
+  // arguments kept live across the loop would spill, and LDS reads cannot be hoisted out of it.
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  u32x4* tab = reinterpret_cast<u32x4*>(smem);
+  float* g_l = reinterpret_cast<float*>(smem + 64 * sizeof(u32x4));
   const int lane = threadIdx.x;
   const int F = p.n_feats;
-  const int xs = p.dim + 4;  // padded row stride (floats)
-  float* X = reinterpret_cast<float*>(smem);
-  float* Gs = X + 32 * xs;
-  // per-feature pointer tables, staged once so they can be indexed dynamically
-  const char** t_feat = reinterpret_cast<const char**>(Gs + 32 * 33 + 1 + ((32 * xs + 32 * 33 + 1) & 1));
-  int64_t* t_ld = reinterpret_cast<int64_t*>(t_feat + 32);
-  char** t_gfeat = reinterpret_cast<char**>(t_ld + 32);
-  int64_t* t_gld = reinterpret_cast<int64_t*>(t_gfeat + 32);
-  float* g_l = reinterpret_cast<float*>(t_gld + 32);  // the sample's gradient row (<= 1024 entries)
-  const int n_gcols = p.skip_gather ? F * F : (p.self_inter ? F * (F + 1) / 2 : F * (F - 1) / 2);
-  if (lane < 32) {
-    const char* fp = nullptr; int64_t fl = 0; char* gp = nullptr; int64_t gl = 0;
-#pragma unroll
-    for (int q = 0; q < kMaxFast; ++q)
-      if (q == lane) {
-        fp = reinterpret_cast<const char*>(p.feat[q]); fl = p.ld[q];
-        gp = reinterpret_cast<char*>(p.gfeat[q]); gl = p.gld[q];
-      }
-    t_feat[lane] = fp; t_ld[lane] = fl; t_gfeat[lane] = gp; t_gld[lane] = gl;
-  }
-  __syncthreads();
-  constexpr int VE = 16 / ES;
-  const int dt = ES == 2 ? KRS_BF16 : KRS_F32;
-  const int pieces = p.dim / VE;  // 16-byte pieces per feature row
+  const int lps = 1 << lps_log2;          // lanes per sample
+  const int slot = lane >> lps_log2;      // which of the wave's samples this lane works on
+  const int dp = lane & (lps - 1);
+  const int ncols = p.skip_gather ? F * F : tri_cols(F, SELF);  // columns of the incoming gradient
+  const int gtotal = spw * ncols;
+  const int chunks = (p.dim + 2 * lps - 1) / (2 * lps);
+  const int64_t n_groups = (p.batch + spw - 1) / spw;
+  // this workgroup's groups are blockIdx.x + k * gridDim.x; local iteration n = k * chunks + chunk
+  const int64_t my_groups = blockIdx.x < n_groups ? (n_groups - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+  const int64_t n_iters = my_groups * chunks;
+  typedef typename std::conditional<ES == 2, uint32_t, f32x2>::type raw_t;   // two adjacent columns
+  typedef typename std::conditional<ES == 2, uint16_t, float>::type gelem_t;
 
-  for (int64_t b = blockIdx.x; b < p.batch; b += gridDim.x) {
-    // stage X (zero rows for f >= F): loads are issued in batches of 8 before any is consumed
-    const int total = 32 * pieces;
-    for (int base = 0; base < total; base += 64 * 8) {
-      u32x4 raw[8];
+  {
+    const int f = lane & 31;
+    uint64_t ptr = 0;
+    int64_t stride = 0;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = base + q * 64 + lane;
-        const int f = min(idx / pieces, F - 1);            // clamped: always a real row
-        const int pc = idx % pieces;
-        raw[q] = *reinterpret_cast<const u32x4*>(t_feat[f] + (b * t_ld[f] + (int64_t)pc * VE) * ES);
+    for (int q = 0; q < kMaxFast; ++q)  // static kernarg indices
+      if (q == f) {
+        ptr = reinterpret_cast<uint64_t>(lane < 32 ? p.feat[q] : p.gfeat[q]);
+        stride = lane < 32 ? p.ld[q] : p.gld[q];
       }
+    tab[lane] = u32x4{(uint32_t)ptr, (uint32_t)(ptr >> 32), (uint32_t)stride * ES, 0u};
+  }
+
+  raw_t xr[FR];
+  gelem_t gr[NG];
+  auto issue = [&](int64_t it) {
+    const int64_t k = it / chunks;
+    const int ch = (int)(it - k * chunks);
+    const int64_t grp = blockIdx.x + k * gridDim.x;
+    const int64_t b = grp * spw + slot;
+    const bool live = slot < spw && b < p.batch;
+    const int d = ch * 2 * lps + 2 * dp;
+    const uint32_t bc = (uint32_t)(live ? b : p.batch - 1);   // clamped: every load is unconditional
+    const uint32_t dc = (live && d < p.dim) ? d : 0;
+    if (ch == 0) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int idx = base + q * 64 + lane;
-        if (idx < total) {
-          const int f = idx / pieces, pc = idx % pieces;
-          const bool live = f < F;
-          float* dst = X + f * xs + pc * VE;
-          if constexpr (ES == 2) {
+      for (int q = 0; q < NG; ++q) {  // clamped, unconditional, converted only when consumed
+        const int idx = min(q * 64 + lane, gtotal - 1);
+        const int sidx = MULTI ? idx / ncols : 0;
+        const int c = idx - sidx * ncols;
+        const int64_t bb = min(grp * spw + sidx, p.batch - 1);
+        gr[q] = reinterpret_cast<const gelem_t __attribute__((address_space(1)))*>(
+            reinterpret_cast<uint64_t>(p.out))[bb * p.out_ld + c];
+      }
+    }
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              dst[2 * w] = live ? __uint_as_float(raw[q][w] << 16) : 0.0f;
-              dst[2 * w + 1] = live ? __uint_as_float(raw[q][w] & 0xffff0000u) : 0.0f;
-            }
-          } else {
+    for (int j = 0; j < FR; ++j) {  // entries j >= F repeat the last feature (host side)
+      const u32x4 e = tab[j];
+      const uint64_t addr = (((uint64_t)e[1] << 32) | e[0]) + (uint64_t)bc * e[2] + dc * ES;
+      xr[j] = *reinterpret_cast<const raw_t __attribute__((address_space(1)))*>(addr);
+    }
+  };
+
+  if (n_iters > 0) issue(0);
+  int parity = 0;
+  for (int64_t it = 0; it < n_iters; ++it) {
+    const int64_t k = it / chunks;
+    const int ch = (int)(it - k * chunks);
+    const int64_t grp = blockIdx.x + k * gridDim.x;
+    const int64_t b = grp * spw + slot;
+    const int d = ch * 2 * lps + 2 * dp;
+    const bool act = slot < spw && b < p.batch && d < p.dim;
+    if (ch == 0) {
+      parity ^= 1;
+      float* dstg = g_l + parity * spw * GSTRIDE;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) dst[w] = live ? __uint_as_float(raw[q][w]) : 0.0f;
-          }
+      for (int q = 0; q < NG; ++q) {
+        const int idx = q * 64 + lane;
+        const int sidx = MULTI ? idx / ncols : 0;
+        int c = idx - sidx * ncols;
+        bool keep = idx < gtotal;
+        if (p.skip_gather) {  // [F, F] masked layout -> lower-triangle order
+          const int i = c / F, j = c - i * F;
+          keep = keep && (SELF ? j <= i : j < i);
+          c = tri_cols(i, SELF) + j;
+        }
+        float v;
+        if constexpr (ES == 2) v = bf16_to_f32(gr[q]); else v = gr[q];
+        if (keep) dstg[sidx * GSTRIDE + c] = v;
+      }
+    }
+    f32x2 x[FR], acc[FR];
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+      if constexpr (ES == 2) x[j] = f32x2{__uint_as_float(xr[j] << 16), __uint_as_float(xr[j] & 0xffff0000u)};
+      else x[j] = xr[j];
+      // pin the unpacked value here: left alone, the compiler sinks the unpack into the FMA section
+      // and then waits on the loads issued below (and the previous stores) through the in-order vmcnt
+      asm volatile("" : "+v"(x[j]));
+      acc[j] = f32x2{0.0f, 0.0f};
+    }
+    // single-wave workgroup: LDS operations of a wave complete in order, the barrier only keeps the
+    // compiler from moving the reads below over the writes above (no vmcnt wait as __syncthreads has)
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    issue(it + 1 < n_iters ? it + 1 : it);
+    const float* grow = g_l + parity * spw * GSTRIDE + (MULTI ? (slot < spw ? slot : 0) * GSTRIDE : 0);
+#pragma unroll
+    for (int i = 0; i < FR; ++i) {
+      // The wave-uniform branch also makes every row its own basic block: as one straight-line
+      // block the compiler hoists all F(F-1)/2 LDS reads to the top and spills.
+      if (i < F) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+          const float g = grow[tri_cols(i, SELF) + j];
+          const f32x2 g2 = {g, g};
+          acc[i] += g2 * x[j];
+          acc[j] += g2 * x[i];
+        }
+        if constexpr (SELF) {
+          const float g = 2.0f * grow[tri_cols(i, SELF) + i];
+          acc[i] += f32x2{g, g} * x[i];
         }
       }
     }
-    // the sample's gradient row goes to LDS with coalesced loads first ...
-    for (int c = lane; c < n_gcols; c += 64) g_l[c] = ld_elem(p.out, dt, b * p.out_ld + c);
-    __syncthreads();
-    // ... then Gs[i][j] = G[i][j]*kept(i,j) + G[j][i]*kept(j,i) is built from LDS
-    for (int e = lane; e < 1024; e += 64) {
-      const int i = e >> 5, j = e & 31;
-      float g = 0.0f;
-      if (i < F && j < F) {
-        const int cij = (int)pair_col(i, j, F, p.self_inter, p.skip_gather);
-        const int cji = (int)pair_col(j, i, F, p.self_inter, p.skip_gather);
-        const float gij = g_l[pair_kept(i, j, p.self_inter) ? cij : 0];
-        const float gji = g_l[pair_kept(j, i, p.self_inter) ? cji : 0];
-        g = (pair_kept(i, j, p.self_inter) ? gij : 0.0f) + (pair_kept(j, i, p.self_inter) ? gji : 0.0f);
-      }
-      Gs[i * 33 + j] = g;
-    }
-    __syncthreads();
-
-    f32x16 acc[NBLK];
 #pragma unroll
-    for (int n = 0; n < NBLK; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-    const int row = lane & 31;
-    const int half = lane >> 5;
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const int j = 2 * s + half;
-      const float a = Gs[row * 33 + j];  // A[i = row][k = j]
-#pragma unroll
-      for (int n = 0; n < NBLK; ++n) {
-        const int d = n * 32 + row;
-        const float bv = d < p.dim ? X[j * xs + d] : 0.0f;  // B[k = j][n = d]
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[n], 0, 0, 0);
+    for (int i = 0; i < FR; ++i) {
+      if (i < F && act) {
+        const u32x4 e = tab[32 + i];
+        const uint64_t dst = (((uint64_t)e[1] << 32) | e[0]) + (uint64_t)(uint32_t)b * e[2] + d * ES;
+        if constexpr (ES == 2)
+          *reinterpret_cast<uint32_t __attribute__((address_space(1)))*>(dst) = pack_bf16x2(acc[i][0], acc[i][1]);
+        else
+          *reinterpret_cast<f32x2 __attribute__((address_space(1)))*>(dst) = acc[i];
       }
     }
-    // dX[i][d]: d = n*32 + (lane & 31), i = (r & 3) + 8*(r >> 2) + 4*half
-#pragma unroll
-    for (int n = 0; n < NBLK; ++n) {
-      const int d = n * 32 + row;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (i < F && d < p.dim) st_elem(t_gfeat[i], dt, b * t_gld[i] + d, acc[n][r]);
-      }
-    }
-    __syncthreads();
   }
+}
+
+template <int ES, int FR, bool SELF, bool MULTI>
+void launch_dot_bwd(const DotParams& p, int lps_log2, int spw, unsigned blocks, hipStream_t st) {
+  const size_t lds = 64 * 16 + (size_t)2 * spw * (tri_cols(FR, SELF) + 1) * sizeof(float);  // table + double buffer
+  hipLaunchKernelGGL((dot_bwd_valu_kernel<ES, FR, SELF, MULTI>), dim3(blocks), dim3(64), lds, st, p, lps_log2, spw);
 }
 
 // ---- plain kernels (any D / alignment, F <= 64); the pointer tables travel as kernel arguments ----
@@ -341,34 +394,40 @@ extern "C" int krs_dot_interaction_bwd(const void* const* feats, const int64_t* 
   if (batch == 0) return KRS_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int es = dtype == KRS_BF16 ? 2 : 4;
-  bool fast = fast_ok(feats, ld, n_feats, dim, es) && dim <= 256;
+  // pairs of adjacent columns per lane: rows 2*es-byte aligned, even D; 32-bit byte offsets
+  bool fast = n_feats <= kMaxFast && dim % 2 == 0;
+  for (int f = 0; fast && f < n_feats; ++f)
+    fast = !(reinterpret_cast<uintptr_t>(feats[f]) % (2 * es)) && !(reinterpret_cast<uintptr_t>(grad_feats[f]) % (2 * es)) &&
+           ld[f] % 2 == 0 && grad_feat_ld[f] % 2 == 0 && ld[f] > 0 && grad_feat_ld[f] > 0 &&
+           (batch * ld[f] + dim) * es < (int64_t(1) << 31) && (batch * grad_feat_ld[f] + dim) * es < (int64_t(1) << 31);
   if (fast) {
     DotParams p{};
-    for (int f = 0; f < n_feats; ++f) {
-      p.feat[f] = feats[f]; p.ld[f] = ld[f]; p.gfeat[f] = grad_feats[f]; p.gld[f] = grad_feat_ld[f];
+    for (int f = 0; f < kMaxFast; ++f) {
+      const int q = std::min(f, n_feats - 1);  // slots past F repeat the last feature: loads stay valid
+      p.feat[f] = feats[q]; p.ld[f] = ld[q]; p.gfeat[f] = grad_feats[q]; p.gld[f] = grad_feat_ld[q];
     }
     p.n_feats = n_feats; p.batch = batch; p.dim = dim; p.self_inter = self_interaction != 0;
     p.skip_gather = skip_gather != 0; p.out = const_cast<void*>(grad_out); p.out_ld = grad_ld;
-    const size_t lds = (size_t)(32 * (dim + 4) + 32 * 33 + 2) * sizeof(float) + 32 * 4 * 8 + 1024 * sizeof(float);
-    const unsigned blocks = (unsigned)std::min<int64_t>(batch, 256 * 32);
-    const int nblk = (dim + 31) / 32;
-#define KRS_DOT_BWD(ES, NB)                                                                     \
-  hipLaunchKernelGGL((dot_bwd_mfma_kernel<ES, NB>), dim3(blocks), dim3(64), lds, st, p)
-#define KRS_DOT_BWD_ES(ES)                                                                      \
-  switch (nblk) {                                                                               \
-    case 1: KRS_DOT_BWD(ES, 1); break;                                                          \
-    case 2: KRS_DOT_BWD(ES, 2); break;                                                          \
-    case 3: KRS_DOT_BWD(ES, 3); break;                                                          \
-    case 4: KRS_DOT_BWD(ES, 4); break;                                                          \
-    case 5: KRS_DOT_BWD(ES, 5); break;                                                          \
-    case 6: KRS_DOT_BWD(ES, 6); break;                                                          \
-    case 7: KRS_DOT_BWD(ES, 7); break;                                                          \
-    default: KRS_DOT_BWD(ES, 8); break;                                                         \
-  }
-    if (es == 2) { KRS_DOT_BWD_ES(2) } else { KRS_DOT_BWD_ES(4) }
-#undef KRS_DOT_BWD_ES
+    const int ncols = skip_gather ? n_feats * n_feats : tri_cols(n_feats, self_interaction != 0);
+    int lps_log2 = 0;
+    while ((2 << lps_log2) < dim && lps_log2 < 6) ++lps_log2;     // lanes per sample: dim/2 up to 64
+    const int spw = std::min(64 >> lps_log2, std::max(1, 1024 / std::max(ncols, 1)));
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(batch, spw), 256 * 64);
+    // one sample per wave: rows rounded up to 28 (the 26 + 1 features of DLRM) or 32; several
+    // samples per wave (small D) and the [F, F] layout always take the 32-row build
+    const bool multi = spw > 1 || ncols > 64 * ((tri_cols(kMaxFast, true) + 63) / 64);
+    const bool self = self_interaction != 0;
+#define KRS_DOT_BWD(ES)                                                                        \
+  if (multi) { if (self) launch_dot_bwd<ES, 32, true, true>(p, lps_log2, spw, blocks, st);      \
+               else launch_dot_bwd<ES, 32, false, true>(p, lps_log2, spw, blocks, st); }        \
+  else if (n_feats <= 28 && !skip_gather) {                                                     \
+               if (self) launch_dot_bwd<ES, 28, true, false>(p, lps_log2, spw, blocks, st);     \
+               else launch_dot_bwd<ES, 28, false, false>(p, lps_log2, spw, blocks, st); }       \
+  else {       if (self) launch_dot_bwd<ES, 32, true, false>(p, lps_log2, spw, blocks, st);     \
+               else launch_dot_bwd<ES, 32, false, false>(p, lps_log2, spw, blocks, st); }
+    if (es == 2) { KRS_DOT_BWD(2) } else { KRS_DOT_BWD(4) }
 #undef KRS_DOT_BWD
-    KRS_CHECK_LAUNCH("dot_bwd_mfma_kernel");
+    KRS_CHECK_LAUNCH("dot_bwd_valu_kernel");
     return KRS_OK;
   }
   if (n_feats > kMaxGeneric)

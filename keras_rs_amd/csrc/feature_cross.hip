@@ -725,6 +725,7 @@ __global__ __launch_bounds__(64) void cross_bwd_vec_kernel(const CrossParams p, 
   if (col >= p.n) return;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = min(p.m, r0 + rows_per_block);
+  const bool fold = p.dxd == p.dx0;  // x is x0: the direct term lands in dx0 as well
   float db[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) db[k] = 0.0f;
@@ -750,10 +751,13 @@ __global__ __launch_bounds__(64) void cross_bwd_vec_kernel(const CrossParams p, 
       RowVec<T, V>::load(p.x, o, x);
       if (p.dx0_acc) RowVec<T, V>::load(p.dx0, o, t);
 #pragma unroll
-      for (int k = 0; k < V; ++k) t[k] = (p.dx0_acc ? t[k] : 0.0f) + g[k] * (u[k] + p.diag * x[k]);
+      for (int k = 0; k < V; ++k) {
+        t[k] = (p.dx0_acc ? t[k] : 0.0f) + g[k] * (u[k] + p.diag * x[k]);
+        if (fold) t[k] += g[k] + p.diag * gx0[k];
+      }
       RowVec<T, V>::store(p.dx0, o, t);
     }
-    if (p.dxd) {
+    if (p.dxd && !fold) {
 #pragma unroll
       for (int k = 0; k < V; ++k) t[k] = g[k] + p.diag * gx0[k];
       RowVec<T, V>::store(p.dxd, o, t);
@@ -778,11 +782,14 @@ __global__ __launch_bounds__(64) void cross_bwd_scalar_kernel(const CrossParams 
     const float dz = gx0 * act_grad_from_output(p.act, uv);
     db += dz;
     if (p.du) st_elem(p.du, p.dtype, o, dz);
+    const bool fold = p.dxd == p.dx0;
     if (p.dx0) {
       const float uf = uv + p.diag * ld_elem(p.x, p.dtype, o);
-      st_elem(p.dx0, p.dtype, o, (p.dx0_acc ? ld_elem(p.dx0, p.dtype, o) : 0.0f) + g * uf);
+      float t = (p.dx0_acc ? ld_elem(p.dx0, p.dtype, o) : 0.0f) + g * uf;
+      if (fold) t += g + p.diag * gx0;
+      st_elem(p.dx0, p.dtype, o, t);
     }
-    if (p.dxd) st_elem(p.dxd, p.dtype, o, g + p.diag * gx0);
+    if (p.dxd && !fold) st_elem(p.dxd, p.dtype, o, g + p.diag * gx0);
   }
   if (p.dbias) atomicAdd(p.dbias + col, db);
 }

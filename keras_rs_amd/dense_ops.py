@@ -95,15 +95,17 @@ def cross_epilogue_fwd(u, x0, x, diag_scale=0.0):
 
 def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
                        dx0_into: torch.Tensor | None = None,
-                       want_du=True, want_dxd=True, want_dbias=True):
-    """Returns (du, dx0, dxd, dbias); dx0 accumulates into `dx0_into` when given."""
+                       want_du=True, want_dxd=True, want_dbias=True, fold_direct=False):
+    """Returns (du, dx0, dxd, dbias); dx0 accumulates into `dx0_into` when given.
+    fold_direct (the case x is x0): the direct term g + diag*g*x0 is added into dx0 instead of
+    being written to its own buffer (the C ABI's `dxd == dx0` aliasing rule); dxd is then dx0."""
     g, u, x0, x = (_rowmajor(t, "cross_epilogue_bwd").contiguous() for t in (g, u, x0, x))
     m, n = x.shape
     du = torch.empty_like(x) if want_du else None
     dx0 = dx0_into if dx0_into is not None else torch.empty_like(x)
     if not dx0.is_contiguous():
         raise L.KrsError("cross_epilogue_bwd: dx0 buffer must be contiguous")
-    dxd = torch.empty_like(x) if want_dxd else None
+    dxd = dx0 if fold_direct else (torch.empty_like(x) if want_dxd else None)
     dbias = torch.empty(n, dtype=torch.float32, device=x.device) if want_dbias else None
     rc = L.lib().krs_cross_epilogue_bwd(
         L.ptr(g), L.ptr(u), L.ptr(x0), L.ptr(x), L.ptr(du), L.ptr(dx0), C.c_int(int(dx0_into is not None)),

@@ -285,10 +285,13 @@ int krs_oracle_cross_epilogue_bwd(const void* g, const void* u, const void* x0, 
       float uv = u ? ld(u, dtype, o) : 0.0f;
       float dz = gx0 * act_grad_from_output(act, uv);
       if (du) st(du, dtype, o, dz);
-      if (dx0)
-        st(dx0, dtype, o,
-           (dx0_accumulate ? ld(dx0, dtype, o) : 0.0f) + gv * (uv + diag_scale * ld(x, dtype, o)));
-      if (dxd) st(dxd, dtype, o, gv + diag_scale * gx0);
+      int fold = dxd && dxd == dx0; /* x is x0: both terms of dL/dx0 in one buffer */
+      if (dx0) {
+        float t = (dx0_accumulate ? ld(dx0, dtype, o) : 0.0f) + gv * (uv + diag_scale * ld(x, dtype, o));
+        if (fold) t += gv + diag_scale * gx0;
+        st(dx0, dtype, o, t);
+      }
+      if (dxd && !fold) st(dxd, dtype, o, gv + diag_scale * gx0);
       if (dbias) dbias[j] += dz;
     }
   return KRS_OK;

@@ -207,11 +207,11 @@ def cross_epilogue_fwd(u, x0, x, diag_scale=0.0):
     return y
 
 
-def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, dx0_init=None, act=None):
+def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, dx0_init=None, act=None, fold_direct=False):
     m, n = x.shape
     du = np.zeros_like(x)
     dx0 = np.zeros_like(x) if dx0_init is None else dx0_init.copy()
-    dxd = np.zeros_like(x)
+    dxd = dx0 if fold_direct else np.zeros_like(x)
     dbias = np.zeros(n, dtype=np.float32)
     rc = lib().krs_oracle_cross_epilogue_bwd(
         _p(g), _p(u), _p(x0), _p(x), _p(du), _p(dx0), C.c_int(int(dx0_init is not None)),

@@ -122,6 +122,14 @@ def test_cross_elementwise_fwd_bwd(dt, m, n, act):
     np.testing.assert_allclose(to_f32(to_np(dxd)), to_f32(edxd), **tol)
     np.testing.assert_allclose(dbias.cpu().numpy(), edb, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(D.colsum(g).cpu().numpy(), ko.colsum(to_np(g)), rtol=1e-5, atol=1e-5)
+    # x is x0: dxd aliases dx0 and the buffer receives the sum of both terms
+    _, fx0, fxd, _ = D.cross_epilogue_bwd(g, u, x0, x0, 0.25, act=D.ACTS[act], fold_direct=True, want_dbias=False)
+    assert fxd is fx0
+    _, efx0, _, _ = ko.cross_epilogue_bwd(to_np(g), to_np(u), to_np(x0), to_np(x0), 0.25, act=act, fold_direct=True)
+    np.testing.assert_allclose(to_f32(to_np(fx0)), to_f32(efx0), **tol)
+    _, sx0, sxd, _ = ko.cross_epilogue_bwd(to_np(g), to_np(u), to_np(x0), to_np(x0), 0.25, act=act)
+    ftol = dict(rtol=2 ** -6, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(to_f32(efx0), to_f32(sx0) + to_f32(sxd), **ftol)
 
 
 @pytest.mark.parametrize("case", KAT["dot_interaction"]["cases"],
