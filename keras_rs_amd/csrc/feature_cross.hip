@@ -242,21 +242,19 @@ __device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) 
 // dead by now) so that each lane ends up with 8 consecutive columns of one row: x0 / x / R are
 // read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], char* smem, int64_t m0,
-                                              int64_t n0, int split) {
+__device__ __forceinline__ void gemm_epilogue_wave(const GemmParams& p, f32x16 (&acc)[2][2], float* stage, int64_t wm0,
+                                                   int64_t wn0, int split) {
+  // (wm0, wn0): origin of this wave's 64x64 block of C; `stage`: its private 32 x SST floats of LDS.
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
-  // Epilogue.  The accumulators go through LDS (the operand tiles are dead: every wave passed
-  // the loop's last barrier) so that each lane ends up with 8 consecutive columns of one row:
-  // x0 / x / R are then read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
+  // The accumulators go through LDS (the operand tiles are dead: every wave passed the loop's
+  // last barrier) so that each lane ends up with 8 consecutive columns of one row: x0 / x / R are
+  // then read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
   // MFMA C/D layout: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
   constexpr int SST = 68;  // staging row stride in floats (64 + pad)
-  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SST);  // 32 rows x 64 cols per wave
   const int ec = (lane & 7) * 8;
-  const int64_t gn = n0 + wn * 64 + ec;
+  const int64_t gn = wn0 + ec;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {  // the wave's upper / lower 32 rows
     // operands of the specialised epilogues: in flight while the accumulators are staged
@@ -264,7 +262,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     if constexpr (EPI == 1 || EPI == 2) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int64_t gmc = min(m0 + wm * 64 + i * 32 + it * 8 + (lane >> 3), p.m - 1);
+        const int64_t gmc = min(wm0 + i * 32 + it * 8 + (lane >> 3), p.m - 1);
         const int64_t gnc = min(gn, p.n - 8);
         if constexpr (EPI == 1) {
           ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x) + gmc * p.ep.ldx + gnc);
@@ -283,7 +281,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int er = it * 8 + (lane >> 3);
-      const int64_t gm = m0 + wm * 64 + i * 32 + er;
+      const int64_t gm = wm0 + i * 32 + er;
       if (gm >= p.m || gn >= p.n) continue;
       float v[8];
       const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
@@ -329,6 +327,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
+}
+
+// 128x128 workgroup tile, 4 waves as 2x2
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], char* smem, int64_t m0,
+                                              int64_t n0, int split) {
+  const int wave = threadIdx.x >> 6;
+  gemm_epilogue_wave<EPI>(p, acc, reinterpret_cast<float*>(smem) + wave * (32 * 68), m0 + (wave >> 1) * 64,
+                          n0 + (wave & 1) * 64, split);
 }
 
 // EPI: 0 = general epilogue, 1 = cross (bf16, vector access), 2 = residual add (bf16, vector access).
@@ -536,6 +543,119 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
   gemm_epilogue<EPI>(p, acc, smem, m0, n0, 0);
 }
 
+// Long-K forward / data-gradient shapes with M, N >= 256: the same LDS-DMA pipeline on a 256x256
+// workgroup tile (8 waves as 2(M) x 4(N), 128x64 per wave = 4x2 MFMA fragments, 128 accumulator
+// registers).  A 128x128 tile at full MFMA rate would need 64 B/clk/CU from L2 -- the whole L1
+// fill path -- and measures ~30 % MFMA utilisation; the 256x256 tile halves the operand bytes per
+// flop (and the LDS reads per MFMA drop from 1 to 3/4).  One workgroup per CU: two 64 KB stages.
+template <int ES, int EPI>
+__global__ __launch_bounds__(512) void gemm_glds256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = 256, TN = 256;
+  constexpr int BK = ROW_BYTES / ES;
+  constexpr int OPA_BYTES = TM * ROW_BYTES;   // 32 KB
+  constexpr int STAGE_BYTES = (TM + TN) * ROW_BYTES;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  // the N tiles of one M panel run back to back on one XCD (workgroup id % 8), sharing A in its L2
+  const int64_t nt = (p.n + TN - 1) / TN;
+  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int64_t m_tile = (slot / nt) * 8 + xcd;
+  if (m_tile * TM >= p.m) return;
+  const int64_t m0 = m_tile * TM;
+  const int64_t n0 = (slot % nt) * TN;
+  const int64_t ntiles = p.k / BK;
+
+  // per-lane source rows / chunks of the 4 DMA pieces (8 rows x 128 B each) this wave issues per
+  // operand and tile; source-side XOR swizzle as in gemm_glds_kernel
+  const char* asrc[4];
+  const char* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int64_t ar = min(m0 + r, p.m - 1);
+    const int64_t br = min(n0 + r, p.n - 1);
+    asrc[i] = p.a + (ar * p.lda) * ES + c * 16;
+    bsrc[i] = p.b + (br * p.ldb) * ES + c * 16;
+  }
+  auto issue = [&](int64_t t, int stage) {
+    char* sa = smem + stage * STAGE_BYTES + (wave * 4) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr)(asrc[i] + t * ROW_BYTES), (lptr)(sa + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(bsrc[i] + t * ROW_BYTES), (lptr)(sa + OPA_BYTES + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2][2];  // [upper / lower 64 rows][m fragment][n fragment]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
+
+  if (ntiles > 0) issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frow = lane & 31;
+  const int fhalf = lane >> 5;
+  int aoff[4], boff[2], akey[4], bkey[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 128 + i * 32 + frow;
+    aoff[i] = ra * ROW_BYTES; akey[i] = (ra >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rb = wn * 64 + j * 32 + frow;
+    boff[j] = OPA_BYTES + rb * ROW_BYTES; bkey[j] = (rb >> 1) & 7;
+  }
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
+    const char* st = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < ROW_BYTES / 32; ++ks) {
+      const int c = ks * 2 + fhalf;
+      u32x4 fa[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(st + boff[j] + ((c ^ bkey[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + aoff[i] + ((c ^ akey[i]) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16& d = acc[i >> 1][i & 1][j];
+          if constexpr (ES == 2) {
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                       __builtin_bit_cast(bf16x8, fb[j]), d, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              d = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i][q]), __uint_as_float(fb[j][q]), d, 0, 0, 0);
+          }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
+    __syncthreads();                                   // and every wave is done with tile t
+  }
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  // two explicit calls: a loop over `h` is left rolled for the large general epilogue and would
+  // index the accumulators dynamically
+  gemm_epilogue_wave<EPI>(p, acc[0], stage, m0 + wm * 128, n0 + wn * 64, 0);
+  gemm_epilogue_wave<EPI>(p, acc[1], stage, m0 + wm * 128 + 64, n0 + wn * 64, 0);
+}
+
 // fixed-order reduction of the split-K slabs + epilogue
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const GemmParams p) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -613,6 +733,27 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   // (K = 512: eight tiles, then a heavy epilogue) run better on the register-staged kernel, whose
   // 36 KB of LDS lets three workgroups share a CU and hide each other's epilogues.
   const bool use_glds = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0 && p.k >= 1024;
+  if (use_glds && p.m >= 256 && p.n >= 256) {
+    const size_t lds256 = 2 * 512 * ROW_BYTES;  // 2 stages x (256 A rows + 256 B rows) x 128 B
+    const dim3 grid256((unsigned)(ceil_div(ceil_div(p.m, 256), 8) * 8 * ceil_div(p.n, 256)));
+#define KRS_GLDS256_LAUNCH(EP)                                                                       \
+  {                                                                                                  \
+    auto kern = gemm_glds256_kernel<ES, EP>;                                                         \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) {                                                                                 \
+      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));         \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    hipLaunchKernelGGL(kern, grid256, dim3(512), lds256, st, p);                                     \
+  }
+    if (epi == 1) KRS_GLDS256_LAUNCH(1)
+    else if (epi == 2) KRS_GLDS256_LAUNCH(2)
+    else KRS_GLDS256_LAUNCH(0)
+#undef KRS_GLDS256_LAUNCH
+    KRS_CHECK_LAUNCH("gemm_glds256_kernel");
+    return KRS_OK;
+  }
   if (use_glds) {
     const size_t glds_lds = 4 * BM * ROW_BYTES;  // 2 stages x (A + B) x 16 KB
 #define KRS_GLDS_LAUNCH(EP)                                                                          \

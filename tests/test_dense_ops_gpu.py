@@ -28,7 +28,8 @@ def _tol(dt, k):
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 3, 3), (5, 7, 9), (128, 128, 64), (130, 200, 72), (256, 512, 512),
-                                   (300, 136, 1000), (64, 3456, 512), (130, 200, 1088), (257, 512, 3456)])
+                                   (300, 136, 1000), (64, 3456, 512), (130, 200, 1088), (257, 512, 3456),
+                                   (700, 300, 1024), (512, 768, 2048)])  # the last three: 256x256-tile kernel
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
 def test_gemm_layouts(m, n, k, dt, layout):
@@ -46,7 +47,7 @@ def test_gemm_layouts(m, n, k, dt, layout):
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", [None, "relu", "sigmoid", "tanh"])
-@pytest.mark.parametrize("m,d,p", [(64, 128, 128), (200, 256, 64), (33, 24, 24), (200, 256, 1024)])
+@pytest.mark.parametrize("m,d,p", [(64, 128, 128), (200, 256, 64), (33, 24, 24), (200, 256, 1024), (300, 520, 1024)])
 def test_gemm_cross_epilogue(dt, act, m, d, p):
     from keras_rs_amd import dense_ops as D
 
@@ -82,6 +83,13 @@ def test_gemm_residual_and_fp32_out_from_bf16_and_splitk():
     r = _t(rng.uniform(-1, 1, (96, 40)))
     c, _ = D.gemm(a, b, r=r, beta=0.5)
     np.testing.assert_allclose(c.cpu().numpy(), (a @ b + 0.5 * r).cpu().numpy(), rtol=2e-5, atol=2e-5)
+    # the same through the 256x256-tile kernel (bf16, K-contiguous operands, vector residual epilogue)
+    a = _t(rng.uniform(-1, 1, (520, 1024)), torch.bfloat16)
+    bt = _t(rng.uniform(-1, 1, (264, 1024)), torch.bfloat16)
+    r = _t(rng.uniform(-1, 1, (520, 264)), torch.bfloat16)
+    c, _ = D.gemm(a, bt, b_is_nk=True, r=r, beta=1.0)
+    exp = a.float() @ bt.float().t() + r.float()
+    np.testing.assert_allclose(c.float().cpu().numpy(), exp.cpu().numpy(), rtol=2 ** -6, atol=0.1)
 
 
 @pytest.mark.parametrize("case", KAT["feature_cross"]["cases"], ids=lambda c: c["name"])
