@@ -86,6 +86,7 @@ class Model(torch.nn.Module):
         from keras_rs_amd.layers import base
 
         self.a, self.hots = a, hots
+        self.concat = kl.concat_features
         opt = kl.Adagrad(learning_rate=0.0034, initial_accumulator_value=0.1)  # configs/v6e_8.py lr
         feats = {}
         for t in range(a.tables):
@@ -99,7 +100,10 @@ class Model(torch.nn.Module):
 
             self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16")
         else:
-            self.embedding = kl.DistributedEmbedding(feats, dtype="bfloat16", name="embedding_layer")
+            # the dense feature's 128 columns are reserved in front of the 26 embeddings: the lookups land
+            # directly in the [B, 3456] interaction input (concat-free layout)
+            self.embedding = kl.DistributedEmbedding(feats, dtype="bfloat16", name="embedding_layer",
+                                                     slab_lead_cols=a.dim)
         self.dot = kl.DotInteraction(dtype="bfloat16")
         self.cross = torch.nn.ModuleList(
             kl.FeatureCross(projection_dim=a.projection, kernel_initializer=base.GlorotUniform(seed=1337 + i),
@@ -109,7 +113,7 @@ class Model(torch.nn.Module):
         emb = self.embedding(pre)
         feats = [dense_out] + [emb[k] for k in emb]
         inter = self.dot(feats)                                   # [B, 351]
-        x0 = torch.cat(feats, dim=-1)                             # [B, 3456]  (model.py:204-207)
+        x0 = self.concat(feats)                                   # [B, 3456]  (model.py:204-207)
         xl = x0
         for layer in self.cross:                                  # DCNBlock.call, model.py:332-336
             xl = layer(x0, xl)

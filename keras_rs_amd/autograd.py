@@ -22,9 +22,19 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
-def _split_columns(out: torch.Tensor, n: int, dim: int):
-    """Per-feature [B, dim] column views of the fused [B, n*dim] lookup output."""
-    return tuple(out[:, i * dim:(i + 1) * dim] for i in range(n))
+def _split_columns(out: torch.Tensor, n: int, dim: int, lead: int = 0):
+    """Per-feature [B, dim] column views of the fused [B, lead + n*dim] lookup output."""
+    return tuple(out[:, lead + i * dim:lead + (i + 1) * dim] for i in range(n))
+
+
+def _sum_slab_and_feature_grads(g_slab, gs, lead, batch, n, dim, dtype, device):
+    """Gradient of the fused lookup output [B, n*dim] from the gradient of the slab (its columns
+    lead..) and of the per-feature views; either side may be absent."""
+    gv = _gather_feature_grads(gs, batch, dim, dtype, device) if any(g is not None for g in gs) else None
+    if g_slab is None:
+        return gv if gv is not None else torch.zeros((batch, n * dim), dtype=dtype, device=device)
+    g_s = g_slab[:, lead:lead + n * dim]
+    return g_s if gv is None else g_s + gv
 
 
 def _gather_feature_grads(grads, batch: int, dim: int, dtype, device):
@@ -176,10 +186,14 @@ class EmbedBagFusedFn(torch.autograd.Function):
     backward runs; it receives a zero gradient."""
 
     @staticmethod
-    def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, optimizer, anchor):
+    def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, optimizer, anchor, lead=0):
+        # outputs: the whole slab [B, lead + n*dim] (columns 0..lead are left for the caller, see
+        # layers.concat_features) followed by the per-feature column views
+        n = len(bags.features)
+        slab = torch.empty((batch, lead + n * bags.dim), dtype=out_dtype or bags.dtype, device=ids.device)
         out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
-                                  out_dtype=out_dtype, want_scale=True)
-        ctx.bags, ctx.batch, ctx.hots, ctx.optimizer = bags, batch, hots, optimizer
+                                  out=slab[:, lead:], want_scale=True)
+        ctx.bags, ctx.batch, ctx.hots, ctx.optimizer, ctx.lead = bags, batch, hots, optimizer, lead
         ctx.save_for_backward(ids, offsets, weights, scale)
         ctx.out_meta = (out.dtype, out.device)
         # The backward's plan (sort of the lookups by row) depends only on the ids: start it now on
@@ -197,13 +211,14 @@ class EmbedBagFusedFn(torch.autograd.Function):
                 if t is not None:
                     t.record_stream(side)
             ctx.plan = (ws, done)
-        return _split_columns(out, len(bags.features), bags.dim)
+        return (slab,) + _split_columns(slab, n, bags.dim, lead)
 
     @staticmethod
-    def backward(ctx, *gs):
+    def backward(ctx, g_slab, *gs):
         ids, offsets, weights, scale = ctx.saved_tensors
         bags = ctx.bags
-        g = _gather_feature_grads(gs, ctx.batch, bags.dim, *ctx.out_meta)
+        g = _sum_slab_and_feature_grads(g_slab, gs, ctx.lead, ctx.batch, len(bags.features), bags.dim,
+                                        *ctx.out_meta)
         if ctx.plan is not None:
             ws, done = ctx.plan
             torch.cuda.current_stream().wait_event(done)
@@ -212,4 +227,26 @@ class EmbedBagFusedFn(torch.autograd.Function):
             ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
         bags.backward_fused(ctx.optimizer, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                             bag_scale=scale)
-        return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device))
+        return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device), None)
+
+
+class SlabFillFn(torch.autograd.Function):
+    """concat([*heads, slab[:, lead:]]) without the copy of the slab: the heads (lead columns in
+    total) are written into the slab's reserved leading columns and the slab itself is the result.
+    The write goes through `.data`, so tensors that saved views of the slab keep their version."""
+
+    @staticmethod
+    def forward(ctx, slab, *heads):
+        col = 0
+        ctx.cols = []
+        with torch.no_grad():
+            for h in heads:
+                w = h.shape[1]
+                slab.data[:, col:col + w].copy_(h)
+                ctx.cols.append((col, col + w))
+                col += w
+        return slab.data.as_strided(slab.shape, slab.stride(), slab.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + tuple(g[:, a:b] for a, b in ctx.cols)

@@ -153,7 +153,10 @@ def dot_interaction_bwd(feats: Sequence[torch.Tensor], grad_out: torch.Tensor, s
     feats = [_rowmajor(f, "dot_interaction feature") for f in feats]
     grad_out = _rowmajor(grad_out, "dot_interaction grad")
     batch, dim = feats[0].shape
-    grads = [torch.empty((batch, dim), dtype=f.dtype, device=f.device) for f in feats]
+    # one buffer, per-feature column views: a consumer that wants the gradients side by side
+    # (the embedding backward) can take the buffer as it is
+    gbuf = torch.empty((batch, len(feats) * dim), dtype=feats[0].dtype, device=feats[0].device)
+    grads = [gbuf[:, i * dim:(i + 1) * dim] for i in range(len(feats))]
     ptrs, lds = _ptr_table(feats)
     gptrs, glds = _ptr_table(grads)
     rc = L.lib().krs_dot_interaction_bwd(ptrs, lds, C.c_int(len(feats)), C.c_int64(batch), C.c_int(dim),

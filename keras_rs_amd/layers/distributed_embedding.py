@@ -112,10 +112,19 @@ class _Group:
 
 class DistributedEmbedding(base.Layer):
     """Args (base_distributed_embedding.py:468-477): feature_configs (nested structure of
-    FeatureConfig), table_stacking ("auto" | names), update_stats, **kwargs."""
+    FeatureConfig), table_stacking ("auto" | names), update_stats, **kwargs.
 
-    def __init__(self, feature_configs, *, table_stacking="auto", update_stats: bool = False, **kwargs: Any):
+    Not in the reference: slab_lead_cols.  The fused-optimizer ("sparsecore") lookups of one
+    embedding width land in ONE [B, n*dim] buffer whose column blocks are the returned features;
+    slab_lead_cols reserves that many extra leading columns in it, so that
+    layers.concat_features([dense, *embeddings]) (the DLRM / DCN interaction input,
+    examples/ml_perf/model.py:204-207) can place `dense` there and return the buffer itself
+    instead of copying every embedding."""
+
+    def __init__(self, feature_configs, *, table_stacking="auto", update_stats: bool = False,
+                 slab_lead_cols: int = 0, **kwargs: Any):
         super().__init__(**kwargs)
+        self.slab_lead_cols = int(slab_lead_cols)
         self._table_stacking = table_stacking
         self.update_stats = update_stats
         self._lock = threading.Lock()
@@ -314,8 +323,11 @@ class DistributedEmbedding(base.Layer):
             w = None if weights is None else weights[key]
             out_dtype = self.compute_dtype
             if placement == "sparsecore":
-                out = EmbedBagFusedFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w, out_dtype,
-                                            g.fused_kind, self._anchor)
+                lead = self.slab_lead_cols if len(self._groups[placement]) == 1 else 0
+                slab, *out = EmbedBagFusedFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w,
+                                                   out_dtype, g.fused_kind, self._anchor, lead)
+                for i, o in enumerate(out):  # lets layers.concat_features find the slab (zero-copy concat)
+                    o._krs_slab = (slab, lead + i * g.dim, len(out), lead)
             else:
                 out = EmbedBagFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w, out_dtype,
                                        False, *g.bags.tables)
@@ -457,6 +469,8 @@ class DistributedEmbedding(base.Layer):
                                                              is_leaf=_is_feature_config)
         config["tables"] = table_dicts
         config["table_stacking"] = self._table_stacking
+        if self.slab_lead_cols:
+            config["slab_lead_cols"] = self.slab_lead_cols
         return config
 
     @classmethod
@@ -507,6 +521,35 @@ class DistributedEmbedding(base.Layer):
 
 
 # ---------------------------------------------------------------------- helpers
+def concat_features(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    """torch.cat(tensors, dim=-1) for the interaction input of a DLRM / DCN model
+    (examples/ml_perf/model.py:204-207 concatenates the bottom-MLP output and every embedding).
+
+    When the trailing tensors are ALL the features of one DistributedEmbedding slab, in order, the
+    slab is used in place: with `slab_lead_cols` equal to the total width of the tensors in front of
+    them, those are written into the reserved columns and the slab itself is returned (no copy of
+    the embeddings, and their gradient arrives as one matrix); otherwise the result is a two-piece
+    concat of [heads..., slab].  Anything else falls back to torch.cat."""
+    from keras_rs_amd.autograd import SlabFillFn
+
+    tensors = list(tensors)
+    info = [getattr(t, "_krs_slab", None) for t in tensors]
+    start = len(tensors)
+    while start > 0 and info[start - 1] is not None and info[start - 1][0] is info[-1][0]:
+        start -= 1
+    run = info[start:]
+    if run:
+        slab, _, n_views, lead = run[0]
+        dim = (slab.shape[1] - lead) // n_views
+        ordered = len(run) == n_views and all(r[1] == lead + i * dim for i, r in enumerate(run))
+        heads = tensors[:start]
+        if ordered and all(h.dim() == 2 and h.shape[0] == slab.shape[0] and h.dtype == slab.dtype for h in heads):
+            if sum(h.shape[1] for h in heads) == lead:
+                return SlabFillFn.apply(slab, *heads) if heads else slab
+            return torch.cat(heads + [slab[:, lead:]], dim=-1)
+    return torch.cat(tensors, dim=-1)
+
+
 def _to_numpy(x):
     if isinstance(x, torch.Tensor):
         return x.detach().cpu().numpy()

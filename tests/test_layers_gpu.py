@@ -271,6 +271,45 @@ def test_distributed_embedding_training_step_matches_formula(placement, optimize
                                rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("lead", [0, 8, 4])
+def test_concat_features_uses_the_slab_and_trains_like_torch_cat(lead):
+    # SURVEY.md section 8f.3 (concat-free layout): concat_features([dense, *embeddings]) == torch.cat,
+    # forward values, gradient of `dense`, and the fused table update, for lead == width of the dense
+    # head (slab returned in place), lead == 0 (two-piece concat) and a mismatching lead (same)
+    kl = _layers()
+    rng = np.random.default_rng(5)
+    ids = {k: rng.integers(0, 40, (12, h)).astype(np.int32) for k, h in (("a", 3), ("b", 1), ("c", 2))}
+    w_dot = torch.rand(12, 6, device=DEV)
+
+    def run(use_helper):
+        tabs = [kl.TableConfig(f"t{k}", 40, 8, placement="sparsecore", optimizer=kl.SGD(0.5), combiner="sum",
+                               initializer=kl_base.RandomUniform(-1, 1, seed=3 + i)) for i, k in enumerate("abc")]
+        layer = kl.DistributedEmbedding({k: kl.FeatureConfig(k, t, ids[k].shape, (12, 8)) for k, t in zip("abc", tabs)},
+                                        slab_lead_cols=lead if use_helper else 0)
+        dense = torch.linspace(-1, 1, 12 * 8, device=DEV).reshape(12, 8).requires_grad_(True)
+        emb = layer(ids)
+        feats = [dense] + [emb[k] for k in "abc"]
+        inter = kl.DotInteraction()(feats)
+        x0 = kl.concat_features(feats) if use_helper else torch.cat(feats, dim=-1)
+        if use_helper and lead == 8:
+            assert x0.data_ptr() == emb["a"]._krs_slab[0].data_ptr()  # the slab itself, nothing copied
+        y = kl.FeatureCross(kernel_initializer=kl_base.GlorotUniform(seed=1))(x0, x0)
+        ((y * y).sum() + (inter * w_dot).sum()).backward()
+        return x0.detach().clone(), dense.grad.clone(), layer.get_embedding_tables()
+
+    from keras_rs_amd.layers import base as kl_base
+
+    x_a, gd_a, t_a = run(True)
+    x_b, gd_b, t_b = run(False)
+    assert torch.equal(x_a, x_b)
+    np.testing.assert_allclose(gd_a.cpu().numpy(), gd_b.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for k in t_a:
+        np.testing.assert_allclose(t_a[k].cpu().numpy(), t_b[k].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # anything that is not "all features of one slab, in order, at the end" is a plain concat
+    plain = [torch.ones(2, 3, device=DEV), torch.zeros(2, 2, device=DEV)]
+    assert torch.equal(kl.concat_features(plain), torch.cat(plain, dim=-1))
+
+
 def test_set_embedding_tables_and_mixed_width_groups():
     kl = _layers()
     t1 = kl.TableConfig("t1", 30, 8, placement="default_device", combiner="sum")

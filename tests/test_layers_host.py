@@ -156,3 +156,10 @@ def test_initializers_and_policy():
     assert torch.equal(a, base.VarianceScaling(seed=3)((8, 8)))
     pol = base.DTypePolicy("mixed_bfloat16")
     assert pol.compute_dtype == torch.bfloat16 and pol.variable_dtype == torch.float32
+
+
+def test_concat_features_is_torch_cat_without_a_slab():
+    import keras_rs_amd.layers as kl
+
+    parts = [torch.arange(6.0).reshape(2, 3), torch.ones(2, 2), torch.zeros(2, 1)]
+    assert torch.equal(kl.concat_features(parts), torch.cat(parts, dim=-1))
