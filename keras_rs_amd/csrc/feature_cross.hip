@@ -656,6 +656,228 @@ __global__ __launch_bounds__(512) void gemm_glds256_kernel(const GemmParams p) {
   gemm_epilogue_wave<EPI>(p, acc[1], stage, m0 + wm * 128 + 64, n0 + wn * 64, 0);
 }
 
+// Weight-gradient shapes in bf16 (C = A^T B with BOTH operands K-strided in HBM: activations
+// contracted over the batch).  The operand tiles go to LDS by DMA exactly as they lie in memory --
+// rows of K, 16-byte chunks of 8 columns -- and the MFMA fragments (8 consecutive K per lane) are
+// read with gfx950's transposing ds_read_b64_tr_b16: no staging registers, no in-register
+// transposes, no ds_write traffic (the register-staged path spends half its LDS cycles on the
+// bank conflicts of its transposed writes).
+// LDS image of one operand tile (64 k x 128 columns): 16 blocks of 1 KB, block kb = 4 k-rows;
+// inside a block the 64-byte unit (cq, kr) (32-column quarter cq, k-row kr) sits at (cq*4 + kr)*64,
+// which is the lane-linear order of one DMA instruction whose lanes 4u..4u+3 fetch the 64
+// contiguous bytes of unit u (so the memory side still sees whole 64-byte quads).
+// A transposing read hands lane i of a 16-lane group column i of the 4 x 16 matrix whose row r is
+// the 4 x 8 bytes addressed by lanes 4r..4r+3: a 32-lane half addresses the four k-rows of one
+// 32-column quarter, i.e. 256 contiguous bytes -- every bank once.  Two reads (blocks kb, kb+1)
+// give a lane its 8 k-values.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmParams p, int mt, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = 64;
+  constexpr int OP_BYTES = BK * 128 * 2;     // 16 KB
+  constexpr int STAGE_BYTES = 2 * OP_BYTES;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* trptr;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // One K split = one XCD at a time (workgroup id % 8 picks the XCD): all mt*nt tiles of a split walk
+  // the same K rows together, so a row of A / B is consumed whole (by the tiles side by side) while
+  // its DRAM page and TLB entry are hot, and the operand tiles are shared through that XCD's L2.
+  const int64_t tiles = (int64_t)mt * nt;
+  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = (int)((slot / tiles) * 8 + xcd);
+  if (split >= p.splits) return;
+  const int64_t tile = slot % tiles;
+  const int64_t m0 = (tile % mt) * BM;
+  const int64_t n0 = (tile / mt) * BN;
+  const int64_t kbeg = (int64_t)split * p.k_per_split;
+  const int64_t kend = min(p.k, kbeg + p.k_per_split);
+  const int64_t ntiles = (kend - kbeg) / BK;   // K extents are multiples of 64 (checked on the host)
+
+  // DMA: this wave fills blocks kb = wave*4 + j of each operand; lane = (quarter*4 + k-row)*4 + chunk
+  const int dkr = (lane >> 2) & 3, dcol = (lane >> 4) * 32 + (lane & 3) * 8;
+  const int64_t acol = min(m0 + dcol, p.m - 8);   // clamped: surplus columns are never stored
+  const int64_t bcol = min(n0 + dcol, p.n - 8);
+  const char* asrc = p.a + ((kbeg + wave * 16 + dkr) * p.lda + acol) * 2;
+  const char* bsrc = p.b + ((kbeg + wave * 16 + dkr) * p.ldb + bcol) * 2;
+  const int64_t astep = p.lda * 8, bstep = p.ldb * 8;   // 4 k-rows, in bytes
+  auto issue = [&](int64_t t, int stage) {
+    char* sa = smem + stage * STAGE_BYTES + (wave * 4) * 1024;
+    const char* at = asrc + t * BK * p.lda * 2;
+    const char* bt = bsrc + t * BK * p.ldb * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr)(at + j * astep), (lptr)(sa + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(bt + j * bstep), (lptr)(sa + OP_BYTES + j * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (ntiles > 0) issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // transposing-read addresses: group g = lane >> 4 (columns (g & 1) * 16 .., k half g >> 1),
+  // lane-in-group ii: k-row ii >> 2, 4-column quad ii & 3
+  const int g = lane >> 4, ii = lane & 15;
+  const int lane_off = (ii >> 2) * 64 + (g & 1) * 32 + (ii & 3) * 8 + (g >> 1) * 2048;
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // a fragment's 32 columns are one quarter of the tile
+    aoff[i] = (wm * 2 + i) * 256 + lane_off;
+    boff[i] = OP_BYTES + (wn * 2 + i) * 256 + lane_off;
+  }
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
+    char* st = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + aoff[i] + ks * 4096));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + aoff[i] + ks * 4096 + 1024));
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + boff[i] + ks * 4096));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + boff[i] + ks * 4096 + 1024));
+        const uint2 ua0 = __builtin_bit_cast(uint2, a0), ua1 = __builtin_bit_cast(uint2, a1);
+        const uint2 ub0 = __builtin_bit_cast(uint2, b0), ub1 = __builtin_bit_cast(uint2, b1);
+        fa[i] = u32x4{ua0.x, ua0.y, ua1.x, ua1.y};
+        fb[i] = u32x4{ub0.x, ub0.y, ub1.x, ub1.y};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                              __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
+    __syncthreads();                                   // and every wave is done with tile t
+  }
+  gemm_epilogue<EPI>(p, acc, smem, m0, n0, split);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p, int mt, int nt) {
+  // 256 x 256 tile, 8 waves as 2(M) x 4(N); each operand tile is two 128-column halves with the 128-column image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BK = 64;
+  constexpr int TM = 256, TN = 256;
+  constexpr int HALF_BYTES = BK * 128 * 2;   // 16 KB
+  constexpr int OP_BYTES = 2 * HALF_BYTES;   // 32 KB
+  constexpr int STAGE_BYTES = 2 * OP_BYTES;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* trptr;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  // One K split = one XCD at a time (workgroup id % 8 picks the XCD): all mt*nt tiles of a split walk
+  // the same K rows together, so a row of A / B is consumed whole (by the tiles side by side) while
+  // its DRAM page and TLB entry are hot, and the operand tiles are shared through that XCD's L2.
+  const int64_t tiles = (int64_t)mt * nt;
+  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = (int)((slot / tiles) * 8 + xcd);
+  if (split >= p.splits) return;
+  const int64_t tile = slot % tiles;
+  const int64_t m0 = (tile % mt) * TM;
+  const int64_t n0 = (tile / mt) * TN;
+  const int64_t kbeg = (int64_t)split * p.k_per_split;
+  const int64_t kend = min(p.k, kbeg + p.k_per_split);
+  const int64_t ntiles = (kend - kbeg) / BK;   // K extents are multiples of 64 (checked on the host)
+
+  // DMA: this wave fills blocks kb = (wave & 3)*4 + j of half wave >> 2 of each operand;
+  // lane = (quarter*4 + k-row)*4 + chunk
+  const int dkr = (lane >> 2) & 3, dcol = (wave >> 2) * 128 + (lane >> 4) * 32 + (lane & 3) * 8;
+  const int64_t acol = min(m0 + dcol, p.m - 8);   // clamped: surplus columns are never stored
+  const int64_t bcol = min(n0 + dcol, p.n - 8);
+  const char* asrc = p.a + ((kbeg + (wave & 3) * 16 + dkr) * p.lda + acol) * 2;
+  const char* bsrc = p.b + ((kbeg + (wave & 3) * 16 + dkr) * p.ldb + bcol) * 2;
+  const int64_t astep = p.lda * 8, bstep = p.ldb * 8;   // 4 k-rows, in bytes
+  auto issue = [&](int64_t t, int stage) {
+    char* sa = smem + stage * STAGE_BYTES + (wave >> 2) * HALF_BYTES + ((wave & 3) * 4) * 1024;
+    const char* at = asrc + t * BK * p.lda * 2;
+    const char* bt = bsrc + t * BK * p.ldb * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr)(at + j * astep), (lptr)(sa + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(bt + j * bstep), (lptr)(sa + OP_BYTES + j * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2][2];  // [upper / lower 64 rows][m fragment][n fragment]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
+
+  if (ntiles > 0) issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // transposing-read addresses: group g = lane >> 4 (columns (g & 1) * 16 .., k half g >> 1),
+  // lane-in-group ii: k-row ii >> 2, 4-column quad ii & 3
+  const int g = lane >> 4, ii = lane & 15;
+  const int lane_off = (ii >> 2) * 64 + (g & 1) * 32 + (ii & 3) * 8 + (g >> 1) * 2048;
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) aoff[i] = wm * HALF_BYTES + i * 256 + lane_off;  // a fragment = one 32-column quarter
+#pragma unroll
+  for (int j = 0; j < 2; ++j) boff[j] = OP_BYTES + (wn >> 1) * HALF_BYTES + ((wn & 1) * 2 + j) * 256 + lane_off;
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const int cur = (int)(t & 1);
+    if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
+    char* st = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      u32x4 fa[4], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint2 b0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + boff[j] + ks * 4096)));
+        const uint2 b1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + boff[j] + ks * 4096 + 1024)));
+        fb[j] = u32x4{b0.x, b0.y, b1.x, b1.y};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint2 a0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + aoff[i] + ks * 4096)));
+        const uint2 a1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + aoff[i] + ks * 4096 + 1024)));
+        fa[i] = u32x4{a0.x, a0.y, a1.x, a1.y};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16& d = acc[i >> 1][i & 1][j];
+          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                     d, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
+    __syncthreads();                                   // and every wave is done with tile t
+  }
+  float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  gemm_epilogue_wave<EPI>(p, acc[0], stage_f, m0 + wm * 128, n0 + wn * 64, split);
+  gemm_epilogue_wave<EPI>(p, acc[1], stage_f, m0 + wm * 128 + 64, n0 + wn * 64, split);
+}
+
 // fixed-order reduction of the split-K slabs + epilogue
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const GemmParams p) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -686,6 +908,8 @@ int pick_splits(int64_t m, int64_t n, int64_t k) {
   const int64_t max_s = k / 1024;          // keep >= 1024 of K per split
   if (s > max_s) s = max_s;
   if (s > 64) s = 64;
+  if (s > 8) s = (s + 7) / 8 * 8;          // whole rounds over the 8 XCDs (gemm_tn_glds_kernel deals splits to XCDs)
+  if (s > max_s) s = max_s / 8 * 8;
   return s < 1 ? 1 : (int)s;
 }
 
@@ -772,6 +996,38 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     else KRS_GLDS_LAUNCH(0)
 #undef KRS_GLDS_LAUNCH
     KRS_CHECK_LAUNCH("gemm_glds_kernel");
+    return KRS_OK;
+  }
+  // bf16 weight gradients: LDS-DMA + transposing reads (K extents in whole 64-row tiles, >= 8 columns)
+  if (ES == 2 && p.a_km && !p.b_nk && p.k % 64 == 0 && p.k_per_split % 64 == 0 && p.m >= 8 && p.n >= 8 &&
+      p.m % 8 == 0 && p.n % 8 == 0) {
+    if (p.m >= 256 && p.n >= 256) {
+      const int mt_ = (int)ceil_div(p.m, 256), nt_ = (int)ceil_div(p.n, 256);
+      const dim3 grid_tn((unsigned)(ceil_div(p.splits, 8) * 8 * mt_ * nt_));
+      const size_t lds_tn = 2 * 2 * 64 * 256 * 2;  // 2 stages x (A + B) x 32 KB
+      auto kern = gemm_tn_glds256_kernel<0>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_tn));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, grid_tn, dim3(512), lds_tn, st, p, mt_, nt_);
+      KRS_CHECK_LAUNCH("gemm_tn_glds256_kernel");
+      return KRS_OK;
+    }
+    const int mt_ = (int)ceil_div(p.m, BM), nt_ = (int)ceil_div(p.n, BN);
+    const dim3 grid_tn((unsigned)(ceil_div(p.splits, 8) * 8 * mt_ * nt_));
+    const size_t lds_tn = 4 * 64 * 128 * 2;  // 2 stages x (A + B) x 16 KB
+    auto kern = gemm_tn_glds_kernel<0>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_tn));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid_tn, dim3(256), lds_tn, st, p, mt_, nt_);
+    KRS_CHECK_LAUNCH("gemm_tn_glds_kernel");
     return KRS_OK;
   }
   if (p.a_km) KRS_GEMM_CASE(true, false)
