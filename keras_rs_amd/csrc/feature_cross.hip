@@ -956,8 +956,9 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   // Long contractions: the LDS-DMA pipeline (no staging registers, no ds_write traffic).  Short ones
   // (K = 512: eight tiles, then a heavy epilogue) run better on the register-staged kernel, whose
   // 36 KB of LDS lets three workgroups share a CU and hide each other's epilogues.
-  const bool use_glds = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0 && p.k >= 1024;
-  if (use_glds && p.m >= 256 && p.n >= 256) {
+  const bool dma_ok = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0;
+  const bool use_glds = dma_ok && p.k >= 1024;
+  if (dma_ok && p.k >= 256 && p.m >= 256 && p.n >= 256) {
     const size_t lds256 = 2 * 512 * ROW_BYTES;  // 2 stages x (256 A rows + 256 B rows) x 128 B
     const dim3 grid256((unsigned)(ceil_div(ceil_div(p.m, 256), 8) * 8 * ceil_div(p.n, 256)));
 #define KRS_GLDS256_LAUNCH(EP)                                                                       \

@@ -54,3 +54,8 @@ for name, fn, fl, by in cases:
     tot += us
     print(f"{name:42s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s  {by / us / 1e3:7.1f} GB/s (min HBM bytes)")
 print(f"layer fwd+bwd total {tot:.1f} us")
+# the K = 512 product without its epilogue traffic (plain bf16 store): what the epilogues cost
+us = t(lambda: D.gemm(h, Vt, b_is_nk=True))
+print(f"{'      y = h V      plain (K=512,N=3456)':42s} {us:8.1f} us  {F / us / 1e6:7.1f} TF/s")
+us = t(lambda: D.cross_epilogue_fwd(u, x0, x, 0.0))
+print(f"{'      cross epilogue alone (4 x [B,d])':42s} {us:8.1f} us  {4 * B * d * 2 / us / 1e3:7.1f} GB/s")
