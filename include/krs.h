@@ -175,6 +175,37 @@ int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_tables,
                                     int batch, int dim, int table_dtype, int64_t nnz,
                                     const void* workspace, void* stream);
 
+/* Fused Adam on the touched rows ("lazy": a row that is not looked up keeps its moments and its
+ * value).  The reference names keras.optimizers.Adam for 'sparsecore' tables and hands
+ * (learning_rate, beta_1, beta_2, epsilon) to the SparseCore library
+ * (embedding/jax/config_conversion.py:256-265; amsgrad unsupported); the arithmetic restated here
+ * is Keras' Adam.update_step:
+ *   m += (g - m)(1 - beta_1);  v += (g*g - v)(1 - beta_2);
+ *   w -= lr * bias_correction * m / (sqrt(v) + epsilon),
+ *   bias_correction = sqrt(1 - beta_2^t) / (1 - beta_1^t), t = 1-based step count (host side).
+ * tables[t].slot = fp32 [2][vocab][dim]: m then v.  tables[t].lr = learning rate. */
+int krs_embed_bag_bwd_fused_adam(const krs_table* tables, int n_tables,
+                                 const krs_feature* feats, int n_feats,
+                                 const float* weights, const float* bag_scale,
+                                 const void* grad, int grad_dtype, int64_t grad_ld,
+                                 int batch, int dim, int table_dtype, int64_t nnz,
+                                 float beta_1, float beta_2, float epsilon, float bias_correction,
+                                 const void* workspace, void* stream);
+
+/* Fused FTRL on the touched rows: keras.optimizers.Ftrl.update_step with the options the
+ * reference supports (embedding/jax/config_conversion.py:266-283: learning_rate_power, l1, l2,
+ * beta, initial_accumulator_value; no l2 shrinkage):
+ *   n' = n + g*g;  z += g - (n'^-p - n^-p) / lr * w;
+ *   w = (clip(z, -l1, l1) - z) / (n'^-p / lr + 2*(l2 + beta / (2 lr)));  n = n'.
+ * tables[t].slot = fp32 [2][vocab][dim]: accumulator n then linear z. */
+int krs_embed_bag_bwd_fused_ftrl(const krs_table* tables, int n_tables,
+                                 const krs_feature* feats, int n_feats,
+                                 const float* weights, const float* bag_scale,
+                                 const void* grad, int grad_dtype, int64_t grad_ld,
+                                 int batch, int dim, int table_dtype, int64_t nnz,
+                                 float learning_rate_power, float l1, float l2, float beta,
+                                 const void* workspace, void* stream);
+
 /* Sparse form: unique global rows and their summed gradients.
  *   unique_rows [nnz] int64 (first *n_unique valid), row_grads [nnz, dim] fp32,
  *   n_unique device int64. */

@@ -59,6 +59,8 @@ SYMBOLS = [
     "krs_embed_bag_bwd_dense",
     "krs_embed_bag_bwd_fused_sgd",
     "krs_embed_bag_bwd_fused_adagrad",
+    "krs_embed_bag_bwd_fused_adam",
+    "krs_embed_bag_bwd_fused_ftrl",
     "krs_embed_bag_bwd_sparse",
     "krs_gemm",
     "krs_gemm_workspace_bytes",

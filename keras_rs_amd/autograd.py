@@ -225,8 +225,11 @@ class EmbedBagFusedFn(torch.autograd.Function):
             ws.record_stream(torch.cuda.current_stream())
         else:
             ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
-        bags.backward_fused(ctx.optimizer, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
-                            bag_scale=scale)
+        opt = ctx.optimizer  # a kind string, or an object with .fused_kind / .next_hyper() (the layer's group)
+        kind = opt if isinstance(opt, str) else opt.fused_kind
+        hyper = None if isinstance(opt, str) or kind in ("sgd", "adagrad") else opt.next_hyper()
+        bags.backward_fused(kind, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
+                            bag_scale=scale, hyper=hyper)
         return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device), None)
 
 

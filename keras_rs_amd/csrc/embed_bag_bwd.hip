@@ -130,7 +130,46 @@ __global__ __launch_bounds__(256) void bag_keys_kernel(const KeyParams p) {
 }
 
 // ---- apply ------------------------------------------------------------------
-enum ApplyMode { kDense = 0, kSgd = 1, kAdagrad = 2, kSparse = 3 };
+enum ApplyMode { kDense = 0, kSgd = 1, kAdagrad = 2, kSparse = 3, kAdam = 4, kFtrl = 5 };
+constexpr bool mode_is_fused(int m) { return m == kSgd || m == kAdagrad || m == kAdam || m == kFtrl; }
+constexpr int mode_slots(int m) { return m == kAdagrad ? 1 : ((m == kAdam || m == kFtrl) ? 2 : 0); }
+
+// optimizer constants shared by every table of a call (the learning rate is per table)
+struct Hyper {
+  float a, b, c, d;  // Adam: beta_1, beta_2, epsilon, bias-correction factor; FTRL: lr_power, l1, l2, beta
+};
+
+// One element of the fused row update; g = the row's summed gradient.  s0 / s1 = slot planes.
+//   SGD / Adagrad: jax/test_utils.py:474-497.
+//   Adam (lazy: touched rows only; keras.optimizers.Adam.update_step as named by
+//     jax/config_conversion.py:256-265): alpha = lr * sqrt(1 - b2^t) / (1 - b1^t) (h.d carries the
+//     factor), m += (g - m)(1 - b1), v += (g^2 - v)(1 - b2), w -= alpha * m / (sqrt(v) + eps).
+//   FTRL (keras.optimizers.Ftrl.update_step, options of jax/config_conversion.py:266-283; no
+//     l2 shrinkage): n' = n + g^2; z += g - (n'^-p - n^-p) / lr * w;
+//     w = (clip(z, -l1, l1) - z) / (n'^-p / lr + 2 (l2 + beta / (2 lr))); n = n'.
+template <int MODE>
+__device__ __forceinline__ void row_update(float& w, float& s0, float& s1, float g, float lr, const Hyper& h) {
+  if constexpr (MODE == kSgd) {
+    w = w - lr * g;
+  } else if constexpr (MODE == kAdagrad) {
+    s0 = fmaf(g, g, s0);
+    w = w - lr * g / sqrtf(s0);
+  } else if constexpr (MODE == kAdam) {
+    s0 = s0 + (g - s0) * (1.0f - h.a);
+    s1 = s1 + (g * g - s1) * (1.0f - h.b);
+    w = w - (lr * h.d) * s0 / (sqrtf(s1) + h.c);
+  } else if constexpr (MODE == kFtrl) {
+    const float n_new = s0 + g * g;
+    // the default power -0.5 is an exactly rounded square root on both sides of the parity check
+    const float pn = h.a == -0.5f ? sqrtf(n_new) : powf(n_new, -h.a);
+    const float po = h.a == -0.5f ? sqrtf(s0) : powf(s0, -h.a);
+    s1 = s1 + g - (pn - po) / lr * w;
+    const float quad = pn / lr + 2.0f * (h.c + h.d / (2.0f * lr));
+    const float zc = fminf(fmaxf(s1, -h.b), h.b);
+    w = (zc - s1) / quad;
+    s0 = n_new;
+  }
+}
 
 struct ApplyParams {
   const krs_table* tables;  // dense: gradient buffers; fused: the tables themselves
@@ -152,6 +191,7 @@ struct ApplyParams {
   const uint32_t* long_list;
   int64_t* unique_rows;        // sparse
   float* row_grads;            // sparse
+  Hyper hyper;                 // Adam / FTRL
 };
 
 template <typename T>
@@ -309,14 +349,15 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
     tb = lds_desc ? s_tab[t] : p.tables[t];
     off = ((int64_t)key - tb.row_base) * p.dim + csub * N;
   }
-  float wv[N], av[N];
+  float wv[N], av[N], bv[N];
 #pragma unroll
-  for (int k = 0; k < N; ++k) { wv[k] = 0.0f; av[k] = 0.0f; }
+  for (int k = 0; k < N; ++k) { wv[k] = 0.0f; av[k] = 0.0f; bv[k] = 0.0f; }
   // dim % N == 0, so a 16-byte aligned buffer keeps every lane's piece naturally aligned
   const bool t_al = ((reinterpret_cast<uintptr_t>(tb.weights) | reinterpret_cast<uintptr_t>(tb.slot)) & 15) == 0;
-  if constexpr (MODE == kSgd || MODE == kAdagrad)
-    load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
-  if constexpr (MODE == kAdagrad) load_elems<float, N>(tb.slot + off, av, t_al);
+  const int64_t plane = tb.vocab * p.dim;  // second slot plane (Adam v / FTRL linear)
+  if constexpr (mode_is_fused(MODE)) load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
+  if constexpr (mode_slots(MODE) >= 1) load_elems<float, N>(tb.slot + off, av, t_al);
+  if constexpr (mode_slots(MODE) == 2) load_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
 
   // ---- gather and sum the segment's gradient rows, four at a time ----
   float acc[N];
@@ -372,17 +413,10 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
   } else if constexpr (MODE == kDense) {
     store_elems<float, N>(reinterpret_cast<float*>(tb.weights) + off, acc, t_al);
   } else {
-    if constexpr (MODE == kSgd) {
 #pragma unroll
-      for (int k = 0; k < N; ++k) wv[k] = wv[k] - tb.lr * acc[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        av[k] = fmaf(acc[k], acc[k], av[k]);
-        wv[k] = wv[k] - tb.lr * acc[k] / sqrtf(av[k]);
-      }
-      store_elems<float, N>(tb.slot + off, av, t_al);
-    }
+    for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], acc[k], tb.lr, p.hyper);
+    if constexpr (mode_slots(MODE) >= 1) store_elems<float, N>(tb.slot + off, av, t_al);
+    if constexpr (mode_slots(MODE) == 2) store_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
     store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
   }
   }  // segments of this group
@@ -481,21 +515,17 @@ __global__ __launch_bounds__(256) void bag_apply_long_kernel(const ApplyParams p
         if constexpr (MODE == kDense) {
           store_elems<float, N>(reinterpret_cast<float*>(tb.weights) + off, tot, t_al);
         } else {
-          float wv[N];
+          float wv[N], av[N], bv[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) { av[k] = 0.0f; bv[k] = 0.0f; }
+          const int64_t plane = tb.vocab * p.dim;
           load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
-          if constexpr (MODE == kSgd) {
+          if constexpr (mode_slots(MODE) >= 1) load_elems<float, N>(tb.slot + off, av, t_al);
+          if constexpr (mode_slots(MODE) == 2) load_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
 #pragma unroll
-            for (int k = 0; k < N; ++k) wv[k] = wv[k] - tb.lr * tot[k];
-          } else {
-            float av[N];
-            load_elems<float, N>(tb.slot + off, av, t_al);
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-              av[k] = fmaf(tot[k], tot[k], av[k]);
-              wv[k] = wv[k] - tb.lr * tot[k] / sqrtf(av[k]);
-            }
-            store_elems<float, N>(tb.slot + off, av, t_al);
-          }
+          for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], tot[k], tb.lr, p.hyper);
+          if constexpr (mode_slots(MODE) >= 1) store_elems<float, N>(tb.slot + off, av, t_al);
+          if constexpr (mode_slots(MODE) == 2) store_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
           store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
         }
       }
@@ -538,13 +568,12 @@ __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, in
         reinterpret_cast<float*>(tb.weights)[off] = acc;
       } else {
         float w = ld_elem(tb.weights, table_dtype, off);
-        if (MODE == kSgd) {
-          w = w - tb.lr * acc;
-        } else {
-          const float av = fmaf(acc, acc, tb.slot[off]);
-          tb.slot[off] = av;
-          w = w - tb.lr * acc / sqrtf(av);
-        }
+        const int64_t plane = tb.vocab * p.dim;
+        float s0 = mode_slots(MODE) >= 1 ? tb.slot[off] : 0.0f;
+        float s1 = mode_slots(MODE) == 2 ? tb.slot[plane + off] : 0.0f;
+        row_update<MODE>(w, s0, s1, acc, tb.lr, p.hyper);
+        if (mode_slots(MODE) >= 1) tb.slot[off] = s0;
+        if (mode_slots(MODE) == 2) tb.slot[plane + off] = s1;
         st_elem(tb.weights, table_dtype, off, w);
       }
     }
@@ -658,6 +687,7 @@ ApplyParams make_apply(const krs_table* tables, int n_tables, const krs_feature*
   p.keys = l.keys_sorted; p.vals = l.vals_sorted; p.seg_start = l.seg_start; p.n_seg = l.n_seg;
   p.n_long = l.n_long; p.long_list = l.long_list;
   p.unique_rows = nullptr; p.row_grads = nullptr;
+  p.hyper = Hyper{0.0f, 0.0f, 0.0f, 0.0f};
   return p;
 }
 
@@ -744,6 +774,29 @@ extern "C" int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_ta
   if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
   ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kAdagrad>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int krs_embed_bag_bwd_fused_adam(const krs_table* tables, int n_tables, const krs_feature* feats,
+                                            int n_feats, const float* weights, const float* bag_scale,
+                                            const void* grad, int grad_dtype, int64_t grad_ld, int batch,
+                                            int dim, int table_dtype, int64_t nnz, float beta_1, float beta_2,
+                                            float epsilon, float bias_correction, const void* workspace,
+                                            void* stream) {
+  if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
+  ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  p.hyper = Hyper{beta_1, beta_2, epsilon, bias_correction};
+  return run_apply<kAdam>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int krs_embed_bag_bwd_fused_ftrl(const krs_table* tables, int n_tables, const krs_feature* feats,
+                                            int n_feats, const float* weights, const float* bag_scale,
+                                            const void* grad, int grad_dtype, int64_t grad_ld, int batch,
+                                            int dim, int table_dtype, int64_t nnz, float learning_rate_power,
+                                            float l1, float l2, float beta, const void* workspace, void* stream) {
+  if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
+  ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  p.hyper = Hyper{learning_rate_power, l1, l2, beta};
+  return run_apply<kFtrl>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats, const float* weights,

@@ -152,17 +152,28 @@ class FusedBags:
         L.check(rc, "krs_embed_bag_bwd_dense")
         return list(out)
 
-    def backward_fused(self, kind, ws, grad, batch, nnz, hots=None, weights=None, bag_scale=None):
-        """In-place SGD / Adagrad on the touched rows of the tables (and Adagrad slots)."""
+    def backward_fused(self, kind, ws, grad, batch, nnz, hots=None, weights=None, bag_scale=None, hyper=None):
+        """In-place SGD / Adagrad / Adam / FTRL on the touched rows of the tables (and their slots:
+        [V, D] fp32 for Adagrad, [2, V, D] fp32 for Adam (m, v) and FTRL (accumulator, linear)).
+        hyper: Adam (beta_1, beta_2, epsilon, bias_correction); FTRL (learning_rate_power, l1, l2, beta)."""
         grad, fdesc = self._apply_common(grad, batch, hots)
-        fn = {"sgd": L.lib().krs_embed_bag_bwd_fused_sgd,
-              "adagrad": L.lib().krs_embed_bag_bwd_fused_adagrad}[kind]
-        if kind == "adagrad" and any(s is None for s in self.slots):
-            raise L.KrsError("fused adagrad needs an accumulator slot per table")
-        rc = fn(L.ptr(self.table_desc()), C.c_int(len(self.tables)), L.ptr(fdesc),
+        if kind != "sgd" and any(s is None for s in self.slots):
+            raise L.KrsError(f"fused {kind} needs a slot buffer per table")
+        head = (L.ptr(self.table_desc()), C.c_int(len(self.tables)), L.ptr(fdesc),
                 C.c_int(len(self.features)), L.ptr(weights), L.ptr(bag_scale), L.ptr(grad),
                 C.c_int(L.fdtype(grad)), C.c_int64(grad.stride(0)), C.c_int(batch), C.c_int(self.dim),
-                C.c_int(L.fdtype(self.tables[0])), C.c_int64(nnz), L.ptr(ws), L.stream_ptr())
+                C.c_int(L.fdtype(self.tables[0])), C.c_int64(nnz))
+        tail = (L.ptr(ws), L.stream_ptr())
+        if kind in ("sgd", "adagrad"):
+            fn = {"sgd": L.lib().krs_embed_bag_bwd_fused_sgd, "adagrad": L.lib().krs_embed_bag_bwd_fused_adagrad}[kind]
+            rc = fn(*head, *tail)
+        elif kind in ("adam", "ftrl"):
+            if hyper is None or len(hyper) != 4:
+                raise L.KrsError(f"fused {kind} needs its four hyper-parameters")
+            fn = {"adam": L.lib().krs_embed_bag_bwd_fused_adam, "ftrl": L.lib().krs_embed_bag_bwd_fused_ftrl}[kind]
+            rc = fn(*head, *(C.c_float(float(h)) for h in hyper), *tail)
+        else:
+            raise L.KrsError(f"unknown fused optimizer {kind!r}")
         L.check(rc, f"krs_embed_bag_bwd_fused_{kind}")
 
     def backward_sparse(self, ws, grad, batch, nnz, hots=None, weights=None, bag_scale=None):

@@ -1,10 +1,11 @@
 """keras_rs.layers surface of the hot path."""
 
-from keras_rs_amd.layers.distributed_embedding import Adagrad, DistributedEmbedding, SGD, concat_features
+from keras_rs_amd.layers.distributed_embedding import (Adagrad, Adam, DistributedEmbedding, Ftrl, SGD,
+                                                       concat_features)
 from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig, TableConfig
 from keras_rs_amd.layers.dot_interaction import DotInteraction
 from keras_rs_amd.layers.embed_reduce import EmbedReduce, Embedding, Ragged
 from keras_rs_amd.layers.feature_cross import FeatureCross
 
-__all__ = ["Adagrad", "DistributedEmbedding", "DotInteraction", "EmbedReduce", "Embedding", "FeatureConfig",
-           "FeatureCross", "Ragged", "SGD", "TableConfig", "concat_features"]
+__all__ = ["Adagrad", "Adam", "DistributedEmbedding", "DotInteraction", "EmbedReduce", "Embedding", "FeatureConfig",
+           "FeatureCross", "Ftrl", "Ragged", "SGD", "TableConfig", "concat_features"]

@@ -25,6 +25,7 @@ and tensorflow/ backends:
 from __future__ import annotations
 
 import dataclasses
+import math
 import threading
 from typing import Any, Sequence
 
@@ -41,7 +42,12 @@ from keras_rs_amd.layers.embed_reduce import Ragged, check_shapes_compatible
 SUPPORTED_PLACEMENTS = ("auto", "default_device", "sparsecore")
 
 
-# ---- per-table optimizers that K2 can fuse (jax/test_utils.py:474-497) -------------
+# ---- per-table optimizers that K2 can fuse -------------------------------------------
+# The reference accepts keras SGD / Adagrad / Adam / Ftrl objects (or their names) on 'sparsecore'
+# tables and maps them to the SparseCore library's optimizer specs, rejecting the options that
+# library lacks (jax/config_conversion.py:211-288).  Keras is not installed here, so these small
+# classes carry the same constructor arguments and defaults; any object with the same attribute
+# names (e.g. a real keras optimizer) resolves the same way.
 @dataclasses.dataclass
 class SGD:
     learning_rate: float = 0.01
@@ -59,27 +65,103 @@ class Adagrad:
         return {"learning_rate": self.learning_rate, "initial_accumulator_value": self.initial_accumulator_value}
 
 
+@dataclasses.dataclass
+class Adam:
+    learning_rate: float = 0.001
+    beta_1: float = 0.9
+    beta_2: float = 0.999
+    epsilon: float = 1e-7
+
+    def get_config(self):
+        return dataclasses.asdict(self)
+
+
+@dataclasses.dataclass
+class Ftrl:
+    learning_rate: float = 0.001
+    learning_rate_power: float = -0.5
+    initial_accumulator_value: float = 0.1
+    l1_regularization_strength: float = 0.0
+    l2_regularization_strength: float = 0.0
+    beta: float = 0.0
+
+    def get_config(self):
+        return dataclasses.asdict(self)
+
+
 def optimizer_from_config(cfg: dict):
-    return {"SGD": SGD, "Adagrad": Adagrad}[cfg["class_name"]](**cfg.get("config", {}))
+    return {"SGD": SGD, "Adagrad": Adagrad, "Adam": Adam, "Ftrl": Ftrl}[cfg["class_name"]](**cfg.get("config", {}))
 
 
-def resolve_fused_optimizer(opt):
-    """-> ("sgd"|"adagrad", lr, acc0) or None when the optimizer cannot be fused."""
-    if isinstance(opt, str):
-        o = opt.lower()
-        if o == "sgd":
-            return ("sgd", 0.01, 0.0)
-        if o == "adagrad":
-            return ("adagrad", 0.001, 0.1)
+@dataclasses.dataclass(frozen=True)
+class FusedOptimizer:
+    """What K2 needs to run a table's optimizer inside the backward."""
+
+    kind: str                 # "sgd" | "adagrad" | "adam" | "ftrl"
+    lr: float
+    acc0: float = 0.0         # initial value of the (first) slot plane: Adagrad / FTRL accumulator
+    consts: tuple = ()        # adam: (beta_1, beta_2, epsilon); ftrl: (lr_power, l1, l2, beta)
+
+    @property
+    def n_slot_planes(self) -> int:
+        return {"sgd": 0, "adagrad": 1, "adam": 2, "ftrl": 2}[self.kind]
+
+    def hyper(self, step: int):
+        """The four floats krs_embed_bag_bwd_fused_{adam,ftrl} take; `step` is the 1-based update count."""
+        if self.kind == "adam":
+            b1, b2, eps = self.consts
+            return (b1, b2, eps, math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step))
+        return self.consts if self.kind == "ftrl" else None
+
+    def new_slot(self, shape, device):
+        if self.kind == "adagrad":
+            return torch.full(shape, self.acc0, dtype=torch.float32, device=device)
+        if self.kind in ("adam", "ftrl"):
+            slot = torch.zeros((2,) + tuple(shape), dtype=torch.float32, device=device)
+            if self.kind == "ftrl":
+                slot[0].fill_(self.acc0)
+            return slot
         return None
+
+
+def resolve_fused_optimizer(opt) -> FusedOptimizer | None:
+    """The FusedOptimizer of a TableConfig.optimizer, or None when it cannot be fused (an option
+    the reference rejects as well, a learning-rate schedule, or an unknown optimizer)."""
+    if isinstance(opt, str):
+        cls = {"sgd": SGD, "adagrad": Adagrad, "adam": Adam, "ftrl": Ftrl}.get(opt.lower())
+        if cls is None:
+            return None
+        opt = cls()
     name = type(opt).__name__.lower()
     lr = getattr(opt, "learning_rate", None)
     if callable(lr) or lr is None:
         return None
+    # options without a fused counterpart (jax/config_conversion.py:232-283)
+    if any(getattr(opt, k, None) is not None for k in ("clipnorm", "global_clipnorm", "loss_scale_factor")) or \
+            getattr(opt, "use_ema", False):
+        return None
+    lr = float(lr)
     if name == "sgd":
-        return ("sgd", float(lr), 0.0)
+        if getattr(opt, "nesterov", False) or float(getattr(opt, "momentum", 0.0) or 0.0) != 0.0:
+            return None
+        return FusedOptimizer("sgd", lr)
     if name == "adagrad":
-        return ("adagrad", float(lr), float(getattr(opt, "initial_accumulator_value", 0.1)))
+        if float(getattr(opt, "epsilon", 1e-7)) != 1e-7:
+            return None
+        return FusedOptimizer("adagrad", lr, float(getattr(opt, "initial_accumulator_value", 0.1)))
+    if name == "adam":
+        if getattr(opt, "amsgrad", False):
+            return None
+        return FusedOptimizer("adam", lr, 0.0, (float(getattr(opt, "beta_1", 0.9)), float(getattr(opt, "beta_2", 0.999)),
+                                                float(getattr(opt, "epsilon", 1e-7))))
+    if name == "ftrl":
+        if float(getattr(opt, "l2_shrinkage_regularization_strength", 0.0) or 0.0) != 0.0:
+            return None
+        return FusedOptimizer("ftrl", lr, float(getattr(opt, "initial_accumulator_value", 0.1)),
+                              (float(getattr(opt, "learning_rate_power", -0.5)),
+                               float(getattr(opt, "l1_regularization_strength", 0.0)),
+                               float(getattr(opt, "l2_regularization_strength", 0.0)),
+                               float(getattr(opt, "beta", 0.0))))
     return None
 
 
@@ -107,7 +189,16 @@ class _Group:
     table_index: list          # per feature: index into `tables`
     table_configs: list        # unique TableConfig objects
     bags: FusedBags | None = None
-    fused_kind: str | None = None
+    fused: FusedOptimizer | None = None   # shared by the group's tables (learning rates may differ)
+    step: int = 0                         # fused updates applied so far (Adam bias correction)
+
+    @property
+    def fused_kind(self) -> str | None:
+        return None if self.fused is None else self.fused.kind
+
+    def next_hyper(self):
+        self.step += 1
+        return self.fused.hyper(self.step)
 
 
 class DistributedEmbedding(base.Layer):
@@ -191,7 +282,8 @@ class DistributedEmbedding(base.Layer):
             if resolve_fused_optimizer(fc.table.optimizer) is None:
                 raise NotImplementedError(
                     f"Table '{fc.table.name}': the 'sparsecore' placement fuses the table optimizer into the "
-                    f"backward and supports SGD and Adagrad; got {fc.table.optimizer!r}. Use "
+                    f"backward and supports SGD, Adagrad, Adam and Ftrl (constant learning rate, the option "
+                    f"set of the reference's SparseCore path); got {fc.table.optimizer!r}. Use "
                     "placement='default_device' for other optimizers.")
         self._make_groups("sparsecore", feature_configs)
 
@@ -204,7 +296,7 @@ class DistributedEmbedding(base.Layer):
             if g.bags is not None:
                 continue
             tables, slots, lrs = [], [], []
-            kinds = set()
+            kinds: set = set()
             for tc in g.table_configs:
                 key = id(tc)
                 if key not in self._table_params:
@@ -217,15 +309,17 @@ class DistributedEmbedding(base.Layer):
                 tables.append(p)
                 lr = 0.0
                 if placement == "sparsecore":
-                    kind, lr, acc0 = resolve_fused_optimizer(tc.optimizer)
-                    kinds.add(kind)
-                    if kind == "adagrad" and self._table_slots[key] is None:
-                        self._table_slots[key] = torch.full(p.shape, acc0, dtype=torch.float32, device=p.device)
+                    fo = resolve_fused_optimizer(tc.optimizer)
+                    lr = fo.lr
+                    kinds.add(dataclasses.replace(fo, lr=0.0))   # everything but the learning rate is per group
+                    if self._table_slots[key] is None:
+                        self._table_slots[key] = fo.new_slot(p.shape, p.device)
                 slots.append(self._table_slots[key])
                 lrs.append(lr)
             if len(kinds) > 1:
-                raise NotImplementedError("Tables of one embedding width on 'sparsecore' must share an optimizer type")
-            g.fused_kind = kinds.pop() if kinds else None
+                raise NotImplementedError("Tables of one embedding width on 'sparsecore' must share the optimizer "
+                                          "type and its constants (only the learning rate may differ per table)")
+            g.fused = kinds.pop() if kinds else None
             fcs = self._placement_to_path_to_feature_config[placement]
             feats = [(g.table_index[i], fcs[p].table.combiner, i * g.dim) for i, p in enumerate(g.paths)]
             g.bags = FusedBags(tables, feats, slots=slots, lrs=lrs)
@@ -325,7 +419,7 @@ class DistributedEmbedding(base.Layer):
             if placement == "sparsecore":
                 lead = self.slab_lead_cols if len(self._groups[placement]) == 1 else 0
                 slab, *out = EmbedBagFusedFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w,
-                                                   out_dtype, g.fused_kind, self._anchor, lead)
+                                                   out_dtype, g, self._anchor, lead)
                 for i, o in enumerate(out):  # lets layers.concat_features find the slab (zero-copy concat)
                     o._krs_slab = (slab, lead + i * g.dim, len(out), lead)
             else:

@@ -142,9 +142,10 @@ class ShardedDistributedEmbedding(base.Layer):
             raise NotImplementedError("ShardedDistributedEmbedding: tables must share embedding_dim")
         self.dim = dims.pop()
         kinds = {resolve_fused_optimizer(tc.optimizer) for tc in tcs}
-        if None in kinds or len({k[0] for k in kinds}) != 1 or len({k[1] for k in kinds}) != 1:
+        if None in kinds or len(kinds) != 1 or next(iter(kinds)).kind not in ("sgd", "adagrad"):
             raise NotImplementedError("ShardedDistributedEmbedding: one SGD/Adagrad setting for all tables")
-        self._opt_kind, self._lr, self._acc0 = next(iter(kinds))
+        fo = next(iter(kinds))
+        self._opt_kind, self._lr, self._acc0 = fo.kind, fo.lr, fo.acc0
         self.vloc = max(math.ceil(tc.vocabulary_size / self.world) for tc in tcs)
         self._combiners = [feature_configs[p].table.combiner for p in self._paths]
         self.register_parameter("shard", None)

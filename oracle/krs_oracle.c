@@ -170,17 +170,27 @@ int krs_oracle_embed_bag_bwd_dense(const krs_table* grad_tables, int n_tables,
 }
 
 /*
- * Per-table optimizer step on a dense gradient, jax/test_utils.py:474-497:
- *   SGD      table - lr * grad
- *   Adagrad  acc += grad*grad ; table - lr / sqrt(acc) * grad   (no epsilon)
+ * Per-table optimizer step on a dense gradient.
+ *   SGD      table - lr * grad                                   jax/test_utils.py:474-497
+ *   Adagrad  acc += grad*grad ; table - lr / sqrt(acc) * grad    (no epsilon; same lines)
+ *   Adam     keras.optimizers.Adam.update_step (named at jax/config_conversion.py:256-265):
+ *            m += (g-m)(1-b1); v += (g*g-v)(1-b2); w -= lr*corr*m/(sqrt(v)+eps),
+ *            corr = sqrt(1-b2^t)/(1-b1^t).   hyper = {b1, b2, eps, corr}; acc = [2][vocab][dim]
+ *   FTRL     keras.optimizers.Ftrl.update_step (options of jax/config_conversion.py:266-283):
+ *            n' = n+g*g; z += g-(n'^-p-n^-p)/lr*w; w = (clip(z,-l1,l1)-z)/(n'^-p/lr+2(l2+beta/(2lr)));
+ *            hyper = {p, l1, l2, beta}; acc = [2][vocab][dim] (n, z)
+ * Adam / FTRL arithmetic is a restatement of the published Keras formulas: the SparseCore
+ * library the reference hands them to is not in /root/reference (parity unpinned).
  * Only rows with touched[r] != 0 are updated (the fused device kernels touch
  * only looked-up rows; for SGD an untouched row has grad 0 so the result is
- * identical, for Adagrad acc stays and 0/sqrt(acc) = 0 as long as acc > 0).
- * kind: 0 = SGD, 1 = Adagrad.
+ * identical, for Adagrad acc stays and 0/sqrt(acc) = 0 as long as acc > 0;
+ * Adam / FTRL are "lazy": untouched rows keep value and slots).
+ * kind: 0 = SGD, 1 = Adagrad, 2 = Adam, 3 = FTRL.
  */
-int krs_oracle_apply_optimizer(void* table, int table_dtype, float* acc, const float* grad,
-                               const uint8_t* touched, int64_t vocab, int dim, float lr,
-                               int kind) {
+int krs_oracle_apply_optimizer2(void* table, int table_dtype, float* acc, const float* grad,
+                                const uint8_t* touched, int64_t vocab, int dim, float lr,
+                                int kind, const float* hyper) {
+  const int64_t plane = vocab * dim;
   for (int64_t r = 0; r < vocab; ++r) {
     if (touched && !touched[r]) continue;
     for (int c = 0; c < dim; ++c) {
@@ -191,6 +201,24 @@ int krs_oracle_apply_optimizer(void* table, int table_dtype, float* acc, const f
         float a = fmaf(g, g, acc[i]);
         acc[i] = a;
         t = t - lr * g / sqrtf(a);
+      } else if (kind == 2) {
+        float m = acc[i], v = acc[plane + i];
+        m = m + (g - m) * (1.0f - hyper[0]);
+        v = v + (g * g - v) * (1.0f - hyper[1]);
+        t = t - (lr * hyper[3]) * m / (sqrtf(v) + hyper[2]);
+        acc[i] = m;
+        acc[plane + i] = v;
+      } else if (kind == 3) {
+        float n = acc[i], z = acc[plane + i];
+        float n_new = n + g * g;
+        float pn = hyper[0] == -0.5f ? sqrtf(n_new) : powf(n_new, -hyper[0]);
+        float po = hyper[0] == -0.5f ? sqrtf(n) : powf(n, -hyper[0]);
+        z = z + g - (pn - po) / lr * t;
+        float quad = pn / lr + 2.0f * (hyper[2] + hyper[3] / (2.0f * lr));
+        float zc = fminf(fmaxf(z, -hyper[1]), hyper[1]);
+        t = (zc - z) / quad;
+        acc[i] = n_new;
+        acc[plane + i] = z;
       } else {
         t = t - lr * g;
       }
@@ -198,6 +226,12 @@ int krs_oracle_apply_optimizer(void* table, int table_dtype, float* acc, const f
     }
   }
   return KRS_OK;
+}
+
+int krs_oracle_apply_optimizer(void* table, int table_dtype, float* acc, const float* grad,
+                               const uint8_t* touched, int64_t vocab, int dim, float lr,
+                               int kind) {
+  return krs_oracle_apply_optimizer2(table, table_dtype, acc, grad, touched, vocab, dim, lr, kind, 0);
 }
 
 static inline float act_apply(int act, float v) {

@@ -113,6 +113,54 @@ def test_fused_optimizers(kind, tdt, gdt, dim):
             np.testing.assert_allclose(s["slots"][t].cpu().numpy(), exp_slots[t], rtol=1e-6, atol=1e-6)
 
 
+ADAM = (0.9, 0.999, 1e-7)
+FTRL = (-0.5, 0.02, 0.01, 0.3)   # learning_rate_power, l1, l2, beta
+
+
+@pytest.mark.parametrize("kind", ["adam", "ftrl"])
+@pytest.mark.parametrize("tdt,gdt,dim", [("f32", "f32", 128), ("bf16", "bf16", 128), ("f32", "f32", 7),
+                                         ("f32", "bf16", 64)])
+def test_fused_adam_and_ftrl_two_steps(kind, tdt, gdt, dim):
+    # SURVEY.md section 8f.2.  Two consecutive updates (Adam's bias correction depends on the step);
+    # untouched rows must keep value and slots (lazy semantics).
+    s = _setup(dim, tdt, gdt, False, use_w=True, combiners=["sum", "mean"])
+    fb = s["fb"]
+    dev = s["tables"][0].device
+    fb.slots = [torch.zeros((2,) + tuple(t.shape), dtype=torch.float32, device=dev) for t in s["tables"]]
+    if kind == "ftrl":
+        for sl in fb.slots:
+            sl[0].fill_(0.1)
+    exp_tables = [to_np(t).copy() for t in s["tables"]]
+    exp_slots = [x.cpu().numpy().copy() for x in fb.slots]
+    ids, hots = s["bags"]["ids"], s["hots"]
+    for step in (1, 2):
+        hyper = ADAM + (float(np.sqrt(1 - ADAM[1] ** step) / (1 - ADAM[0] ** step)),) if kind == "adam" else FTRL
+        fb.backward_fused(kind, s["ws"], s["grad"], s["batch"], s["nnz"], hots=hots, weights=s["w"],
+                          bag_scale=s["scale"], hyper=hyper)
+        torch.cuda.synchronize()
+        for t in range(len(exp_tables)):
+            touched = np.zeros(s["vocabs"][t], np.uint8)
+            base = 0
+            for f, (tt, _, _) in enumerate(fb.features):
+                n = s["batch"] * hots[f]
+                if tt == t:
+                    touched[ids[base:base + n]] = 1
+                base += n
+            before = exp_tables[t].copy()
+            ko.apply_optimizer(exp_tables[t], exp_slots[t], s["de"][t], touched, fb.lrs[t], kind, hyper)
+            assert np.array_equal(before[touched == 0], exp_tables[t][touched == 0])
+            got = to_np(s["tables"][t])
+            if tdt == "bf16":
+                np.testing.assert_allclose(to_f32(got), to_f32(exp_tables[t]), rtol=2 ** -7, atol=1e-5)
+                exp_tables[t] = got.copy()  # follow the device's rounding into the next step
+            else:
+                np.testing.assert_allclose(got, exp_tables[t], rtol=2e-5, atol=2e-6)
+            # FTRL's linear term carries (n'^-p - n^-p) / lr * w: a difference of close numbers times 1 / lr
+            np.testing.assert_allclose(fb.slots[t].cpu().numpy(), exp_slots[t], rtol=2e-5, atol=2e-5 if kind == "ftrl" else 1e-6)
+    with pytest.raises(Exception, match="hyper"):
+        fb.backward_fused(kind, s["ws"], s["grad"], s["batch"], s["nnz"], hots=hots)
+
+
 @pytest.mark.parametrize("tdt,gdt,dim", [("f32", "f32", 128), ("bf16", "bf16", 64)])
 def test_hot_rows_take_the_workgroup_path(tdt, gdt, dim):
     """Tiny vocabularies / skewed ids: segments far longer than kLongSeg (512) are summed by a whole
@@ -140,3 +188,14 @@ def test_hot_rows_take_the_workgroup_path(tdt, gdt, dim):
         np.testing.assert_allclose(to_f32(to_np(s["tables"][t])), to_f32(exp_tables[t]),
                                    rtol=2 ** -7 if tdt == "bf16" else 1e-5, atol=1e-5)
         np.testing.assert_allclose(s["slots"][t].cpu().numpy(), exp_slots[t], rtol=1e-4, atol=1e-3)
+    # Adam through the same hot-row path (two slot planes)
+    fb.slots = [torch.zeros((2,) + tuple(t.shape), dtype=torch.float32, device=t.device) for t in s["tables"]]
+    exp_tables = [to_np(t).copy() for t in s["tables"]]
+    exp_slots = [x.cpu().numpy().copy() for x in fb.slots]
+    hyper = ADAM + (float(np.sqrt(1 - ADAM[1]) / (1 - ADAM[0])),)
+    fb.backward_fused("adam", s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                      bag_scale=s["scale"], hyper=hyper)
+    for t in range(len(exp_tables)):
+        ko.apply_optimizer(exp_tables[t], exp_slots[t], s["de"][t], None, fb.lrs[t], "adam", hyper)
+        np.testing.assert_allclose(to_f32(to_np(s["tables"][t])), to_f32(exp_tables[t]),
+                                   rtol=2 ** -7 if tdt == "bf16" else 1e-4, atol=1e-4)

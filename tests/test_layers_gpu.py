@@ -271,6 +271,44 @@ def test_distributed_embedding_training_step_matches_formula(placement, optimize
                                rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("optimizer", ["adam", "ftrl"])
+def test_distributed_embedding_adam_and_ftrl_steps_match_the_keras_formulas(optimizer):
+    # the default TableConfig.optimizer is "adam" (distributed_embedding_config.py:57); two training
+    # steps on 'sparsecore' tables against a float64 transcription of the Keras update rules
+    kl = _layers()
+    opt = kl.Adam(0.05, 0.9, 0.999, 1e-7) if optimizer == "adam" else kl.Ftrl(0.05, -0.5, 0.1, 0.01, 0.02, 0.1)
+    t = kl.TableConfig("table", 23, 8, placement="sparsecore", optimizer=opt, combiner="sum")
+    layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t, (16, 2), (16, 8))})
+    x = np.random.default_rng(0).integers(0, 23, (16, 2)).astype(np.int32)
+    layer.build(None)
+    W = layer.get_embedding_tables()["table"].double().cpu().numpy()
+    w_start = W.copy()
+    m = np.zeros_like(W)
+    v = np.zeros_like(W)
+    n = np.full_like(W, 0.1)
+    z = np.zeros_like(W)
+    touched = np.zeros(23, bool)
+    touched[x.reshape(-1)] = True
+    for step in (1, 2):
+        g = torch.rand(16, 8, device=DEV, generator=torch.Generator(device=DEV).manual_seed(step))
+        (layer({"a": x})["a"] * g).sum().backward()
+        dense = np.zeros_like(W)
+        np.add.at(dense, x.reshape(-1), np.repeat(g.double().cpu().numpy(), 2, axis=0))
+        if optimizer == "adam":
+            corr = np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+            m[touched] += (dense[touched] - m[touched]) * 0.1
+            v[touched] += (dense[touched] ** 2 - v[touched]) * 0.001
+            W[touched] -= 0.05 * corr * m[touched] / (np.sqrt(v[touched]) + 1e-7)
+        else:
+            n_new = n + dense * dense
+            z_new = z + dense - (np.sqrt(n_new) - np.sqrt(n)) / 0.05 * W
+            quad = np.sqrt(n_new) / 0.05 + 2 * (0.02 + 0.1 / (2 * 0.05))
+            w_new = (np.clip(z_new, -0.01, 0.01) - z_new) / quad
+            W[touched], n[touched], z[touched] = w_new[touched], n_new[touched], z_new[touched]
+        np.testing.assert_allclose(layer.get_embedding_tables()["table"].cpu().numpy(), W, rtol=2e-5, atol=2e-6)
+    assert np.array_equal(W[~touched], w_start[~touched])  # lazy: rows never looked up do not move
+
+
 @pytest.mark.parametrize("lead", [0, 8, 4])
 def test_concat_features_uses_the_slab_and_trains_like_torch_cat(lead):
     # SURVEY.md section 8f.3 (concat-free layout): concat_features([dense, *embeddings]) == torch.cat,

@@ -163,3 +163,28 @@ def test_concat_features_is_torch_cat_without_a_slab():
 
     parts = [torch.arange(6.0).reshape(2, 3), torch.ones(2, 2), torch.zeros(2, 1)]
     assert torch.equal(kl.concat_features(parts), torch.cat(parts, dim=-1))
+
+
+def test_fused_optimizer_resolution_follows_the_reference_option_matrix():
+    # jax/config_conversion.py:211-288: names and objects of SGD / Adagrad / Adam / Ftrl, minus the
+    # options the SparseCore path rejects
+    import types
+
+    from keras_rs_amd.layers.distributed_embedding import Adagrad, Adam, Ftrl, SGD, resolve_fused_optimizer as r
+
+    assert r("adam").kind == "adam" and r("adam").consts == (0.9, 0.999, 1e-7) and r("adam").lr == 0.001
+    assert r("ftrl").kind == "ftrl" and r("ftrl").acc0 == 0.1 and r("ftrl").consts == (-0.5, 0.0, 0.0, 0.0)
+    assert r(SGD(0.5)).lr == 0.5 and r(Adagrad(0.1, 0.2)).acc0 == 0.2
+    assert r(Adam(0.01, 0.8, 0.9, 1e-5)).consts == (0.8, 0.9, 1e-5)
+    assert r(Ftrl(0.1, -0.3, 0.2, 0.01, 0.02, 0.5)).consts == (-0.3, 0.01, 0.02, 0.5)
+    assert r("rmsprop") is None
+    keras_like = types.SimpleNamespace
+    assert r(type("Adam", (), dict(learning_rate=0.1, amsgrad=True))()) is None
+    assert r(type("SGD", (), dict(learning_rate=0.1, momentum=0.9))()) is None
+    assert r(type("Ftrl", (), dict(learning_rate=0.1, l2_shrinkage_regularization_strength=0.1))()) is None
+    assert r(type("Adagrad", (), dict(learning_rate=0.1, epsilon=1e-3))()) is None
+    assert r(type("Adam", (), dict(learning_rate=lambda step: 0.1))()) is None      # schedules are not fused
+    assert r(type("Adam", (), dict(learning_rate=0.1, clipnorm=1.0))()) is None
+    h1, h2 = r("adam").hyper(1), r("adam").hyper(2)
+    assert abs(h1[3] - (1 - 0.999) ** 0.5 / (1 - 0.9)) < 1e-12 and h2[3] != h1[3]
+    del keras_like

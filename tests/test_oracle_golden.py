@@ -158,3 +158,38 @@ def test_bf16_round_trip_helpers():
     e = ko.f32_to_bf16_bits(np.linspace(-1, 1, 40, dtype=np.float32).reshape(10, 4))
     out = ko.embed_reduce(e, np.array([3, 7], np.int32), None, "sum")
     np.testing.assert_array_equal(out, e[[3, 7]])  # gather of bf16 rows is bit-exact
+
+
+def test_adam_and_ftrl_oracle_against_float64_keras_formulas():
+    # Adam / FTRL have no vector in the reference's tests (their arithmetic lives in the SparseCore
+    # library): the oracle is checked against an independent float64 transcription of
+    # keras.optimizers.Adam.update_step / Ftrl.update_step over three steps (parity unpinned).
+    rng = np.random.default_rng(0)
+    w0 = rng.uniform(-1, 1, (5, 4)).astype(np.float32)
+    grads = [rng.uniform(-1, 1, (5, 4)).astype(np.float32) for _ in range(3)]
+    lr, b1, b2, eps = 0.05, 0.9, 0.999, 1e-7
+    w = w0.copy()
+    acc = np.zeros((2, 5, 4), np.float32)
+    W, m, v = w0.astype(np.float64), np.zeros((5, 4)), np.zeros((5, 4))
+    for t, g in enumerate(grads, 1):
+        corr = np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        ko.apply_optimizer(w, acc, g, None, lr, "adam", (b1, b2, eps, corr))
+        m += (g - m) * (1 - b1)
+        v += (g.astype(np.float64) ** 2 - v) * (1 - b2)
+        W -= lr * corr * m / (np.sqrt(v) + eps)
+        np.testing.assert_allclose(w, W, rtol=2e-5, atol=1e-6)
+    p_, l1, l2, beta = -0.5, 0.05, 0.02, 0.1
+    w = w0.copy()
+    acc = np.zeros((2, 5, 4), np.float32)
+    acc[0] = 0.1
+    W, n, z = w0.astype(np.float64), np.full((5, 4), 0.1), np.zeros((5, 4))
+    for g in grads:
+        ko.apply_optimizer(w, acc, g, None, lr, "ftrl", (p_, l1, l2, beta))
+        g = g.astype(np.float64)
+        n_new = n + g * g
+        z += g - (n_new ** -p_ - n ** -p_) / lr * W
+        quad = n_new ** -p_ / lr + 2 * (l2 + beta / (2 * lr))
+        W = (np.clip(z, -l1, l1) - z) / quad
+        n = n_new
+        np.testing.assert_allclose(w, W, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(acc[1], z, rtol=2e-5, atol=1e-6)
