@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the MOD-sharded embedding path even at N = 1 (dry run of the multi-GPU code)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2048)
+    ap.add_argument("--host-inputs", type=int, default=0, metavar="WORKERS",
+                    help="also time the step with ids that start in HOST memory, fed through "
+                         "keras_rs_amd.data.ThreadedDataLoader with this many loader threads (PCIe-inclusive rate, "
+                         "reported under `host_inputs`; never `value`)")
     return ap.parse_args()
 
 
@@ -174,8 +178,9 @@ def cpu_baseline(a, hots):
     }
 
 
-def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
-    """Times `steps` steps of the hot path for one bag-length list; returns (seconds, K1 seconds)."""
+def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, loader=None):
+    """Times `steps` steps of the hot path for one bag-length list; returns (seconds, K1 seconds).
+    With `loader`, every step takes its preprocessed ids from it (host-resident inputs)."""
     ids, dense = make_inputs(a, hots, b_local, rank, dev)
     pre = model.embedding.preprocess(ids)
     scale = 1.0 / (b_local * (a.tables + 1) * a.dim)
@@ -185,7 +190,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box):
     g_inter = torch.full((b_local, n_inter), 0.1 * scale, dtype=torch.bfloat16, device=dev)
 
     def step():
-        xl, inter = model(dense, pre)
+        xl, inter = model(dense, pre if loader is None else next(loader))
         # loss = scale * sum(xl) + 0.1 * scale * sum(inter), taken through its (constant) output
         # gradients: the reduction to a scalar is not part of the hot path
         torch.autograd.backward([xl, inter], [g_xl, g_inter])
@@ -303,6 +308,27 @@ def main():
     # the other C3 bag-length list (SURVEY.md section 8d lists both), same tables and model, shorter run
     sec_steps = max(3, a.steps // 2)
     elapsed2, k1_s2 = measure(model, a, secondary, world, rank, dev, b_local, sec_steps, 2, opt_box)
+    host = None
+    if a.host_inputs > 0 and world == 1 and not a.force_sharded:
+        # ids start in host memory: a small pool of batches cycles through the loader threads, which
+        # concatenate them into page-locked memory and upload on their own streams
+        from keras_rs_amd.data import ThreadedDataLoader
+
+        rng = np.random.default_rng(7)
+        pool = [{f"cat_{t:02d}_id": rng.integers(0, a.vocab, (b_local, primary[t]), dtype=np.int32)
+                 for t in range(a.tables)} for _ in range(4)]
+
+        def cycle():
+            while True:
+                yield from pool
+
+        loader = ThreadedDataLoader(model.embedding.preprocess, cycle(), num_workers=a.host_inputs, buffer_size=4)
+        el_h, _ = measure(model, a, primary, world, rank, dev, b_local, a.steps, a.warmup, opt_box, loader=loader)
+        loader.stop()
+        id_bytes = 4 * b_local * sum(primary)
+        host = {"ms_per_step": el_h / a.steps * 1e3, "value": a.batch * sum(primary) / (el_h / a.steps),
+                "unit": "lookups/s", "loader_threads": a.host_inputs, "id_bytes_per_step": id_bytes,
+                "note": "ids generated on the host, ThreadedDataLoader -> preprocess -> pinned upload; PCIe-inclusive"}
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -349,6 +375,8 @@ def main():
         second["embed_fwd_lookups_per_s"] = world * b_local * sum(secondary) / k1_s2
         second["roofline"] = k1_roofline(a, secondary, b_local, k1_s2, n2, sharded)
     out["also"] = second
+    if host is not None:
+        out["host_inputs"] = host
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, primary)
     print(json.dumps(out))

@@ -660,7 +660,13 @@ def _to_tensor(x) -> torch.Tensor:
 
 def _cat_index(parts: Sequence[torch.Tensor]) -> torch.Tensor:
     dt = torch.int64 if any(p.dtype == torch.int64 for p in parts) else torch.int32
-    return torch.cat([p.to(dt) for p in parts]) if len(parts) > 1 else parts[0].to(dt).contiguous()
+    parts = [p.to(dt) for p in parts]
+    if all(p.device.type == "cpu" for p in parts) and torch.cuda.is_available():
+        # host ids: concatenate straight into page-locked memory, so that the upload that follows is a
+        # true asynchronous DMA (the loader threads of data.ThreadedDataLoader overlap it with compute)
+        buf = torch.empty(sum(p.numel() for p in parts), dtype=dt, pin_memory=True)
+        return torch.cat(parts, out=buf) if len(parts) > 1 else buf.copy_(parts[0].reshape(-1))
+    return torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
 
 
 def _shape_of(x):

@@ -271,6 +271,34 @@ def test_distributed_embedding_training_step_matches_formula(placement, optimize
                                rtol=1e-5, atol=1e-6)
 
 
+def test_threaded_data_loader_feeds_preprocessed_host_batches():
+    # host ids -> loader threads (preprocess + asynchronous upload on their own
+    # streams) -> layer call; results equal the direct call on the same ids
+    from keras_rs_amd.data import ThreadedDataLoader
+
+    kl = _layers()
+    t = kl.TableConfig("t", 50, 8, placement="sparsecore", optimizer="sgd", combiner="mean")
+    layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t, (32, 4), (32, 8)),
+                                     "b": kl.FeatureConfig("b", t, (32, 1), (32, 8))})
+    layer.build(None)
+    rng = np.random.default_rng(1)
+    batches = [({"large_emb_inputs": {"a": rng.integers(0, 50, (32, 4)).astype(np.int32),
+                                      "b": rng.integers(0, 50, (32, 1)).astype(np.int32)},
+                 "dense_input": rng.random((32, 3)).astype(np.float32)}, rng.integers(0, 2, 32)) for _ in range(6)]
+    loader = ThreadedDataLoader(layer.preprocess, batches, num_workers=2)
+    seen = 0
+    for x, y in loader:
+        assert x["dense_input"].is_cuda and y.is_cuda
+        out = layer(x["large_emb_inputs"])
+        # find the host batch this one came from (workers may reorder)
+        k = next(i for i, (bx, _) in enumerate(batches) if np.array_equal(bx["dense_input"], x["dense_input"].cpu().numpy()))
+        ref = layer(batches[k][0]["large_emb_inputs"])
+        assert torch.equal(out["a"], ref["a"]) and torch.equal(out["b"], ref["b"])
+        seen += 1
+    assert seen == 6
+    loader.stop()
+
+
 @pytest.mark.parametrize("optimizer", ["adam", "ftrl"])
 def test_distributed_embedding_adam_and_ftrl_steps_match_the_keras_formulas(optimizer):
     # the default TableConfig.optimizer is "adam" (distributed_embedding_config.py:57); two training

@@ -188,3 +188,34 @@ def test_fused_optimizer_resolution_follows_the_reference_option_matrix():
     h1, h2 = r("adam").hyper(1), r("adam").hyper(2)
     assert abs(h1[3] - (1 - 0.999) ** 0.5 / (1 - 0.9)) < 1e-12 and h2[3] != h1[3]
     del keras_like
+
+
+def test_threaded_data_loader_delivers_every_item_and_propagates_errors():
+    # examples/ml_perf/main.py:35-105: loader threads run process_fn on x["large_emb_inputs"]
+    from keras_rs_amd.data import ThreadedDataLoader
+
+    items = [({"large_emb_inputs": {"a": np.full((2, 3), i)}, "dense_input": np.full((2, 4), float(i))},
+              np.full((2,), i)) for i in range(7)]
+    calls = []
+
+    def process(inputs, training=False):
+        calls.append(training)
+        return {"ids": inputs["a"] + 100}
+
+    loader = ThreadedDataLoader(process, items, num_workers=3, training=True, buffer_size=2, device="cpu")
+    got = sorted(int(x["large_emb_inputs"]["ids"][0, 0]) for x, _ in loader)
+    assert got == [100 + i for i in range(7)] and calls == [True] * 7
+    loader.stop()
+
+    def bad():
+        yield items[0]
+        raise RuntimeError("dataset broke")
+
+    loader = ThreadedDataLoader(process, bad(), num_workers=1, device="cpu")
+    next(loader)
+    with pytest.raises(RuntimeError, match="dataset broke"):
+        next(loader)
+    loader.stop()
+    # items of another shape go to process_fn whole
+    loader = ThreadedDataLoader(lambda item, training=False: item * 2, [1, 2, 3], num_workers=1, device="cpu")
+    assert sorted(loader) == [2, 4, 6]
