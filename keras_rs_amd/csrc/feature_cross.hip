@@ -241,92 +241,127 @@ __device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) 
 // Epilogue shared by the GEMM kernels.  The accumulators go through LDS (the operand tiles are
 // dead by now) so that each lane ends up with 8 consecutive columns of one row: x0 / x / R are
 // read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
+// ---- epilogue, in chunks of 32 rows x 64 columns per wave --------------------------------------
+// The accumulators go through LDS (the operand tiles are dead: every wave passed the loop's last
+// barrier) so that each lane ends up with 8 consecutive columns of one row: x0 / x / R are read
+// and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
+// MFMA C/D layout: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
+// epi_prefetch issues a chunk's x0 / x / R loads (specialised forms EPI 1 / 2), epi_process stages
+// the chunk's accumulators and writes it; callers order them so that a chunk's loads are in
+// flight while the previous chunk is processed.
+struct EpiOperands {
+  uint4 ex[4], ex0[4];
+};
+
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_wave(const GemmParams& p, f32x16 (&acc)[2][2], float* stage, int64_t wm0,
-                                                   int64_t wn0, int split) {
-  // (wm0, wn0): origin of this wave's 64x64 block of C; `stage`: its private 32 x SST floats of LDS.
+__device__ __forceinline__ void epi_prefetch(const GemmParams& p, EpiOperands& o, int64_t row0, int64_t wn0) {
+  if constexpr (EPI == 1 || EPI == 2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t gnc = min(wn0 + (lane & 7) * 8, p.n - 8);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t gmc = min(row0 + it * 8 + (lane >> 3), p.m - 1);
+      if constexpr (EPI == 1) {
+        o.ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x) + gmc * p.ep.ldx + gnc);
+        o.ex0[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x0) + gmc * p.ep.ldx + gnc);
+      } else {
+        o.ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.r) + gmc * p.ep.ldr + gnc);
+      }
+    }
+  }
+}
+
+// acc2: the chunk's two 32x32 accumulator fragments (columns 0..31 / 32..63); `stage`: the wave's
+// private 32 x SST floats of LDS; (row0, wn0): origin of the chunk in C.
+template <int EPI>
+__device__ __forceinline__ void epi_process(const GemmParams& p, f32x16 (&acc2)[2], const EpiOperands& o, float* stage,
+                                            int64_t row0, int64_t wn0, int split) {
   const int lane = threadIdx.x & 63;
   const int frow = lane & 31;
   const int fhalf = lane >> 5;
-  // The accumulators go through LDS (the operand tiles are dead: every wave passed the loop's
-  // last barrier) so that each lane ends up with 8 consecutive columns of one row: x0 / x / R are
-  // then read and y / u written as 16-byte (bf16) or 2x16-byte (fp32) vectors.
-  // MFMA C/D layout: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5).
   constexpr int SST = 68;  // staging row stride in floats (64 + pad)
   const int ec = (lane & 7) * 8;
   const int64_t gn = wn0 + ec;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {  // the wave's upper / lower 32 rows
-    // operands of the specialised epilogues: in flight while the accumulators are staged
-    uint4 ex[4], ex0[4];
-    if constexpr (EPI == 1 || EPI == 2) {
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int64_t gmc = min(wm0 + i * 32 + it * 8 + (lane >> 3), p.m - 1);
-        const int64_t gnc = min(gn, p.n - 8);
-        if constexpr (EPI == 1) {
-          ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x) + gmc * p.ep.ldx + gnc);
-          ex0[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x0) + gmc * p.ep.ldx + gnc);
-        } else {
-          ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.r) + gmc * p.ep.ldr + gnc);
-        }
+    for (int r = 0; r < 16; ++r)
+      stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc2[j][r];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private staging: no workgroup barrier
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int er = it * 8 + (lane >> 3);
+    const int64_t gm = row0 + er;
+    if (gm >= p.m || gn >= p.n) continue;
+    float v[8];
+    const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
+    const float4 v1 = *reinterpret_cast<const float4*>(stage + er * SST + ec + 4);
+    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    if constexpr (EPI == 1) {
+      if (p.ep.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.ep.bias + gn);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.ep.bias + gn + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
       }
-    }
+      if (p.ep.act != KRS_ACT_NONE) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < 8; ++q) v[q] = apply_act(p.ep.act, v[q]);
+      }
+      if (p.ep.u_out) store8(p.ep.u_out, KRS_BF16, gm * p.ep.ldu + gn, v);
+      float xv[8], x0v[8];
+      unpack_bf16x8(o.ex[it], xv);
+      unpack_bf16x8(o.ex0[it], x0v);
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc[i][j][r];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private staging: no workgroup barrier
+      for (int q = 0; q < 8; ++q) v[q] = x0v[q] * (v[q] + p.ep.diag_scale * xv[q]) + xv[q];
+      store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
+    } else if constexpr (EPI == 2) {
+      float rv[8];
+      unpack_bf16x8(o.ex[it], rv);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int er = it * 8 + (lane >> 3);
-      const int64_t gm = wm0 + i * 32 + er;
-      if (gm >= p.m || gn >= p.n) continue;
-      float v[8];
-      const float4 v0 = *reinterpret_cast<const float4*>(stage + er * SST + ec);
-      const float4 v1 = *reinterpret_cast<const float4*>(stage + er * SST + ec + 4);
-      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-      if constexpr (EPI == 1) {
-        if (p.ep.bias) {
-          const float4 b0 = *reinterpret_cast<const float4*>(p.ep.bias + gn);
-          const float4 b1 = *reinterpret_cast<const float4*>(p.ep.bias + gn + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (p.ep.act != KRS_ACT_NONE) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) v[q] = apply_act(p.ep.act, v[q]);
-        }
-        if (p.ep.u_out) store8(p.ep.u_out, KRS_BF16, gm * p.ep.ldu + gn, v);
-        float xv[8], x0v[8];
-        unpack_bf16x8(ex[it], xv);
-        unpack_bf16x8(ex0[it], x0v);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = x0v[q] * (v[q] + p.ep.diag_scale * xv[q]) + xv[q];
-        store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
-      } else if constexpr (EPI == 2) {
-        float rv[8];
-        unpack_bf16x8(ex[it], rv);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
-        store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
-      } else if (p.splits > 1) {
-        float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
-        if (p.ep_vec) {
-          *reinterpret_cast<float4*>(dst) = v0;
-          *reinterpret_cast<float4*>(dst + 4) = v1;
-        } else {
-          for (int q = 0; q < 8 && gn + q < p.n; ++q) dst[q] = v[q];
-        }
-      } else if (p.ep_vec) {
-        epilogue_store_vec8(p, gm, gn, v);
+      for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
+      store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
+    } else if (p.splits > 1) {
+      float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
+      if (p.ep_vec) {
+        *reinterpret_cast<float4*>(dst) = v0;
+        *reinterpret_cast<float4*>(dst + 4) = v1;
       } else {
-        for (int q = 0; q < 8 && gn + q < p.n; ++q) epilogue_store(p, gm, gn + q, v[q]);
+        for (int q = 0; q < 8 && gn + q < p.n; ++q) dst[q] = v[q];
       }
+    } else if (p.ep_vec) {
+      epilogue_store_vec8(p, gm, gn, v);
+    } else {
+      for (int q = 0; q < 8 && gn + q < p.n; ++q) epilogue_store(p, gm, gn + q, v[q]);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// a wave's 64x64 block of C (two chunks)
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_wave(const GemmParams& p, f32x16 (&acc)[2][2], float* stage, int64_t wm0,
+                                                   int64_t wn0, int split) {
+  EpiOperands o0, o1;
+  epi_prefetch<EPI>(p, o0, wm0, wn0);
+  epi_prefetch<EPI>(p, o1, wm0 + 32, wn0);
+  epi_process<EPI>(p, acc[0], o0, stage, wm0, wn0, split);
+  epi_process<EPI>(p, acc[1], o1, stage, wm0 + 32, wn0, split);
+}
+
+// a wave's 128x64 block of C (four chunks), two chunks of operands in flight
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_wave128(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
+                                                      int64_t wm0, int64_t wn0, int split) {
+  EpiOperands o0, o1;
+  epi_prefetch<EPI>(p, o0, wm0, wn0);
+  epi_prefetch<EPI>(p, o1, wm0 + 32, wn0);
+  epi_process<EPI>(p, acc[0][0], o0, stage, wm0, wn0, split);
+  epi_prefetch<EPI>(p, o0, wm0 + 64, wn0);
+  epi_process<EPI>(p, acc[0][1], o1, stage, wm0 + 32, wn0, split);
+  epi_prefetch<EPI>(p, o1, wm0 + 96, wn0);
+  epi_process<EPI>(p, acc[1][0], o0, stage, wm0 + 64, wn0, split);
+  epi_process<EPI>(p, acc[1][1], o1, stage, wm0 + 96, wn0, split);
 }
 
 // 128x128 workgroup tile, 4 waves as 2x2
@@ -650,10 +685,7 @@ __global__ __launch_bounds__(512) void gemm_glds256_kernel(const GemmParams p) {
     __syncthreads();                                   // and every wave is done with tile t
   }
   float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  // two explicit calls: a loop over `h` is left rolled for the large general epilogue and would
-  // index the accumulators dynamically
-  gemm_epilogue_wave<EPI>(p, acc[0], stage, m0 + wm * 128, n0 + wn * 64, 0);
-  gemm_epilogue_wave<EPI>(p, acc[1], stage, m0 + wm * 128 + 64, n0 + wn * 64, 0);
+  gemm_epilogue_wave128<EPI>(p, acc, stage, m0 + wm * 128, n0 + wn * 64, 0);
 }
 
 // Weight-gradient shapes in bf16 (C = A^T B with BOTH operands K-strided in HBM: activations
@@ -874,8 +906,7 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
     __syncthreads();                                   // and every wave is done with tile t
   }
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  gemm_epilogue_wave<EPI>(p, acc[0], stage_f, m0 + wm * 128, n0 + wn * 64, split);
-  gemm_epilogue_wave<EPI>(p, acc[1], stage_f, m0 + wm * 128 + 64, n0 + wn * 64, split);
+  gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
 }
 
 // fixed-order reduction of the split-K slabs + epilogue
