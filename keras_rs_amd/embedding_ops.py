@@ -69,7 +69,8 @@ class FusedBags:
         return dev
 
     def feature_desc(self, batch: int, hots: Sequence[int] | None, device) -> torch.Tensor:
-        key = (batch, None if hots is None else tuple(hots), str(device))
+        # CSR form (hots is None): the descriptors carry no batch-dependent field
+        key = (batch if hots is not None else None, None if hots is None else tuple(hots), str(device))
         dev = self._feat_cache.get(key)
         if dev is None:
             arr = np.zeros(len(self.features), dtype=L.FEATURE_DT)

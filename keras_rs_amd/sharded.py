@@ -7,16 +7,21 @@ r % N at local row r // N.  Each rank keeps ONE stacked buffer [T * Vloc, D] (Vl
 ceil(V_max / N)) so that a lookup anywhere in the group is `t * Vloc + r // N`.
 
 Per step (one process per GPU, torch.distributed over RCCL/xGMI; xGMI is point-to-point, so the
-exchange is an all-to-all whose pairs each use their own link):
+exchange is an all-to-all whose pairs each use their own link).  What crosses the links is one
+PARTIALLY POOLED vector per (bag, owner) pair that has lookups -- not one vector per lookup: with
+the ml_perf bag lengths (214 lookups per sample) that is 41 vectors per sample at N = 2 and 79 at
+N = 8.
   fwd  1. composite id c = t*Vloc*N + r  (c % N = owner, c // N = stacked local row)
-       2. K5 MOD-bucketise c (stable), all-to-all of bucket counts, all-to-all-v of local rows
-       3. owner: K1 row gather on its shard           -> one vector per lookup
-       4. all-to-all-v of the vectors back to the sample's home rank
-       5. home: K1 again, with the returned vectors as the "table" and the inverse bucket
-          permutation as ids -> weighted pooling (sum / mean / sqrtn) per bag
-  bwd  mirror image: K2 (dense form) on the returned-vector "table" gives d(vector) per lookup,
-       all-to-all-v to the owners, K2 fused SGD / Adagrad on the shard.  Every row has exactly
-       one owner, so table gradients need no cross-GPU reduction.
+       2. K5 MOD-bucketise c (stable: inside a bucket the lookups stay in bag order); runs of equal
+          bag inside a bucket are the SEGMENTS; combiner scale (mean / sqrtn) and user weights are
+          folded into one weight per lookup; all-to-all of (lookup, segment) counts, all-to-all-v of
+          local rows, segment lengths and weights
+       3. owner: K1 in CSR form over the received segments -> one partial vector per segment
+       4. all-to-all-v of the partial vectors back to the sample's home rank
+       5. home: K1 again, with the partials as the "table": every bag sums its <= N partials
+  bwd  mirror image: d(partial) of a segment is its bag's output gradient (a row gather),
+       all-to-all-v to the owners, K2 fused SGD / Adagrad on the shard in CSR form.  Every row has
+       exactly one owner, so table gradients need no cross-GPU reduction.
 
 The exchange logic is independent of the compute kernels: `kernels` is an object with the four
 methods of HipShardKernels.  The product default runs the HIP kernels; the CPU/gloo tests in
@@ -60,36 +65,40 @@ class HipShardKernels:
         return D.mod_bucketize(ids, n_shards)
 
     def gather_rows(self, table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        """table[rows] (K1 one-hot form).  `table` is a per-step tensor here (an output gradient), so its
+        descriptors are not cached."""
+        from keras_rs_amd.embedding_ops import FusedBags
+
         n = rows.numel()
         if n == 0:
             return torch.empty((0, table.shape[1]), dtype=table.dtype, device=table.device)
-        out, _ = self._bags_for(table, None, 0.0).forward(rows, n, hots=(1,))
+        out, _ = FusedBags([table], [(0, "sum", 0)]).forward(rows, n, hots=(1,))
         return out
 
-    def pool(self, vectors: torch.Tensor, slot_of_pos: torch.Tensor, feats, batch, hots, offsets, weights, out_dtype):
+    def pool_segments(self, table, rows, offsets, weights, out_dtype):
+        """Owner side: one vector per CSR segment of `rows`, sum of weight * table[row]."""
+        n_seg = offsets.numel() - 1
+        if n_seg == 0:
+            return torch.empty((0, table.shape[1]), dtype=out_dtype, device=table.device)
+        out, _ = self._bags_for(table, None, 0.0).forward(rows, n_seg, offsets=offsets, weights=weights,
+                                                          out_dtype=out_dtype)
+        return out
+
+    def pool(self, vectors, ids, feats, batch, offsets, out_dtype):
+        """Home side: bags (feature-major CSR over `ids`) summed out of `vectors` into [batch, n_feats*dim]."""
         from keras_rs_amd.embedding_ops import FusedBags
 
-        fb = FusedBags([vectors], feats)
-        out, scale = fb.forward(slot_of_pos, batch, hots=hots, offsets=offsets, weights=weights,
-                                out_dtype=out_dtype, want_scale=True)
-        return out, scale
+        out, _ = FusedBags([vectors], feats).forward(ids, batch, offsets=offsets, out_dtype=out_dtype)
+        return out
 
-    def pool_backward(self, n_rows, dim, dtype, slot_of_pos, feats, batch, hots, offsets, weights, scale, grad):
-        from keras_rs_amd.embedding_ops import FusedBags
-
-        dummy = torch.empty((n_rows, dim), dtype=dtype, device=grad.device)
-        fb = FusedBags([dummy], feats)
-        ws = fb.plan_backward(slot_of_pos, batch, hots=hots, offsets=offsets)
-        (dv,) = fb.backward_dense(ws, grad, batch, slot_of_pos.numel(), hots=hots, weights=weights, bag_scale=scale)
-        return dv.to(dtype)
-
-    def apply_rows(self, table, slot, rows, grads, lr, kind):
-        n = rows.numel()
-        if n == 0:
+    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind):
+        """Owner side: fused optimizer step; lookup i of segment s carries weights[i] * seg_grads[s]."""
+        n_seg = offsets.numel() - 1
+        if rows.numel() == 0 or n_seg == 0:
             return
         fb = self._bags_for(table, slot, lr)
-        ws = fb.plan_backward(rows, n, hots=(1,))
-        fb.backward_fused(kind, ws, grads, n, n, hots=(1,))
+        ws = fb.plan_backward(rows, n_seg, offsets=offsets)
+        fb.backward_fused(kind, ws, seg_grads, n_seg, rows.numel(), weights=weights)
 
 
 class _ShardedLookupFn(torch.autograd.Function):
@@ -261,34 +270,89 @@ class ShardedDistributedEmbedding(base.Layer):
                                    input_split_sizes=send_counts, group=self._pg)
         return recv
 
+    def _bag_tables(self, batch, hots, device):
+        """Per (batch, hots): bag of every lookup position (feature-major), combiner code of every bag."""
+        key = ("bags", batch, hots, str(device))
+        got = self._offset_cache.get(key)
+        if got is None:
+            bag = torch.cat([f * batch + torch.arange(batch, dtype=torch.int32).repeat_interleave(h)
+                             for f, h in enumerate(hots)])
+            comb = torch.tensor([{"sum": 0, "mean": 1, "sqrtn": 2}[c] for c in self._combiners],
+                                dtype=torch.int32).repeat_interleave(batch)
+            got = self._offset_cache[key] = (bag.to(device), comb.to(device))
+        return got
+
+    def _lookup_weights(self, weights, bag_of_pos, comb_of_bag, n_bags):
+        """User weight x combiner scale per lookup (mean: 1 / sum w, sqrtn: 1 / sqrt(sum w^2), both
+        divide_no_nan: embed_reduce.py:236-262), or None when every bag is a plain sum."""
+        if weights is None and all(c == "sum" for c in self._combiners):
+            return None
+        w = torch.ones(bag_of_pos.numel(), dtype=torch.float32, device=bag_of_pos.device) if weights is None \
+            else weights.float()
+        idx = bag_of_pos.long()
+        s1 = torch.zeros(n_bags, dtype=torch.float32, device=w.device).index_add_(0, idx, w)
+        s2 = torch.zeros(n_bags, dtype=torch.float32, device=w.device).index_add_(0, idx, w * w)
+        inv = lambda d: torch.where(d != 0, 1.0 / d, torch.zeros_like(d))  # noqa: E731
+        scale = torch.where(comb_of_bag == 1, inv(s1), torch.where(comb_of_bag == 2, inv(s2.sqrt()),
+                                                                   torch.ones_like(s1)))
+        return w * scale[idx]
+
     def _forward_impl(self, ids, batch, hots, offsets, weights):
-        k, n = self.kernels, self.world
-        comp = ids + self._composite_offsets(batch, hots, ids.dtype, ids.device)
+        if offsets is not None:
+            raise NotImplementedError("ShardedDistributedEmbedding: dense [batch, hot] inputs only")
+        k, n, dev = self.kernels, self.world, ids.device
+        nnz, n_bags = ids.numel(), batch * len(hots)
+        comp = ids + self._composite_offsets(batch, hots, ids.dtype, dev)
         local_rows, perm, counts = k.bucketize(comp, n)
-        # bucket sizes -> every rank learns how much it receives (tiny all-to-all + one host sync)
-        recv_counts_t = torch.empty_like(counts)
+        bag_of_pos, comb_of_bag = self._bag_tables(batch, hots, dev)
+        w_eff = self._lookup_weights(weights, bag_of_pos, comb_of_bag, n_bags)
+        # segments: runs of one bag inside a bucket (the bucketise is stable, so bags ascend in a bucket)
+        order = perm.long()
+        bag_b = bag_of_pos[order]
+        ends = torch.cumsum(counts, 0)
+        head = torch.ones(nnz, dtype=torch.bool, device=dev)
+        if nnz > 1:
+            head[1:] = bag_b[1:] != bag_b[:-1]
+            starts = ends - counts
+            head[starts[(counts > 0) & (starts < nnz)]] = True
+        head_idx = torch.nonzero(head).squeeze(1)                                   # first lookup of every segment
+        seg_bag = bag_b[head_idx]
+        seg_len = torch.diff(head_idx, append=torch.tensor([nnz], device=dev)).to(torch.int32)
+        seg_counts = torch.bincount(torch.bucketize(head_idx, ends, right=True), minlength=n)
+        # sizes: every rank learns how many lookups / segments it receives (one tiny all-to-all + host sync)
+        mine = torch.stack([counts.to(torch.int64), seg_counts.to(torch.int64)], dim=1).contiguous()   # [n, 2]
+        theirs = torch.empty_like(mine)
         if n > 1:
-            dist.all_to_all_single(recv_counts_t, counts, group=self._pg)
+            dist.all_to_all_single(theirs, mine, group=self._pg)
         else:
-            recv_counts_t.copy_(counts)
-        send_counts = counts.tolist()
-        recv_counts = recv_counts_t.tolist()
-        recv_rows = self._a2a(local_rows, send_counts, recv_counts)             # owner side: rows to serve
-        vectors = k.gather_rows(self.shard.data, recv_rows)                     # [n_recv, D]
-        back = self._a2a(vectors, recv_counts, send_counts)                     # home side, bucket order
-        slot_of_pos = torch.empty_like(perm)
-        slot_of_pos[perm.long()] = torch.arange(perm.numel(), dtype=perm.dtype, device=perm.device)
-        feats = [(0, c, i * self.dim) for i, c in enumerate(self._combiners)]
-        out, scale = k.pool(back, slot_of_pos, feats, batch, hots, offsets, weights, self.compute_dtype)
-        saved = dict(batch=batch, hots=hots, offsets=offsets, weights=weights, scale=scale, feats=feats,
-                     slot_of_pos=slot_of_pos, send_counts=send_counts, recv_counts=recv_counts,
-                     recv_rows=recv_rows, n_back=back.shape[0], vec_dtype=back.dtype,
-                     out_meta=(out.dtype, out.device))
+            theirs.copy_(mine)
+        send_counts, send_segs = mine[:, 0].tolist(), mine[:, 1].tolist()
+        recv_counts, recv_segs = theirs[:, 0].tolist(), theirs[:, 1].tolist()
+        # to the owners: rows, segment lengths, weights (bucket order)
+        recv_rows = self._a2a(local_rows, send_counts, recv_counts)
+        recv_len = self._a2a(seg_len, send_segs, recv_segs)
+        recv_w = None if w_eff is None else self._a2a(w_eff[order], send_counts, recv_counts)
+        recv_off = torch.zeros(recv_len.numel() + 1, dtype=torch.int32, device=dev)
+        recv_off[1:] = torch.cumsum(recv_len, 0)
+        partial = k.pool_segments(self.shard.data, recv_rows, recv_off, recv_w, self.compute_dtype)
+        back = self._a2a(partial, recv_segs, send_segs)                           # home side, segment order
+        # every bag sums its partials: segments sorted by bag -> feature-major CSR over segment ids
+        seg_sorted = torch.argsort(seg_bag, stable=True).to(torch.int32)
+        bag_off = torch.zeros(n_bags + 1, dtype=torch.int32, device=dev)
+        bag_off[1:] = torch.cumsum(torch.bincount(seg_bag, minlength=n_bags), 0)
+        feats = [(0, "sum", i * self.dim) for i in range(len(self._combiners))]
+        out = k.pool(back, seg_sorted, feats, batch, bag_off, self.compute_dtype)
+        saved = dict(batch=batch, seg_bag=seg_bag, send_segs=send_segs, recv_segs=recv_segs, recv_rows=recv_rows,
+                     recv_off=recv_off, recv_w=recv_w, out_meta=(out.dtype, out.device))
         return out, saved
 
     def _backward_impl(self, g, s):
-        k = self.kernels
-        dvec = k.pool_backward(s["n_back"], self.dim, s["vec_dtype"], s["slot_of_pos"], s["feats"], s["batch"],
-                               s["hots"], s["offsets"], s["weights"], s["scale"], g)
-        drows = self._a2a(dvec, s["send_counts"], s["recv_counts"])             # to the owners
-        k.apply_rows(self.shard.data, self._slot, s["recv_rows"], drows, self._lr, self._opt_kind)
+        k, n_feats, batch = self.kernels, len(self._combiners), s["batch"]
+        # d(partial of a segment) = the output gradient of its bag: rows of g viewed as [batch * n_feats, dim]
+        g = g.contiguous()
+        seg_bag = s["seg_bag"]
+        rows = ((seg_bag % batch) * n_feats + seg_bag // batch).to(torch.int32)
+        dpart = k.gather_rows(g.view(batch * n_feats, self.dim), rows)
+        dseg = self._a2a(dpart, s["send_segs"], s["recv_segs"])                   # to the owners
+        k.apply_segments(self.shard.data, self._slot, s["recv_rows"], s["recv_off"], s["recv_w"], dseg, self._lr,
+                         self._opt_kind)

@@ -16,6 +16,8 @@ from oracle import krs_oracle as ko  # noqa: E402
 
 
 class OracleShardKernels:
+    """The five kernel calls of keras_rs_amd.sharded on the CPU oracle."""
+
     def bucketize(self, ids, n):
         l, p, c = ko.mod_bucketize(ids.numpy(), n)
         return torch.from_numpy(l), torch.from_numpy(p), torch.from_numpy(c)
@@ -24,32 +26,35 @@ class OracleShardKernels:
         t = table.detach().numpy()
         return torch.from_numpy(t[rows.numpy()].copy()) if rows.numel() else torch.zeros((0, t.shape[1]))
 
-    def pool(self, vectors, slot_of_pos, feats, batch, hots, offsets, weights, out_dtype):
+    def pool_segments(self, table, rows, offsets, weights, out_dtype):
+        t = np.ascontiguousarray(table.detach().numpy())
+        n_seg = offsets.numel() - 1
+        out = np.zeros((max(n_seg, 1), t.shape[1]), np.float32)
+        if n_seg:
+            f = ko.make_features([0], ["sum"], [0])
+            ko.embed_bag_fwd_raw(ko.make_tables([t]), ko.F32, f, rows.numpy(), offsets.numpy(),
+                                 None if weights is None else weights.numpy(), n_seg, t.shape[1], out)
+        return torch.from_numpy(out[:n_seg])
+
+    def pool(self, vectors, ids, feats, batch, offsets, out_dtype):
         v = np.ascontiguousarray(vectors.numpy())
         if v.shape[0] == 0:
             v = np.zeros((1, v.shape[1]), np.float32)
-        tabs = ko.make_tables([v])
-        f = ko.make_features([0] * len(feats), [c for _, c, _ in feats], [col for _, _, col in feats], hots=hots,
-                             batch=batch)
+        f = ko.make_features([0] * len(feats), [c for _, c, _ in feats], [col for _, _, col in feats])
         out = np.zeros((batch, len(feats) * v.shape[1]), np.float32)
-        scale = np.zeros(len(feats) * batch, np.float32)
-        ko.embed_bag_fwd_raw(tabs, ko.F32, f, slot_of_pos.numpy(), None,
-                             None if weights is None else weights.numpy(), batch, v.shape[1], out, scale)
-        return torch.from_numpy(out), torch.from_numpy(scale)
+        ko.embed_bag_fwd_raw(ko.make_tables([v]), ko.F32, f, ids.numpy(), offsets.numpy(), None, batch, v.shape[1], out)
+        return torch.from_numpy(out)
 
-    def pool_backward(self, n_rows, dim, dtype, slot_of_pos, feats, batch, hots, offsets, weights, scale, grad):
-        de = np.zeros((max(n_rows, 1), dim), np.float32)
-        f = ko.make_features([0] * len(feats), [c for _, c, _ in feats], [col for _, _, col in feats], hots=hots,
-                             batch=batch)
-        ko.embed_bag_bwd_dense(ko.make_tables([de]), f, slot_of_pos.numpy(), None,
-                               None if weights is None else weights.numpy(), scale.numpy(),
-                               np.ascontiguousarray(grad.numpy()), batch, dim)
-        return torch.from_numpy(de[:n_rows])
-
-    def apply_rows(self, table, slot, rows, grads, lr, kind):
+    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind):
         t = table.numpy()
+        n_seg = offsets.numel() - 1
+        if rows.numel() == 0 or n_seg == 0:
+            return
         dense = np.zeros_like(t)
-        np.add.at(dense, rows.numpy(), grads.numpy())
+        f = ko.make_features([0], ["sum"], [0])
+        ko.embed_bag_bwd_dense(ko.make_tables([dense]), f, rows.numpy(), offsets.numpy(),
+                               None if weights is None else weights.numpy(), None,
+                               np.ascontiguousarray(seg_grads.numpy()), n_seg, t.shape[1])
         touched = np.zeros(t.shape[0], np.uint8)
         touched[rows.numpy()] = 1
         ko.apply_optimizer(t, None if slot is None else slot.numpy(), dense, touched, lr, kind)
@@ -62,6 +67,7 @@ def main():
     from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
     kind = sys.argv[1]
+    use_w = len(sys.argv) < 3 or sys.argv[2] == "w"
     opt = kl.SGD(0.1) if kind == "sgd" else kl.Adagrad(0.1, 0.1)
     V, D, B = [37, 10, 64], 8, 6
     combs = ["sum", "mean", "sqrtn", "sum"]
@@ -85,8 +91,9 @@ def main():
 
     rng_r = np.random.default_rng(100 + rank)  # every rank has its own batch
     ids = {f"f{i}": rng_r.integers(0, V[tix[i]], (B, hots[i])).astype(np.int32) for i in range(4)}
-    w = {f"f{i}": rng_r.uniform(0.1, 1, (B, hots[i])).astype(np.float32) for i in range(4)}
-    out = layer(ids, w)
+    w = {f"f{i}": rng_r.uniform(0.1, 1, (B, hots[i])).astype(np.float32) if use_w
+         else np.ones((B, hots[i]), np.float32) for i in range(4)}
+    out = layer(ids, w if use_w else None)
     g = {k: torch.from_numpy(rng_r.uniform(0, 1, (B, D)).astype(np.float32)) for k in out}
     sum((o * g[k]).sum() for k, o in out.items()).backward()
 

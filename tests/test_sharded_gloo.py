@@ -17,11 +17,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
-def test_sharded_embedding_world2_matches_unsharded_oracle(kind):
+@pytest.mark.parametrize("kind,weighted,world", [("sgd", "w", 2), ("adagrad", "w", 2), ("adagrad", "now", 2),
+                                                 ("sgd", "now", 3)])
+def test_sharded_embedding_matches_unsharded_oracle(kind, weighted, world):
+    # weighted: user weights on every feature; "now": none (mean / sqrtn scales are still folded in)
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "_sharded_worker.py"), kind]
+           os.path.join(ROOT, "tests", "_sharded_worker.py"), kind, weighted]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0 and f"SHARDED_OK {kind}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
