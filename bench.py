@@ -102,7 +102,7 @@ class Model(torch.nn.Module):
         if world > 1 or a.force_sharded:
             from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
-            self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16")
+            self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=a.dim)
         else:
             # the dense feature's 128 columns are reserved in front of the 26 embeddings: the lookups land
             # directly in the [B, 3456] interaction input (concat-free layout)

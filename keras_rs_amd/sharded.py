@@ -84,11 +84,12 @@ class HipShardKernels:
                                                           out_dtype=out_dtype)
         return out
 
-    def pool(self, vectors, ids, feats, batch, offsets, out_dtype):
-        """Home side: bags (feature-major CSR over `ids`) summed out of `vectors` into [batch, n_feats*dim]."""
+    def pool(self, vectors, ids, feats, batch, offsets, out_dtype, out=None):
+        """Home side: bags (feature-major CSR over `ids`) summed out of `vectors` into [batch, n_feats*dim]
+        (`out`: a row-major buffer of that shape, possibly a column window of a wider one)."""
         from keras_rs_amd.embedding_ops import FusedBags
 
-        out, _ = FusedBags([vectors], feats).forward(ids, batch, offsets=offsets, out_dtype=out_dtype)
+        out, _ = FusedBags([vectors], feats).forward(ids, batch, offsets=offsets, out=out, out_dtype=out_dtype)
         return out
 
     def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind):
@@ -102,20 +103,24 @@ class HipShardKernels:
 
 
 class _ShardedLookupFn(torch.autograd.Function):
+    """Outputs: the slab [B, lead + n*dim] (see DistributedEmbedding.slab_lead_cols) and its n feature views."""
+
     @staticmethod
     def forward(ctx, layer, ids, batch, hots, offsets, weights, anchor):
-        out, saved = layer._forward_impl(ids, batch, hots, offsets, weights)
+        from keras_rs_amd.autograd import _split_columns
+
+        slab, saved = layer._forward_impl(ids, batch, hots, offsets, weights)
         ctx.layer, ctx.saved = layer, saved
-        n = len(layer._paths)
-        return tuple(out[:, i * layer.dim:(i + 1) * layer.dim] for i in range(n))
+        return (slab,) + _split_columns(slab, len(layer._paths), layer.dim, layer.slab_lead_cols)
 
     @staticmethod
-    def backward(ctx, *gs):
+    def backward(ctx, g_slab, *gs):
         layer = ctx.layer
-        from keras_rs_amd.autograd import _gather_feature_grads
+        from keras_rs_amd.autograd import _sum_slab_and_feature_grads
 
         out_dtype, device = ctx.saved["out_meta"]
-        g = _gather_feature_grads(gs, ctx.saved["batch"], layer.dim, out_dtype, device)
+        g = _sum_slab_and_feature_grads(g_slab, gs, layer.slab_lead_cols, ctx.saved["batch"], len(layer._paths),
+                                        layer.dim, out_dtype, device)
         layer._backward_impl(g, ctx.saved)
         return (None, None, None, None, None, None, torch.zeros((), device=device))
 
@@ -128,8 +133,9 @@ class ShardedDistributedEmbedding(base.Layer):
     'sparsecore' placement.  call(inputs) takes raw {name: ids} or the result of preprocess()."""
 
     def __init__(self, feature_configs: dict[str, FeatureConfig], *, process_group=None, kernels=None,
-                 **kwargs: Any):
+                 slab_lead_cols: int = 0, **kwargs: Any):
         super().__init__(**kwargs)
+        self.slab_lead_cols = int(slab_lead_cols)  # as DistributedEmbedding: room for layers.concat_features
         self._pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -257,8 +263,10 @@ class ShardedDistributedEmbedding(base.Layer):
             inputs = self.preprocess(inputs, weights, training)
         pre = inputs["preprocessed_inputs_per_placement"]["sparsecore"]
         fi = pre["inputs"]
-        outs = _ShardedLookupFn.apply(self, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], pre.get("weights"),
-                                      self._anchor)
+        slab, *outs = _ShardedLookupFn.apply(self, fi["ids"], fi["batch"], fi["hots"], fi["offsets"],
+                                             pre.get("weights"), self._anchor)
+        for i, o in enumerate(outs):
+            o._krs_slab = (slab, self.slab_lead_cols + i * self.dim, len(outs), self.slab_lead_cols)
         return {p: o for p, o in zip(self._paths, outs)}
 
     def _a2a(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
@@ -341,10 +349,12 @@ class ShardedDistributedEmbedding(base.Layer):
         bag_off = torch.zeros(n_bags + 1, dtype=torch.int32, device=dev)
         bag_off[1:] = torch.cumsum(torch.bincount(seg_bag, minlength=n_bags), 0)
         feats = [(0, "sum", i * self.dim) for i in range(len(self._combiners))]
-        out = k.pool(back, seg_sorted, feats, batch, bag_off, self.compute_dtype)
+        lead = self.slab_lead_cols
+        slab = torch.empty((batch, lead + len(feats) * self.dim), dtype=back.dtype, device=dev)
+        k.pool(back, seg_sorted, feats, batch, bag_off, self.compute_dtype, out=slab[:, lead:])
         saved = dict(batch=batch, seg_bag=seg_bag, send_segs=send_segs, recv_segs=recv_segs, recv_rows=recv_rows,
-                     recv_off=recv_off, recv_w=recv_w, out_meta=(out.dtype, out.device))
-        return out, saved
+                     recv_off=recv_off, recv_w=recv_w, out_meta=(slab.dtype, slab.device))
+        return slab, saved
 
     def _backward_impl(self, g, s):
         k, n_feats, batch = self.kernels, len(self._combiners), s["batch"]

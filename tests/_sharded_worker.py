@@ -36,14 +36,17 @@ class OracleShardKernels:
                                  None if weights is None else weights.numpy(), n_seg, t.shape[1], out)
         return torch.from_numpy(out[:n_seg])
 
-    def pool(self, vectors, ids, feats, batch, offsets, out_dtype):
+    def pool(self, vectors, ids, feats, batch, offsets, out_dtype, out=None):
         v = np.ascontiguousarray(vectors.numpy())
         if v.shape[0] == 0:
             v = np.zeros((1, v.shape[1]), np.float32)
         f = ko.make_features([0] * len(feats), [c for _, c, _ in feats], [col for _, _, col in feats])
-        out = np.zeros((batch, len(feats) * v.shape[1]), np.float32)
-        ko.embed_bag_fwd_raw(ko.make_tables([v]), ko.F32, f, ids.numpy(), offsets.numpy(), None, batch, v.shape[1], out)
-        return torch.from_numpy(out)
+        res = np.zeros((batch, len(feats) * v.shape[1]), np.float32)
+        ko.embed_bag_fwd_raw(ko.make_tables([v]), ko.F32, f, ids.numpy(), offsets.numpy(), None, batch, v.shape[1], res)
+        if out is None:
+            return torch.from_numpy(res)
+        out.copy_(torch.from_numpy(res))
+        return out
 
     def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind):
         t = table.numpy()
@@ -81,7 +84,7 @@ def main():
         feats[f"f{i}"] = kl.FeatureConfig(f"f{i}", tc, (B, hots[i]), (B, D))
     for i, tc in enumerate(tcs):
         tc.combiner = combs[i]
-    layer = ShardedDistributedEmbedding(feats, kernels=OracleShardKernels(), device="cpu")
+    layer = ShardedDistributedEmbedding(feats, kernels=OracleShardKernels(), device="cpu", slab_lead_cols=3 * rank)
     rng = np.random.default_rng(7)
     full = {f"t{i}": rng.uniform(-1, 1, (V[i], D)).astype(np.float32) for i in range(3)}
     layer.set_embedding_tables(full)

@@ -404,8 +404,9 @@ def test_embedding_layer_and_readme_quickstart_shape():
 
 @pytest.mark.parametrize("optimizer", ["sgd", "adagrad"])
 def test_sharded_layer_world1_on_hip_matches_unsharded_layer(optimizer):
-    """The sharded path (bucketise -> gather -> pool, K2 dense -> fused apply) on the HIP kernels,
-    degenerate world of 1: same outputs and same updated tables as DistributedEmbedding."""
+    """The sharded path (bucketise -> owner-side partial pooling -> home-side sum, and the CSR-form fused
+    apply) on the HIP kernels, degenerate world of 1: same outputs and same updated tables as
+    DistributedEmbedding, also through layers.concat_features with a reserved dense slot."""
     kl = _layers()
     from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
@@ -426,11 +427,15 @@ def test_sharded_layer_world1_on_hip_matches_unsharded_layer(optimizer):
     w = {f"f{i}": rng.uniform(0.1, 1, (B, hots[i])).astype(np.float32) for i in range(3)}
     g = {f"f{i}": torch.rand(B, D, device=DEV) for i in range(3)}
     results = []
-    for layer in (make(kl.DistributedEmbedding), make(ShardedDistributedEmbedding)):
+    dense = torch.rand(B, 4, device=DEV)
+    gx = torch.rand(B, 4 + 3 * D, device=DEV)
+    for layer in (make(kl.DistributedEmbedding), make(ShardedDistributedEmbedding, slab_lead_cols=4)):
         layer.build(None)
         layer.set_embedding_tables(full)
         out = layer(ids, w)
-        sum((out[k] * g[k]).sum() for k in out).backward()
+        x0 = kl.concat_features([dense] + [out[k] for k in out])
+        assert torch.equal(x0, torch.cat([dense] + [out[k] for k in out], dim=-1))
+        (sum((out[k] * g[k]).sum() for k in out) + (x0 * gx).sum()).backward()
         results.append(({k: v.detach().cpu().numpy() for k, v in out.items()},
                         {k: v.cpu().numpy() for k, v in layer.get_embedding_tables().items()}))
     for k in results[0][0]:
