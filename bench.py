@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the MOD-sharded embedding path even at N = 1 (dry run of the multi-GPU code)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2048)
+    ap.add_argument("--full-model", action="store_true",
+                    help="also time one training step of the whole DLRM-DCN-v2 model (examples/dlrm_dcn_v2.py: bottom "
+                         "MLP, embeddings, 3 cross layers, top MLP, BCE), reported under `full_model`; never `value`")
     ap.add_argument("--host-inputs", type=int, default=0, metavar="WORKERS",
                     help="also time the step with ids that start in HOST memory, fed through "
                          "keras_rs_amd.data.ThreadedDataLoader with this many loader threads (PCIe-inclusive rate, "
@@ -356,6 +359,29 @@ def main():
         host = {"ms_per_step": el_h / a.steps * 1e3, "value": a.batch * sum(primary) / (el_h / a.steps),
                 "unit": "lookups/s", "loader_threads": a.host_inputs, "id_bytes_per_step": id_bytes,
                 "note": "ids generated on the host, ThreadedDataLoader -> preprocess -> pinned upload; PCIe-inclusive"}
+    full = None
+    if a.full_model and world == 1 and not a.force_sharded:
+        del model  # frees the first model's tables before the second set is built
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import dlrm_dcn_v2 as ex
+
+        fm = ex.build_model(b_local, a.vocab, primary, embedding_dim=a.dim, projection=a.projection,
+                            cross_layers=a.cross_layers)
+        x, y = ex.synthetic_batch(b_local, 13, a.vocab, primary, dev)
+        x["large_emb_inputs"] = fm.embedding_layer.preprocess(x["large_emb_inputs"])
+        box = [None]
+        for _ in range(max(a.warmup, 2)):
+            ex.train_step(fm, box, x, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            ex.train_step(fm, box, x, y)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        full = {"ms_per_step": dt * 1e3, "value": a.batch * sum(primary) / dt, "unit": "lookups/s",
+                "model": "bottom MLP 13-512-256-128 (relu), 26 embeddings, 3 x FeatureCross(3456, 512), top MLP "
+                         "3456-1024-1024-512-256-1 (relu / sigmoid), BCE, Adagrad everywhere"}
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -404,6 +430,8 @@ def main():
     out["also"] = second
     if host is not None:
         out["host_inputs"] = host
+    if full is not None:
+        out["full_model"] = full
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a, primary)
     print(json.dumps(out))

@@ -114,6 +114,46 @@ class CrossLayerFn(torch.autograd.Function):
                 dbias if has_bias else None, None, None, None)
 
 
+class DenseFn(torch.autograd.Function):
+    """y = act(x @ K + b): the Dense layers of the DLRM bottom / top MLPs
+    (examples/ml_perf/model.py:214-262) on krs_gemm with the bias + activation epilogue fused.
+    Backward: dz = g * act'(y) written through the output, dK = x^T dz (transposing-read GEMM),
+    db = column sum, dx = dz K^T."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, act, compute_dtype):
+        xc = x.to(compute_dtype).contiguous()
+        kc = kernel.to(compute_dtype)
+        y, _ = D.gemm(xc, kc.t().contiguous(), b_is_nk=True, bias=bias, act=act)
+        ctx.save_for_backward(xc, kc, y if act != L.ACT_NONE else None)
+        ctx.meta = (act, bias is not None, x.dtype, kernel.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, kc, y = ctx.saved_tensors
+        act, has_bias, x_dt, k_dt = ctx.meta
+        g = g.to(xc.dtype)
+        if act == L.ACT_RELU:
+            dz = g * (y > 0).to(g.dtype)
+        elif act == L.ACT_SIGMOID:
+            yf = y.float()
+            dz = (g.float() * yf * (1.0 - yf)).to(g.dtype)
+        elif act == L.ACT_TANH:
+            yf = y.float()
+            dz = (g.float() * (1.0 - yf * yf)).to(g.dtype)
+        else:
+            dz = g
+        dz = dz.contiguous()
+        dk, _ = D.gemm(xc, dz, a_is_km=True, out_dtype=torch.float32)            # [in, units]
+        db = D.colsum(dz) if has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = D.gemm(dz, kc, b_is_nk=True)                                   # [B, in]
+            dx = dx.to(x_dt)
+        return dx, dk.to(k_dt), db, None, None
+
+
 class CrossEpilogueFn(torch.autograd.Function):
     """y = x0 * (u + diag*x) + x for a host-composed u (arbitrary pre_activation callables)."""
 
@@ -189,6 +229,7 @@ class EmbedBagFusedFn(torch.autograd.Function):
     def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, optimizer, anchor, lead=0):
         # outputs: the whole slab [B, lead + n*dim] (columns 0..lead are left for the caller, see
         # layers.concat_features) followed by the per-feature column views
+        ctx.set_materialize_grads(False)  # unused outputs (slab or views) arrive as None, not as zero tensors
         n = len(bags.features)
         slab = torch.empty((batch, lead + n * bags.dim), dtype=out_dtype or bags.dtype, device=ids.device)
         out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,

@@ -909,6 +909,50 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
   gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
 }
 
+// Weight gradients with one tiny dimension (C = A^T B, both operands K-strided, min(M, N) <= 16, long K):
+// the first Dense of the bottom MLP (13 dense features) and the last of the top MLP (1 unit).  The
+// MFMA tiles do not apply and one thread per output would walk K = batch alone; here a thread owns
+// one column of the WIDE operand (coalesced across the workgroup), the THIN operand's rows are
+// staged in LDS and broadcast, K is split over blockIdx.y into fp32 slabs (fixed-order reduce).
+constexpr int kThinMax = 16;
+__global__ __launch_bounds__(256) void gemm_thin_kernel(const GemmParams p, int in_dtype, int thin_is_a) {
+  __shared__ float thin[128][kThinMax];
+  const char* wide_p = thin_is_a ? p.b : p.a;
+  const char* thin_p = thin_is_a ? p.a : p.b;
+  const int64_t ldw = thin_is_a ? p.ldb : p.lda, ldt = thin_is_a ? p.lda : p.ldb;
+  const int64_t n_wide = thin_is_a ? p.n : p.m;
+  const int n_thin = (int)(thin_is_a ? p.m : p.n);
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int split = blockIdx.y;
+  const int64_t kbeg = (int64_t)split * p.k_per_split;
+  const int64_t kend = min(p.k, kbeg + p.k_per_split);
+  float acc[kThinMax];
+#pragma unroll
+  for (int i = 0; i < kThinMax; ++i) acc[i] = 0.0f;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += 128) {
+    const int rows = (int)min<int64_t>(128, kend - k0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 128 * kThinMax; e += 256) {
+      const int r = e / kThinMax, i = e % kThinMax;
+      thin[r][i] = (r < rows && i < n_thin) ? ld_elem(thin_p, in_dtype, (k0 + r) * ldt + i) : 0.0f;
+    }
+    __syncthreads();
+    if (col < n_wide) {
+      for (int r = 0; r < rows; ++r) {
+        const float w = ld_elem(wide_p, in_dtype, (k0 + r) * ldw + col);
+#pragma unroll
+        for (int i = 0; i < kThinMax; ++i) acc[i] = fmaf(thin[r][i], w, acc[i]);
+      }
+    }
+  }
+  if (col >= n_wide) return;
+  for (int i = 0; i < n_thin; ++i) {
+    const int64_t m = thin_is_a ? i : col, n = thin_is_a ? col : i;
+    if (p.splits > 1) p.slabs[((int64_t)split * p.m + m) * p.n + n] = acc[i];
+    else epilogue_store(p, m, n, acc[i]);
+  }
+}
+
 // fixed-order reduction of the split-K slabs + epilogue
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const GemmParams p) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1296,6 +1340,24 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
     }
     const int rc = es == 2 ? launch_mfma<2>(p, st) : launch_mfma<4>(p, st);
     if (rc != KRS_OK) return rc;
+    if (p.splits > 1) {
+      hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p);
+      KRS_CHECK_LAUNCH("gemm_slab_reduce_kernel");
+    }
+    return KRS_OK;
+  }
+  if (p.a_km && !p.b_nk && k >= 1024 && std::min(m, n) <= kThinMax) {
+    const int s = pick_splits(m, n, k);
+    if (s > 1 && workspace && workspace_bytes >= (size_t)s * m * n * sizeof(float)) {
+      p.splits = s;
+      p.k_per_split = ceil_div(k, s);
+      p.slabs = reinterpret_cast<float*>(workspace);
+    }
+    const int thin_is_a = m <= n;
+    const int64_t n_wide = thin_is_a ? n : m;
+    hipLaunchKernelGGL(gemm_thin_kernel, dim3((unsigned)ceil_div(n_wide, 256), (unsigned)p.splits), dim3(256), 0, st, p,
+                       in_dtype, thin_is_a);
+    KRS_CHECK_LAUNCH("gemm_thin_kernel");
     if (p.splits > 1) {
       hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p);
       KRS_CHECK_LAUNCH("gemm_slab_reduce_kernel");

@@ -2,10 +2,11 @@
 
 from keras_rs_amd.layers.distributed_embedding import (Adagrad, Adam, DistributedEmbedding, Ftrl, SGD,
                                                        concat_features)
+from keras_rs_amd.layers.dense import Dense
 from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig, TableConfig
 from keras_rs_amd.layers.dot_interaction import DotInteraction
 from keras_rs_amd.layers.embed_reduce import EmbedReduce, Embedding, Ragged
 from keras_rs_amd.layers.feature_cross import FeatureCross
 
-__all__ = ["Adagrad", "Adam", "DistributedEmbedding", "DotInteraction", "EmbedReduce", "Embedding", "FeatureConfig",
+__all__ = ["Adagrad", "Adam", "Dense", "DistributedEmbedding", "DotInteraction", "EmbedReduce", "Embedding", "FeatureConfig",
            "FeatureCross", "Ftrl", "Ragged", "SGD", "TableConfig", "concat_features"]

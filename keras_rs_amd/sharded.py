@@ -109,6 +109,7 @@ class _ShardedLookupFn(torch.autograd.Function):
     def forward(ctx, layer, ids, batch, hots, offsets, weights, anchor):
         from keras_rs_amd.autograd import _split_columns
 
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero tensors
         slab, saved = layer._forward_impl(ids, batch, hots, offsets, weights)
         ctx.layer, ctx.saved = layer, saved
         return (slab,) + _split_columns(slab, len(layer._paths), layer.dim, layer.slab_lead_cols)

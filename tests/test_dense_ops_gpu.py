@@ -29,7 +29,8 @@ def _tol(dt, k):
 
 @pytest.mark.parametrize("m,n,k", [(1, 3, 3), (5, 7, 9), (128, 128, 64), (130, 200, 72), (256, 512, 512),
                                    (300, 136, 1000), (64, 3456, 512), (130, 200, 1088), (257, 512, 3456),
-                                   (700, 300, 1024), (512, 768, 2048)])  # the last three: 256x256-tile kernel
+                                   (700, 300, 1024), (512, 768, 2048),  # the last three: 256x256-tile kernel
+                                   (13, 520, 4100), (264, 1, 4100), (16, 16, 9000)])  # tn: thin weight-gradient kernel
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
 def test_gemm_layouts(m, n, k, dt, layout):

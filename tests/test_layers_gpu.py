@@ -271,6 +271,64 @@ def test_distributed_embedding_training_step_matches_formula(placement, optimize
                                rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
+@pytest.mark.parametrize("b,d_in,units,act", [(64, 13, 512, "relu"), (300, 520, 264, "sigmoid"), (33, 256, 1, None),
+                                              (257, 512, 256, "tanh"), (16, 24, 8, lambda t: t * t)])
+def test_dense_layer_matches_torch(policy, b, d_in, units, act):
+    # the Dense blocks of the DLRM MLPs (examples/ml_perf/model.py:214-262) on
+    # krs_gemm's bias + activation epilogue; forward and all three gradients against plain torch
+    kl = _layers()
+    from keras_rs_amd.layers import base as kl_base
+
+    layer = kl.Dense(units, activation=act, kernel_initializer=kl_base.GlorotUniform(seed=3),
+                     bias_initializer=kl_base.RandomUniform(-0.1, 0.1, seed=4), dtype=policy)
+    x = (torch.rand(b, d_in, device=DEV) - 0.5).requires_grad_(True)
+    y = layer(x)
+    assert tuple(y.shape) == (b, units) and [tuple(w.shape) for w in layer.weights] == [(d_in, units), (units,)]
+    gy = torch.rand(b, units, device=DEV)
+    (y.float() * gy).sum().backward()
+    fn = {"relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh, None: lambda t: t}.get(act, act)
+    bf = policy != "float32"
+    xr = x.detach().clone().requires_grad_(True)
+    kr = layer.kernel.detach().clone().requires_grad_(True)
+    br = layer.bias.detach().clone().requires_grad_(True)
+    xin, kin = (xr.bfloat16().float(), kr.bfloat16().float()) if bf else (xr, kr)
+    yr = fn(xin @ kin + br)
+    (yr * gy).sum().backward()
+    tol = dict(rtol=2 ** -6, atol=3e-2) if bf else dict(rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), yr.detach().cpu().numpy(), **tol)
+    gtol = dict(rtol=2 ** -5, atol=0.15) if bf else dict(rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.cpu().numpy(), **gtol)
+    np.testing.assert_allclose(layer.kernel.grad.cpu().numpy(), kr.grad.cpu().numpy(), **gtol)
+    np.testing.assert_allclose(layer.bias.grad.cpu().numpy(), br.grad.cpu().numpy(), **gtol)
+    assert kl.Dense.from_config(layer.get_config()).units == units if act is None or isinstance(act, str) else True
+
+
+def test_dlrm_dcn_v2_example_trains():
+    # the reference's ml_perf model assembled from the MI355X layers (examples/dlrm_dcn_v2.py): a few
+    # steps on a fixed batch lower the BCE loss, tables and dense weights move, nothing is NaN
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location(
+        "dlrm_dcn_v2", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "dlrm_dcn_v2.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    hots = [3, 1, 2, 5]
+    model = ex.build_model(256, 500, hots, embedding_dim=32, projection=16, cross_layers=2, bottom=(64, 32),
+                           top=(64, 32, 1), table_optimizer=_layers().Adagrad(0.05, 0.1))
+    x, y = ex.synthetic_batch(256, 13, 500, hots, torch.device(DEV))
+    box = [None]
+    before = None
+    losses = []
+    for _ in range(6):
+        losses.append(float(ex.train_step(model, box, x, y)))
+        if before is None:
+            before = {k: v.clone() for k, v in model.embedding_layer.get_embedding_tables().items()}
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    after = model.embedding_layer.get_embedding_tables()
+    assert any(not torch.equal(before[k], after[k]) for k in before)
+
+
 def test_threaded_data_loader_feeds_preprocessed_host_batches():
     # host ids -> loader threads (preprocess + asynchronous upload on their own
     # streams) -> layer call; results equal the direct call on the same ids
