@@ -268,7 +268,7 @@ class EmbedBagFusedFn(torch.autograd.Function):
             ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
         opt = ctx.optimizer  # a kind string, or an object with .fused_kind / .next_hyper() (the layer's group)
         kind = opt if isinstance(opt, str) else opt.fused_kind
-        hyper = None if isinstance(opt, str) or kind in ("sgd", "adagrad") else opt.next_hyper()
+        hyper = None if isinstance(opt, str) else opt.next_hyper()   # also refreshes scheduled learning rates
         bags.backward_fused(kind, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                             bag_scale=scale, hyper=hyper)
         return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device), None)

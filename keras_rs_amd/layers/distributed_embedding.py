@@ -98,13 +98,19 @@ class FusedOptimizer:
     """What K2 needs to run a table's optimizer inside the backward."""
 
     kind: str                 # "sgd" | "adagrad" | "adam" | "ftrl"
-    lr: float
+    lr: Any                   # float, or a schedule: callable(step) / callable() (jax/config_conversion.py:136-176)
     acc0: float = 0.0         # initial value of the (first) slot plane: Adagrad / FTRL accumulator
     consts: tuple = ()        # adam: (beta_1, beta_2, epsilon); ftrl: (lr_power, l1, l2, beta)
 
     @property
     def n_slot_planes(self) -> int:
         return {"sgd": 0, "adagrad": 1, "adam": 2, "ftrl": 2}[self.kind]
+
+    def lr_at(self, step: int) -> float:
+        """Learning rate of the update with 0-based index `step` (keras `iterations`)."""
+        if not callable(self.lr):
+            return float(self.lr)
+        return float(self.lr(step)) if _n_positional(self.lr) == 1 else float(self.lr())
 
     def hyper(self, step: int):
         """The four floats krs_embed_bag_bwd_fused_{adam,ftrl} take; `step` is the 1-based update count."""
@@ -124,23 +130,37 @@ class FusedOptimizer:
         return None
 
 
+def _n_positional(fn) -> int:
+    import inspect
+
+    try:
+        args = inspect.getfullargspec(fn).args
+    except TypeError:
+        return 99
+    return len(args) if inspect.isfunction(fn) else len(args) - 1
+
+
 def resolve_fused_optimizer(opt) -> FusedOptimizer | None:
     """The FusedOptimizer of a TableConfig.optimizer, or None when it cannot be fused (an option
-    the reference rejects as well, a learning-rate schedule, or an unknown optimizer)."""
+    the reference rejects as well, or an unknown optimizer).  Learning rates: a number, or a schedule
+    called with the step count or with nothing (jax/config_conversion.py:136-176)."""
     if isinstance(opt, str):
         cls = {"sgd": SGD, "adagrad": Adagrad, "adam": Adam, "ftrl": Ftrl}.get(opt.lower())
         if cls is None:
             return None
         opt = cls()
     name = type(opt).__name__.lower()
-    lr = getattr(opt, "learning_rate", None)
-    if callable(lr) or lr is None:
+    # keras optimizers evaluate `learning_rate` at the current step; the schedule itself is `_learning_rate`
+    lr = getattr(opt, "_learning_rate", None)
+    if lr is None:
+        lr = getattr(opt, "learning_rate", None)
+    if lr is None or (callable(lr) and _n_positional(lr) > 1):
         return None
     # options without a fused counterpart (jax/config_conversion.py:232-283)
     if any(getattr(opt, k, None) is not None for k in ("clipnorm", "global_clipnorm", "loss_scale_factor")) or \
             getattr(opt, "use_ema", False):
         return None
-    lr = float(lr)
+    lr = lr if callable(lr) else float(lr)
     if name == "sgd":
         if getattr(opt, "nesterov", False) or float(getattr(opt, "momentum", 0.0) or 0.0) != 0.0:
             return None
@@ -190,13 +210,18 @@ class _Group:
     table_configs: list        # unique TableConfig objects
     bags: FusedBags | None = None
     fused: FusedOptimizer | None = None   # shared by the group's tables (learning rates may differ)
-    step: int = 0                         # fused updates applied so far (Adam bias correction)
+    table_opts: list | None = None        # per table: its FusedOptimizer (learning rate / schedule)
+    step: int = 0                         # fused updates applied so far (Adam bias correction, schedules)
 
     @property
     def fused_kind(self) -> str | None:
         return None if self.fused is None else self.fused.kind
 
     def next_hyper(self):
+        """Called once per fused update: advances the step count, refreshes scheduled learning rates in
+        the kernel descriptors, returns the Adam / FTRL constants (None for SGD / Adagrad)."""
+        if self.table_opts and any(callable(o.lr) for o in self.table_opts):
+            self.bags.lrs = [o.lr_at(self.step) for o in self.table_opts]   # table_desc() re-uploads on change
         self.step += 1
         return self.fused.hyper(self.step)
 
@@ -295,7 +320,7 @@ class DistributedEmbedding(base.Layer):
         for gi, g in enumerate(self._groups.get(placement, [])):
             if g.bags is not None:
                 continue
-            tables, slots, lrs = [], [], []
+            tables, slots, lrs, topts = [], [], [], []
             kinds: set = set()
             for tc in g.table_configs:
                 key = id(tc)
@@ -310,7 +335,8 @@ class DistributedEmbedding(base.Layer):
                 lr = 0.0
                 if placement == "sparsecore":
                     fo = resolve_fused_optimizer(tc.optimizer)
-                    lr = fo.lr
+                    lr = fo.lr_at(0)
+                    topts.append(fo)
                     kinds.add(dataclasses.replace(fo, lr=0.0))   # everything but the learning rate is per group
                     if self._table_slots[key] is None:
                         self._table_slots[key] = fo.new_slot(p.shape, p.device)
@@ -320,6 +346,7 @@ class DistributedEmbedding(base.Layer):
                 raise NotImplementedError("Tables of one embedding width on 'sparsecore' must share the optimizer "
                                           "type and its constants (only the learning rate may differ per table)")
             g.fused = kinds.pop() if kinds else None
+            g.table_opts = topts or None
             fcs = self._placement_to_path_to_feature_config[placement]
             feats = [(g.table_index[i], fcs[p].table.combiner, i * g.dim) for i, p in enumerate(g.paths)]
             g.bags = FusedBags(tables, feats, slots=slots, lrs=lrs)

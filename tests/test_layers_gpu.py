@@ -395,6 +395,26 @@ def test_distributed_embedding_adam_and_ftrl_steps_match_the_keras_formulas(opti
     assert np.array_equal(W[~touched], w_start[~touched])  # lazy: rows never looked up do not move
 
 
+def test_fused_optimizer_follows_a_learning_rate_schedule():
+    # jax/config_conversion.py:136-176: callable learning rates are evaluated per step; here SGD with
+    # lr(step) = 0.5 / (1 + step) over three updates of one row
+    kl = _layers()
+
+    class ScheduledSGD:
+        def __init__(self):
+            self.learning_rate = lambda step: 0.5 / (1 + step)
+    ScheduledSGD.__name__ = "SGD"
+    t = kl.TableConfig("table", 5, 8, placement="sparsecore", optimizer=ScheduledSGD(), combiner="sum")
+    layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t, (1, 1), (1, 8))})
+    x = np.array([[2]], np.int32)
+    layer.build(None)
+    w = layer.get_embedding_tables()["table"][2].double().cpu().numpy()
+    for step in range(3):
+        layer({"a": x})["a"].sum().backward()          # gradient of the row: all ones
+        w = w - 0.5 / (1 + step)
+        np.testing.assert_allclose(layer.get_embedding_tables()["table"][2].cpu().numpy(), w, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("lead", [0, 8, 4])
 def test_concat_features_uses_the_slab_and_trains_like_torch_cat(lead):
     # SURVEY.md section 8f.3 (concat-free layout): concat_features([dense, *embeddings]) == torch.cat,

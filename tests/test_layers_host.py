@@ -183,7 +183,15 @@ def test_fused_optimizer_resolution_follows_the_reference_option_matrix():
     assert r(type("SGD", (), dict(learning_rate=0.1, momentum=0.9))()) is None
     assert r(type("Ftrl", (), dict(learning_rate=0.1, l2_shrinkage_regularization_strength=0.1))()) is None
     assert r(type("Adagrad", (), dict(learning_rate=0.1, epsilon=1e-3))()) is None
-    assert r(type("Adam", (), dict(learning_rate=lambda step: 0.1))()) is None      # schedules are not fused
+    # learning-rate schedules: called with the step count or with nothing (jax/config_conversion.py:136-176)
+    class KerasLikeSGD:
+        def __init__(self, lr):
+            self._learning_rate = lr        # keras keeps the schedule here; `learning_rate` evaluates it
+            self.learning_rate = 123.0
+    KerasLikeSGD.__name__ = "SGD"
+    assert r(KerasLikeSGD(lambda step: 0.1 / (1 + step))).lr_at(3) == 0.025
+    assert r(KerasLikeSGD(lambda: 0.25)).lr_at(9) == 0.25
+    assert r(KerasLikeSGD(lambda step, extra: 0.1)) is None
     assert r(type("Adam", (), dict(learning_rate=0.1, clipnorm=1.0))()) is None
     h1, h2 = r("adam").hyper(1), r("adam").hyper(2)
     assert abs(h1[3] - (1 - 0.999) ** 0.5 / (1 - 0.9)) < 1e-12 and h2[3] != h1[3]
