@@ -92,14 +92,15 @@ class HipShardKernels:
         out, _ = FusedBags([vectors], feats).forward(ids, batch, offsets=offsets, out=out, out_dtype=out_dtype)
         return out
 
-    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind):
+    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None):
         """Owner side: fused optimizer step; lookup i of segment s carries weights[i] * seg_grads[s]."""
         n_seg = offsets.numel() - 1
         if rows.numel() == 0 or n_seg == 0:
             return
-        fb = self._bags_for(table, slot, lr)
+        fb = self._bags_for(table, slot, 0.0)
+        fb.lrs = [float(lr)]   # scheduled rates change per step: the descriptor is re-uploaded when it does
         ws = fb.plan_backward(rows, n_seg, offsets=offsets)
-        fb.backward_fused(kind, ws, seg_grads, n_seg, rows.numel(), weights=weights)
+        fb.backward_fused(kind, ws, seg_grads, n_seg, rows.numel(), weights=weights, hyper=hyper)
 
 
 class _ShardedLookupFn(torch.autograd.Function):
@@ -158,10 +159,12 @@ class ShardedDistributedEmbedding(base.Layer):
             raise NotImplementedError("ShardedDistributedEmbedding: tables must share embedding_dim")
         self.dim = dims.pop()
         kinds = {resolve_fused_optimizer(tc.optimizer) for tc in tcs}
-        if None in kinds or len(kinds) != 1 or next(iter(kinds)).kind not in ("sgd", "adagrad"):
-            raise NotImplementedError("ShardedDistributedEmbedding: one SGD/Adagrad setting for all tables")
-        fo = next(iter(kinds))
-        self._opt_kind, self._lr, self._acc0 = fo.kind, fo.lr, fo.acc0
+        if None in kinds or len(kinds) != 1:
+            raise NotImplementedError("ShardedDistributedEmbedding: one fusable optimizer setting (SGD / Adagrad / "
+                                      "Adam / Ftrl, see resolve_fused_optimizer) for all tables")
+        self._fused = next(iter(kinds))
+        self._opt_kind = self._fused.kind
+        self._step = 0
         self.vloc = max(math.ceil(tc.vocabulary_size / self.world) for tc in tcs)
         self._combiners = [feature_configs[p].table.combiner for p in self._paths]
         self.register_parameter("shard", None)
@@ -189,8 +192,7 @@ class ShardedDistributedEmbedding(base.Layer):
                                                                      self._device)
         self.shard = torch.nn.Parameter(shard, requires_grad=False)
         self._weight_order.append(self.shard)
-        if self._opt_kind == "adagrad":
-            self._slot = torch.full((rows, self.dim), self._acc0, dtype=torch.float32, device=self._device)
+        self._slot = self._fused.new_slot((rows, self.dim), self._device)
         self._anchor = torch.zeros((), device=self._device, requires_grad=True)
         self.built = True
 
@@ -365,5 +367,7 @@ class ShardedDistributedEmbedding(base.Layer):
         rows = ((seg_bag % batch) * n_feats + seg_bag // batch).to(torch.int32)
         dpart = k.gather_rows(g.view(batch * n_feats, self.dim), rows)
         dseg = self._a2a(dpart, s["send_segs"], s["recv_segs"])                   # to the owners
-        k.apply_segments(self.shard.data, self._slot, s["recv_rows"], s["recv_off"], s["recv_w"], dseg, self._lr,
-                         self._opt_kind)
+        lr = self._fused.lr_at(self._step)
+        self._step += 1
+        k.apply_segments(self.shard.data, self._slot, s["recv_rows"], s["recv_off"], s["recv_w"], dseg, lr,
+                         self._opt_kind, self._fused.hyper(self._step))

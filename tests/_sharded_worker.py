@@ -48,7 +48,7 @@ class OracleShardKernels:
         out.copy_(torch.from_numpy(res))
         return out
 
-    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind):
+    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None):
         t = table.numpy()
         n_seg = offsets.numel() - 1
         if rows.numel() == 0 or n_seg == 0:
@@ -60,7 +60,7 @@ class OracleShardKernels:
                                np.ascontiguousarray(seg_grads.numpy()), n_seg, t.shape[1])
         touched = np.zeros(t.shape[0], np.uint8)
         touched[rows.numpy()] = 1
-        ko.apply_optimizer(t, None if slot is None else slot.numpy(), dense, touched, lr, kind)
+        ko.apply_optimizer(t, None if slot is None else slot.numpy(), dense, touched, lr, kind, hyper)
 
 
 def main():
@@ -71,7 +71,8 @@ def main():
 
     kind = sys.argv[1]
     use_w = len(sys.argv) < 3 or sys.argv[2] == "w"
-    opt = kl.SGD(0.1) if kind == "sgd" else kl.Adagrad(0.1, 0.1)
+    opt = {"sgd": kl.SGD(0.1), "adagrad": kl.Adagrad(0.1, 0.1), "adam": kl.Adam(0.1, 0.9, 0.999, 1e-7),
+           "ftrl": kl.Ftrl(0.1, -0.5, 0.1, 0.01, 0.02, 0.3)}[kind]
     V, D, B = [37, 10, 64], 8, 6
     combs = ["sum", "mean", "sqrtn", "sum"]
     tcs = [kl.TableConfig(f"t{i}", V[i], D, optimizer=opt, combiner="sum", placement="sparsecore") for i in range(3)]
@@ -125,7 +126,14 @@ def main():
     for k in full:
         exp = full[k].copy()
         acc = np.full_like(exp, 0.1)
-        ko.apply_optimizer(exp, acc, dense[k], touched[k], 0.1, kind)
+        hyper = None
+        if kind in ("adam", "ftrl"):
+            acc = np.zeros((2,) + exp.shape, np.float32)
+            if kind == "ftrl":
+                acc[0] = 0.1
+            hyper = (0.9, 0.999, 1e-7, float(np.sqrt(1 - 0.999) / (1 - 0.9))) if kind == "adam" else \
+                (-0.5, 0.01, 0.02, 0.3)
+        ko.apply_optimizer(exp, acc, dense[k], touched[k], 0.1, kind, hyper)
         np.testing.assert_allclose(after[k].numpy(), exp, rtol=1e-5, atol=1e-6)
     if rank == 0:
         print("SHARDED_OK", kind)

@@ -480,7 +480,7 @@ def test_embedding_layer_and_readme_quickstart_shape():
     assert tuple(seq.shape) == (3, 4, 6)
 
 
-@pytest.mark.parametrize("optimizer", ["sgd", "adagrad"])
+@pytest.mark.parametrize("optimizer", ["sgd", "adagrad", "adam", "ftrl"])
 def test_sharded_layer_world1_on_hip_matches_unsharded_layer(optimizer):
     """The sharded path (bucketise -> owner-side partial pooling -> home-side sum, and the CSR-form fused
     apply) on the HIP kernels, degenerate world of 1: same outputs and same updated tables as
@@ -488,7 +488,8 @@ def test_sharded_layer_world1_on_hip_matches_unsharded_layer(optimizer):
     kl = _layers()
     from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
-    opt = kl.SGD(0.1) if optimizer == "sgd" else kl.Adagrad(0.1, 0.1)
+    opt = {"sgd": kl.SGD(0.1), "adagrad": kl.Adagrad(0.1, 0.1), "adam": kl.Adam(0.1),
+           "ftrl": kl.Ftrl(0.1, -0.5, 0.1, 0.01, 0.02, 0.3)}[optimizer]
     rng = np.random.default_rng(5)
     V, D, B = [50, 31], 16, 24
     hots = [1, 3, 2]

@@ -18,7 +18,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("kind,weighted,world", [("sgd", "w", 2), ("adagrad", "w", 2), ("adagrad", "now", 2),
-                                                 ("sgd", "now", 3)])
+                                                 ("sgd", "now", 3), ("adam", "w", 2), ("ftrl", "now", 2)])
 def test_sharded_embedding_matches_unsharded_oracle(kind, weighted, world):
     # weighted: user weights on every feature; "now": none (mean / sqrtn scales are still folded in)
     env = dict(os.environ, OMP_NUM_THREADS="1")
