@@ -29,7 +29,20 @@ namespace krs {
 namespace {
 
 constexpr uint32_t kInvalidKey = 0xffffffffu;
-constexpr int kLongSeg = 512;  // segments longer than this are summed by a whole workgroup
+constexpr int kLongSeg = 128;   // segments longer than this are summed by whole workgroups
+constexpr int kChunk = 2048;    // ... in chunks of this many lookups, one workgroup each
+constexpr int kPartialBytes = 2048;  // fp32 partial row of a chunk (row bytes <= 1024 on the vector path)
+
+// one workgroup's share of a long segment
+struct LongItem {
+  uint32_t seg;       // segment index
+  uint32_t chunk;     // which kChunk-sized piece of it
+  uint32_t partial;   // slot in the partial-row buffer, or ~0u when the segment is a single chunk
+};
+// a long segment that spans several chunks: its partial rows are summed in chunk order afterwards
+struct MultiSeg {
+  uint32_t seg, partial_base, n_chunks;
+};
 
 struct PlanLayout {
   uint32_t* keys_in;      // dead after the sort -> reused as head flags
@@ -40,8 +53,10 @@ struct PlanLayout {
   uint32_t* head_index;   // = vals_in, first n words
   uint32_t* seg_start;    // = vals_in, next n words: first sorted position of every segment
   uint32_t* n_seg;        // number of segments (a trailing run of invalid keys counts as one)
-  uint32_t* n_long;       // number of segments longer than kLongSeg
-  uint32_t* long_list;    // their segment indices (any order)
+  uint32_t* n_long;       // number of LongItems (device scalar); [1] partial rows handed out; [2] MultiSegs
+  LongItem* long_list;    // work items of the segments longer than kLongSeg (any order)
+  MultiSeg* multi_list;   // segments longer than kChunk
+  float* partials;        // [<= 2 * nnz / kChunk + 2] fp32 partial rows, kPartialBytes apart
   void* temp;
   size_t temp_bytes;
   size_t total_bytes;
@@ -73,7 +88,10 @@ PlanLayout plan_layout(void* ws, int64_t nnz, bool need_temp = false) {
   l.vals_sorted = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8, 256);
   l.n_seg = reinterpret_cast<uint32_t*>(p + o);
   l.n_long = l.n_seg + 1; o += 256;
-  l.long_list = reinterpret_cast<uint32_t*>(p + o); o += align_up((n / kLongSeg + 2) * 4, 256);
+  // every long segment has <= len / kChunk + 1 items; there are <= n / kLongSeg long segments
+  l.long_list = reinterpret_cast<LongItem*>(p + o); o += align_up((n / kLongSeg + n / kChunk + 2) * sizeof(LongItem), 256);
+  l.multi_list = reinterpret_cast<MultiSeg*>(p + o); o += align_up((n / kChunk + 2) * sizeof(MultiSeg), 256);
+  l.partials = reinterpret_cast<float*>(p + o); o += align_up((2 * (n / kChunk) + 2) * (size_t)kPartialBytes, 256);
   l.head_flag = l.keys_in;
   l.head_index = reinterpret_cast<uint32_t*>(l.vals_in);
   l.seg_start = reinterpret_cast<uint32_t*>(l.vals_in) + n;
@@ -187,8 +205,10 @@ struct ApplyParams {
   const uint64_t* vals;
   const uint32_t* seg_start;   // first sorted position of every segment
   const uint32_t* n_seg;       // device scalar
-  const uint32_t* n_long;      // device scalar
-  const uint32_t* long_list;
+  const uint32_t* n_long;      // device scalars: items, partial rows, multi-chunk segments
+  const LongItem* long_list;
+  const MultiSeg* multi_list;
+  float* partials;
   int64_t* unique_rows;        // sparse
   float* row_grads;            // sparse
   Hyper hyper;                 // Adam / FTRL
@@ -422,6 +442,42 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
   }  // segments of this group
 }
 
+// Writes one finished row (summed gradient `tot` of segment u, this lane's N columns): dense
+// gradient row, compact (unique_rows, grads) entry, or the fused optimizer update in place.
+template <typename GT, typename TT, int MODE>
+__device__ __forceinline__ void finish_row(const ApplyParams& p, uint32_t u, uint32_t key, int64_t s0, int sub,
+                                           const float (&tot)[Piece<GT>::N]) {
+  constexpr int N = Piece<GT>::N;
+  if constexpr (MODE == kSparse) {
+    if (sub == 0) p.unique_rows[u] = (int64_t)key;
+    float* dst = p.row_grads + (int64_t)u * p.dim + sub * N;
+#pragma unroll
+    for (int k = 0; k < N; ++k) dst[k] = tot[k];
+  } else {
+    const uint64_t v0 = p.vals[s0];
+    const int f0 = (int)((uint32_t)(v0 >> 32) / (uint32_t)p.batch);
+    const krs_table tb = p.tables[p.feats[f0].table];
+    const int64_t off = ((int64_t)key - tb.row_base) * p.dim + sub * N;
+    const bool t_al = ((reinterpret_cast<uintptr_t>(tb.weights) | reinterpret_cast<uintptr_t>(tb.slot)) & 15) == 0;
+    if constexpr (MODE == kDense) {
+      store_elems<float, N>(reinterpret_cast<float*>(tb.weights) + off, tot, t_al);
+    } else {
+      float wv[N], av[N], bv[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) { av[k] = 0.0f; bv[k] = 0.0f; }
+      const int64_t plane = tb.vocab * p.dim;
+      load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
+      if constexpr (mode_slots(MODE) >= 1) load_elems<float, N>(tb.slot + off, av, t_al);
+      if constexpr (mode_slots(MODE) == 2) load_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
+#pragma unroll
+      for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], tot[k], tb.lr, p.hyper);
+      if constexpr (mode_slots(MODE) >= 1) store_elems<float, N>(tb.slot + off, av, t_al);
+      if constexpr (mode_slots(MODE) == 2) store_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
+      store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
+    }
+  }
+}
+
 // Hot rows (segments longer than kLongSeg, e.g. power-law ids or tiny vocabularies): one
 // workgroup per segment.  Its 256/LPR groups sum interleaved positions of the segment (four
 // gradient rows in flight each), the partial rows meet in LDS and are added in a fixed order
@@ -442,15 +498,19 @@ __global__ __launch_bounds__(256) void bag_apply_long_kernel(const ApplyParams p
   const char* grad = reinterpret_cast<const char*>(p.grad) + (int64_t)csub * 16;
   const bool g_aligned = ((reinterpret_cast<uintptr_t>(p.grad) | (uintptr_t)(p.grad_ld * sizeof(GT))) & 15) == 0;
   for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) {
-    const uint32_t u = p.long_list[li];
+    const LongItem item = p.long_list[li];
+    const uint32_t u = item.seg;
     const int64_t s0 = p.seg_start[u];
-    const int64_t e0 = u + 1 < n_seg ? (int64_t)p.seg_start[u + 1] : p.nnz;
+    const int64_t seg_end = u + 1 < n_seg ? (int64_t)p.seg_start[u + 1] : p.nnz;
     const uint32_t key = p.keys[s0];
     if (key == kInvalidKey) continue;
+    // this workgroup's piece of the segment
+    const int64_t c0 = s0 + (int64_t)item.chunk * kChunk;
+    const int64_t e0 = min(seg_end, c0 + kChunk);
     float acc[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k] = 0.0f;
-    for (int64_t j0 = s0 + g; j0 < e0; j0 += (int64_t)GPB * kApplyUnroll) {
+    for (int64_t j0 = c0 + g; j0 < e0; j0 += (int64_t)GPB * kApplyUnroll) {
       uint64_t vv[kApplyUnroll];
 #pragma unroll
       for (int q = 0; q < kApplyUnroll; ++q) vv[q] = p.vals[min(j0 + (int64_t)q * GPB, e0 - 1)];
@@ -501,36 +561,41 @@ __global__ __launch_bounds__(256) void bag_apply_long_kernel(const ApplyParams p
       for (int gg = 0; gg < GPB; ++gg)
 #pragma unroll
         for (int k = 0; k < N; ++k) tot[k] += part[gg * p.dim + sub * N + k];
-      if constexpr (MODE == kSparse) {
-        if (sub == 0) p.unique_rows[u] = (int64_t)key;
-        float* dst = p.row_grads + (int64_t)u * p.dim + sub * N;
+      if (item.partial != 0xffffffffu) {  // one of several chunks: the row is finished by bag_apply_finish_kernel
+        float* dst = p.partials + (int64_t)item.partial * (kPartialBytes / 4) + sub * N;
 #pragma unroll
         for (int k = 0; k < N; ++k) dst[k] = tot[k];
       } else {
-        const uint64_t v0 = p.vals[s0];
-        const int f0 = (int)((uint32_t)(v0 >> 32) / (uint32_t)p.batch);
-        const krs_table tb = p.tables[p.feats[f0].table];
-        const int64_t off = ((int64_t)key - tb.row_base) * p.dim + sub * N;
-        const bool t_al = ((reinterpret_cast<uintptr_t>(tb.weights) | reinterpret_cast<uintptr_t>(tb.slot)) & 15) == 0;
-        if constexpr (MODE == kDense) {
-          store_elems<float, N>(reinterpret_cast<float*>(tb.weights) + off, tot, t_al);
-        } else {
-          float wv[N], av[N], bv[N];
-#pragma unroll
-          for (int k = 0; k < N; ++k) { av[k] = 0.0f; bv[k] = 0.0f; }
-          const int64_t plane = tb.vocab * p.dim;
-          load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
-          if constexpr (mode_slots(MODE) >= 1) load_elems<float, N>(tb.slot + off, av, t_al);
-          if constexpr (mode_slots(MODE) == 2) load_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
-#pragma unroll
-          for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], tot[k], tb.lr, p.hyper);
-          if constexpr (mode_slots(MODE) >= 1) store_elems<float, N>(tb.slot + off, av, t_al);
-          if constexpr (mode_slots(MODE) == 2) store_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
-          store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
-        }
+        finish_row<GT, TT, MODE>(p, u, key, s0, sub, tot);
       }
     }
     __syncthreads();
+  }
+}
+
+// Segments longer than kChunk: their chunks' partial rows are added in chunk order (fixed, so the
+// result stays run-to-run bit-identical) by one group of LPR lanes each, which then writes the row.
+template <typename GT, typename TT, int LPR, int MODE>
+__global__ __launch_bounds__(256) void bag_apply_finish_kernel(const ApplyParams p) {
+  constexpr int N = Piece<GT>::N;
+  constexpr int GPB = 256 / LPR;
+  const uint32_t n_multi = p.n_long[2];
+  const int sub = threadIdx.x % LPR;
+  const int row_pieces = (int)(((int64_t)p.dim * sizeof(GT)) >> 4);
+  if (sub >= row_pieces) return;
+  for (uint32_t mi = blockIdx.x * GPB + threadIdx.x / LPR; mi < n_multi; mi += gridDim.x * GPB) {
+    const MultiSeg ms = p.multi_list[mi];
+    const int64_t s0 = p.seg_start[ms.seg];
+    const uint32_t key = p.keys[s0];
+    float tot[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) tot[k] = 0.0f;
+    for (uint32_t c = 0; c < ms.n_chunks; ++c) {
+      const float* src = p.partials + (int64_t)(ms.partial_base + c) * (kPartialBytes / 4) + sub * N;
+#pragma unroll
+      for (int k = 0; k < N; ++k) tot[k] += src[k];
+    }
+    finish_row<GT, TT, MODE>(p, ms.seg, key, s0, sub, tot);
   }
 }
 
@@ -593,13 +658,23 @@ __global__ void seg_scatter_kernel(const uint32_t* flags, const uint32_t* index,
   if (flags[i]) seg_start[index[i]] = (uint32_t)i;
   if (i == nnz - 1) *n_seg = index[i] + flags[i];
 }
-__global__ void long_list_kernel(const uint32_t* seg_start, const uint32_t* n_seg, int64_t nnz, uint32_t* n_long,
-                                 uint32_t* long_list) {
+__global__ void long_list_kernel(const uint32_t* seg_start, const uint32_t* n_seg, int64_t nnz, uint32_t* counters,
+                                 LongItem* items, MultiSeg* multi) {
+  // counters[0] = work items, [1] = partial rows handed out, [2] = multi-chunk segments
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t ns = *n_seg;
   if (u >= ns) return;
   const int64_t e = u + 1 < ns ? (int64_t)seg_start[u + 1] : nnz;
-  if (e - (int64_t)seg_start[u] > kLongSeg) long_list[atomicAdd(n_long, 1u)] = (uint32_t)u;
+  const int64_t len = e - (int64_t)seg_start[u];
+  if (len <= kLongSeg) return;
+  const uint32_t nch = (uint32_t)((len + kChunk - 1) / kChunk);
+  const uint32_t base = atomicAdd(counters, nch);
+  uint32_t pb = 0xffffffffu;
+  if (nch > 1) {
+    pb = atomicAdd(counters + 1, nch);
+    multi[atomicAdd(counters + 2, 1u)] = MultiSeg{(uint32_t)u, pb, nch};
+  }
+  for (uint32_t c = 0; c < nch; ++c) items[base + c] = LongItem{(uint32_t)u, c, nch > 1 ? pb + c : 0xffffffffu};
 }
 __global__ void count_unique_kernel(const uint32_t* keys, const uint32_t* n_seg, int64_t nnz, int64_t* n_unique) {
   // segments minus the trailing run of invalid keys, if any
@@ -623,10 +698,10 @@ int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
   else { KRS_LAUNCH_APPLY(64) }
 #undef KRS_LAUNCH_APPLY
   KRS_CHECK_LAUNCH("bag_apply_kernel");
-  // hot rows: upper bound of the list length is nnz / kLongSeg; surplus workgroups leave at once
+  // hot rows: upper bound of the item count is nnz / kLongSeg + nnz / kChunk; surplus workgroups leave at once
   const int64_t max_long = p.nnz / kLongSeg;
   if (max_long > 0) {
-    const unsigned lb = (unsigned)(max_long < 4096 ? max_long : 4096);
+    const unsigned lb = (unsigned)(max_long < 8192 ? max_long : 8192);
     const size_t lds = (size_t)(256 / lpr) * p.dim * sizeof(float);
 #define KRS_LAUNCH_LONG(L)                                                                              \
   if (p.weights)                                                                                        \
@@ -639,6 +714,15 @@ int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
     else { KRS_LAUNCH_LONG(64) }
 #undef KRS_LAUNCH_LONG
     KRS_CHECK_LAUNCH("bag_apply_long_kernel");
+    const int64_t max_multi = p.nnz / kChunk;
+    if (max_multi > 0) {
+      const unsigned fb = (unsigned)std::min<int64_t>(ceil_div(max_multi, 256 / lpr), 1024);
+      if (lpr == 8) hipLaunchKernelGGL((bag_apply_finish_kernel<GT, TT, 8, MODE>), dim3(fb), dim3(256), 0, st, p);
+      else if (lpr == 16) hipLaunchKernelGGL((bag_apply_finish_kernel<GT, TT, 16, MODE>), dim3(fb), dim3(256), 0, st, p);
+      else if (lpr == 32) hipLaunchKernelGGL((bag_apply_finish_kernel<GT, TT, 32, MODE>), dim3(fb), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((bag_apply_finish_kernel<GT, TT, 64, MODE>), dim3(fb), dim3(256), 0, st, p);
+      KRS_CHECK_LAUNCH("bag_apply_finish_kernel");
+    }
   }
   return KRS_OK;
 }
@@ -685,7 +769,7 @@ ApplyParams make_apply(const krs_table* tables, int n_tables, const krs_feature*
   p.bag_scale = bag_scale;
   p.grad = grad; p.grad_ld = grad_ld; p.batch = batch; p.dim = dim; p.nnz = nnz;
   p.keys = l.keys_sorted; p.vals = l.vals_sorted; p.seg_start = l.seg_start; p.n_seg = l.n_seg;
-  p.n_long = l.n_long; p.long_list = l.long_list;
+  p.n_long = l.n_long; p.long_list = l.long_list; p.multi_list = l.multi_list; p.partials = l.partials;
   p.unique_rows = nullptr; p.row_grads = nullptr;
   p.hyper = Hyper{0.0f, 0.0f, 0.0f, 0.0f};
   return p;
@@ -742,8 +826,9 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
                      l.n_seg);
   KRS_CHECK_LAUNCH("seg_scatter_kernel");
   // segments too long for one lane group (at most nnz / kLongSeg of them)
-  KRS_HIP(hipMemsetAsync(l.n_long, 0, sizeof(uint32_t), st));
-  hipLaunchKernelGGL(long_list_kernel, dim3(nb), dim3(256), 0, st, l.seg_start, l.n_seg, nnz, l.n_long, l.long_list);
+  KRS_HIP(hipMemsetAsync(l.n_long, 0, 3 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(long_list_kernel, dim3(nb), dim3(256), 0, st, l.seg_start, l.n_seg, nnz, l.n_long, l.long_list,
+                     l.multi_list);
   KRS_CHECK_LAUNCH("long_list_kernel");
   return KRS_OK;
 }

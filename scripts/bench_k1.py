@@ -40,7 +40,13 @@ else:
 HOTS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
 hots = (HOTS * 4)[: a.tables] if a.multihot else [1] * a.tables
 gi = torch.Generator(device=dev).manual_seed(1338)
-if a.idmode == "seq":
+if a.idmode.startswith("pow"):
+    # power-law skew (C5-like): id = floor(V * u^e), e.g. --idmode pow4: the lowest 1 % of the rows
+    # take 32 % of the lookups, the lowest 0.01 % take 10 %
+    e = float(a.idmode[3:] or 4)
+    ids = torch.cat([(torch.rand(a.batch * h, device=dev, generator=gi) ** e * a.vocab).to(torch.int32).clamp_(0, a.vocab - 1)
+                     for h in hots])
+elif a.idmode == "seq":
     ids = torch.cat([(torch.arange(a.batch * h, device=dev, dtype=torch.int32) % a.vocab) for h in hots])
 else:
     ids = torch.cat([torch.randint(0, a.vocab, (a.batch * h,), device=dev, generator=gi, dtype=torch.int32)
