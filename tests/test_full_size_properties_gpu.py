@@ -120,3 +120,49 @@ def test_dot_interaction_and_feature_cross_identities_at_full_size():
     x = (torch.rand(B, F * D, device=DEV, generator=g) - 0.5).to(torch.bfloat16)
     y = layer(x0, x)
     assert torch.equal(y, (x0.float() + x.float()).to(torch.bfloat16))
+
+
+def test_backward_identities_at_full_size():
+    """C3-size backward through the 256x256-tile GEMMs (LDS-DMA, transposing-read weight gradient) and
+    the DotInteraction backward, against closed forms that need no oracle run:
+    FeatureCross with kernel V = 0 and bias 1: u = 1, so dL/dx = g and dL/dx0 = g exactly, dU = 0 exactly,
+    dV = (x U)^T (g * x0) and dbias = colsum(g * x0) (checked against fp32 torch on a row/column slice);
+    DotInteraction: dX = (G + G^T) X on a slice of the batch."""
+    import keras_rs_amd.layers as kl
+    from keras_rs_amd.layers import base
+
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    F, d, p = 27, 27 * D, 512
+    x0 = ((torch.rand(B, d, device=DEV, generator=gen) - 0.5)).to(torch.bfloat16).requires_grad_(True)
+    x = ((torch.rand(B, d, device=DEV, generator=gen) - 0.5)).to(torch.bfloat16).requires_grad_(True)
+    layer = kl.FeatureCross(projection_dim=p, kernel_initializer=base.GlorotUniform(seed=2), bias_initializer="ones",
+                            dtype="mixed_bfloat16")
+    layer.build(x0.shape)
+    with torch.no_grad():
+        layer.kernel.zero_()                                           # V = 0, U stays random
+    g = ((torch.rand(B, d, device=DEV, generator=gen) - 0.5)).to(torch.bfloat16)
+    y = layer(x0, x)
+    assert torch.equal(y, (x0.float() + x.float()).to(torch.bfloat16))
+    y.backward(g)
+    assert torch.equal(x.grad, g) and torch.equal(x0.grad, g)          # u = 1: both are g, bit for bit
+    assert torch.count_nonzero(layer.down_kernel.grad) == 0            # dh = dz V^T = 0
+    dz = (g.float() * x0.detach().float()).to(torch.bfloat16)          # what the elementwise pass hands the GEMMs
+    h = (x.detach().float() @ layer.down_kernel.detach().to(torch.bfloat16).float()).to(torch.bfloat16)
+    cols = slice(1000, 1256)
+    exp = h.float().t() @ dz[:, cols].float()                          # fp32 reference of dV[:, cols]
+    torch.testing.assert_close(layer.kernel.grad[:, cols], exp, rtol=2e-2, atol=0.5)
+    # the bias gradient sums the unrounded fp32 products (the bf16 dz only feeds the GEMMs)
+    torch.testing.assert_close(layer.bias.grad, (g.double() * x0.detach().double()).sum(0).float(), rtol=1e-3, atol=5e-3)
+    # DotInteraction backward on the full batch, checked on 512 samples
+    feats = [x0.detach()[:, f * D:(f + 1) * D].clone().requires_grad_(True) for f in range(F)]
+    out = kl.DotInteraction(dtype="bfloat16")(feats)
+    go = ((torch.rand(out.shape, device=DEV, generator=gen) - 0.5)).to(torch.bfloat16)
+    out.backward(go)
+    sl = slice(4096, 4608)
+    X = torch.stack([f.detach()[sl].float() for f in feats], 1)        # [512, F, D]
+    G = torch.zeros(512, F, F, device=DEV)
+    ii, jj = torch.tril_indices(F, F, -1, device=DEV)
+    G[:, ii, jj] = go[sl].float()
+    dX = torch.matmul(G + G.transpose(1, 2), X)
+    for f in (0, 13, 26):
+        torch.testing.assert_close(feats[f].grad[sl].float(), dX[:, f], rtol=2 ** -6, atol=2e-2)
