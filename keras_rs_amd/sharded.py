@@ -337,8 +337,9 @@ class ShardedDistributedEmbedding(base.Layer):
             dist.all_to_all_single(theirs, mine, group=self._pg)
         else:
             theirs.copy_(mine)
-        send_counts, send_segs = mine[:, 0].tolist(), mine[:, 1].tolist()
-        recv_counts, recv_segs = theirs[:, 0].tolist(), theirs[:, 1].tolist()
+        sizes = torch.stack([mine, theirs]).cpu()   # ONE device-to-host copy / sync for all four lists
+        send_counts, send_segs = sizes[0, :, 0].tolist(), sizes[0, :, 1].tolist()
+        recv_counts, recv_segs = sizes[1, :, 0].tolist(), sizes[1, :, 1].tolist()
         # to the owners: rows, segment lengths, weights (bucket order)
         recv_rows = self._a2a(local_rows, send_counts, recv_counts)
         recv_len = self._a2a(seg_len, send_segs, recv_segs)
