@@ -263,8 +263,8 @@ __device__ __forceinline__ void epi_prefetch(const GemmParams& p, EpiOperands& o
       const int64_t gmc = min(row0 + it * 8 + (lane >> 3), p.m - 1);
       if constexpr (EPI == 1) {
         o.ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x) + gmc * p.ep.ldx + gnc);
-        if (p.ep.x0 != p.ep.x)  // first layer of a stack: x is x0, one read serves both
-          o.ex0[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x0) + gmc * p.ep.ldx + gnc);
+        // (unconditional even when x is x0: a predicated load makes hipcc drain the whole load queue)
+        o.ex0[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x0) + gmc * p.ep.ldx + gnc);
       } else {
         o.ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.r) + gmc * p.ep.ldr + gnc);
       }
@@ -312,7 +312,7 @@ __device__ __forceinline__ void epi_process(const GemmParams& p, f32x16 (&acc2)[
       if (p.ep.u_out) store8(p.ep.u_out, KRS_BF16, gm * p.ep.ldu + gn, v);
       float xv[8], x0v[8];
       unpack_bf16x8(o.ex[it], xv);
-      unpack_bf16x8(p.ep.x0 != p.ep.x ? o.ex0[it] : o.ex[it], x0v);
+      unpack_bf16x8(o.ex0[it], x0v);
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = x0v[q] * (v[q] + p.ep.diag_scale * xv[q]) + xv[q];
       store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
