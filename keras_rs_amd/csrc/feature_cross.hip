@@ -1141,6 +1141,11 @@ template <typename T, int V>
 struct RowVec;  // V contiguous elements <-> fp32
 template <>
 struct RowVec<float, 4> {
+  typedef float4 raw_t;
+  static __device__ __forceinline__ raw_t load_raw(const void* p, int64_t o) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + o);
+  }
+  static __device__ __forceinline__ void unpack(const raw_t& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
   static __device__ __forceinline__ void load(const void* p, int64_t o, float (&f)[4]) {
     const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + o);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -1151,6 +1156,16 @@ struct RowVec<float, 4> {
 };
 template <>
 struct RowVec<uint16_t, 8> {
+  typedef uint4 raw_t;
+  static __device__ __forceinline__ raw_t load_raw(const void* p, int64_t o) {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + o);
+  }
+  static __device__ __forceinline__ void unpack(const raw_t& r, float (&f)[8]) {
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
   static __device__ __forceinline__ void load(const void* p, int64_t o, float (&f)[8]) {
     const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + o);
     f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
@@ -1203,16 +1218,36 @@ __global__ __launch_bounds__(64) void cross_bwd_vec_kernel(const CrossParams p, 
   float db[V];
 #pragma unroll
   for (int k = 0; k < V; ++k) db[k] = 0.0f;
+  // two rows of g / x0 / u are kept in flight ahead of the row being processed (clamped row index:
+  // the loads are unconditional)
+  typedef typename RowVec<T, V>::raw_t raw_t;
+  constexpr int AHEAD = 2;
+  raw_t rg[AHEAD], rx0[AHEAD], ru[AHEAD];
+  const void* usrc = p.u ? p.u : p.g;  // without u the value is ignored below
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a) {
+    const int64_t oa = min(r0 + a, r1 - 1) * p.ld + col;
+    rg[a] = RowVec<T, V>::load_raw(p.g, oa);
+    rx0[a] = RowVec<T, V>::load_raw(p.x0, oa);
+    ru[a] = RowVec<T, V>::load_raw(usrc, oa);
+  }
   for (int64_t i = r0; i < r1; ++i) {
     const int64_t o = i * p.ld + col;
     float g[V], u[V], x0[V], x[V], gx0[V], dz[V], t[V];
-    RowVec<T, V>::load(p.g, o, g);
-    RowVec<T, V>::load(p.x0, o, x0);
-    if (p.u) {
-      RowVec<T, V>::load(p.u, o, u);
-    } else {
+    RowVec<T, V>::unpack(rg[0], g);
+    RowVec<T, V>::unpack(rx0[0], x0);
+    RowVec<T, V>::unpack(ru[0], u);
+    if (!p.u) {
 #pragma unroll
       for (int k = 0; k < V; ++k) u[k] = 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a + 1 < AHEAD; ++a) { rg[a] = rg[a + 1]; rx0[a] = rx0[a + 1]; ru[a] = ru[a + 1]; }
+    {
+      const int64_t on = min(i + AHEAD, r1 - 1) * p.ld + col;
+      rg[AHEAD - 1] = RowVec<T, V>::load_raw(p.g, on);
+      rx0[AHEAD - 1] = RowVec<T, V>::load_raw(p.x0, on);
+      ru[AHEAD - 1] = RowVec<T, V>::load_raw(usrc, on);
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
