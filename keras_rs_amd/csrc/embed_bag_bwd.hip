@@ -301,7 +301,9 @@ __device__ __forceinline__ int find_table(const krs_table* tables, int n_tables,
   return lo;
 }
 
-constexpr int kApplyUnroll = 4;
+constexpr int kApplyUnroll = 2;  // gradient rows in flight per group in the per-segment kernel: segments are short
+                                 // (1-2 lookups on average at C3), a wider unroll only issues clamped duplicates
+constexpr int kLongUnroll = 4;   // ... and per group in the hot-row kernel, whose chunks are long
 constexpr int kSegsPerGroup = 4;  // segments each group walks (amortises the descriptor prologue)
 constexpr int kMaxLdsDesc = 512;  // features / tables whose descriptors are cached in LDS
 
@@ -510,14 +512,14 @@ __global__ __launch_bounds__(256) void bag_apply_long_kernel(const ApplyParams p
     float acc[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k] = 0.0f;
-    for (int64_t j0 = c0 + g; j0 < e0; j0 += (int64_t)GPB * kApplyUnroll) {
-      uint64_t vv[kApplyUnroll];
+    for (int64_t j0 = c0 + g; j0 < e0; j0 += (int64_t)GPB * kLongUnroll) {
+      uint64_t vv[kLongUnroll];
 #pragma unroll
-      for (int q = 0; q < kApplyUnroll; ++q) vv[q] = p.vals[min(j0 + (int64_t)q * GPB, e0 - 1)];
-      float coef[kApplyUnroll];
-      u32x4 raw[kApplyUnroll];
+      for (int q = 0; q < kLongUnroll; ++q) vv[q] = p.vals[min(j0 + (int64_t)q * GPB, e0 - 1)];
+      float coef[kLongUnroll];
+      u32x4 raw[kLongUnroll];
 #pragma unroll
-      for (int q = 0; q < kApplyUnroll; ++q) {
+      for (int q = 0; q < kLongUnroll; ++q) {
         const uint32_t bag = (uint32_t)(vv[q] >> 32);
         const uint32_t pos = (uint32_t)vv[q];
         const int f = (int)(bag / (uint32_t)p.batch);
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256) void bag_apply_long_kernel(const ApplyParams p
         }
       }
 #pragma unroll
-      for (int q = 0; q < kApplyUnroll; ++q) {
+      for (int q = 0; q < kLongUnroll; ++q) {
         if (j0 + (int64_t)q * GPB < e0) {
           float gv[N];
           Piece<GT>::unpack(make_uint4(raw[q].x, raw[q].y, raw[q].z, raw[q].w), gv);
