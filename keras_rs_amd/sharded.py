@@ -226,28 +226,54 @@ class ShardedDistributedEmbedding(base.Layer):
 
     # ---------------------------------------------------------------- inputs
     def preprocess(self, inputs: dict, weights: dict | None = None, training: bool = False):
+        """{feature: ids} -> one feature-major id buffer.  A feature is a dense [batch, hot] (or [batch])
+        array, or ragged: an embed_reduce.Ragged (values + row offsets) or a numpy object array of rows;
+        with any ragged feature the bags are described by CSR offsets instead of `hots`."""
+        from keras_rs_amd.layers.distributed_embedding import _ragged_numpy_to_csr
+        from keras_rs_amd.layers.embed_reduce import Ragged
+
         if not self.built:
             self.build()
         dev = self.shard.device
-        parts, wparts, hots, batch = [], [], [], None
+        parts, wparts, hots, lens, batch = [], [], [], [], None
+        ragged = False
         for p in self._paths:
             x = inputs[p]
-            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
-            if t.dim() == 1:
-                t = t.reshape(-1, 1)
-            batch = t.shape[0] if batch is None else batch
-            if t.shape[0] != batch:
+            w = None if weights is None else weights[p]
+            x, w = _ragged_numpy_to_csr(x, w)
+            if isinstance(x, Ragged):
+                ragged = True
+                vals = x.values if isinstance(x.values, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x.values))
+                offs = np.asarray(x.row_offsets.cpu() if isinstance(x.row_offsets, torch.Tensor) else x.row_offsets,
+                                  dtype=np.int64)
+                b = len(offs) - 1
+                t = vals.reshape(-1)
+                hots.append(None)
+                lens.append(np.diff(offs))
+                if w is not None:
+                    w = w.values if isinstance(w, Ragged) else w
+            else:
+                t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+                if t.dim() == 1:
+                    t = t.reshape(-1, 1)
+                b = t.shape[0]
+                hots.append(int(t.shape[1]))
+                lens.append(np.full(b, t.shape[1], dtype=np.int64))
+            batch = b if batch is None else batch
+            if b != batch:
                 raise ValueError("all features must share the batch size")
-            hots.append(int(t.shape[1]))
             parts.append(t.reshape(-1).to(torch.int64 if t.dtype == torch.int64 else torch.int32))
             if weights is not None:
-                w = weights[p]
                 w = w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w))
                 wparts.append(w.reshape(-1).float())
         ids = torch.cat(parts).to(dev, non_blocking=True)
         w = torch.cat(wparts).to(dev, non_blocking=True) if weights is not None else None
+        offsets = None
+        if ragged:
+            offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.int64)).to(dev)
         return {"preprocessed_inputs_per_placement": {"sparsecore": {
-            "inputs": {"ids": ids, "hots": tuple(hots), "batch": batch, "offsets": None}, "weights": w}}}
+            "inputs": {"ids": ids, "hots": None if ragged else tuple(hots), "batch": batch, "offsets": offsets},
+            "weights": w}}}
 
     def _composite_offsets(self, batch, hots, dtype, device):
         key = (batch, hots, dtype, str(device))
@@ -309,13 +335,20 @@ class ShardedDistributedEmbedding(base.Layer):
         return w * scale[idx]
 
     def _forward_impl(self, ids, batch, hots, offsets, weights):
-        if offsets is not None:
-            raise NotImplementedError("ShardedDistributedEmbedding: dense [batch, hot] inputs only")
         k, n, dev = self.kernels, self.world, ids.device
-        nnz, n_bags = ids.numel(), batch * len(hots)
-        comp = ids + self._composite_offsets(batch, hots, ids.dtype, dev)
+        n_feats = len(self._paths)
+        nnz, n_bags = ids.numel(), batch * n_feats
+        if offsets is None:
+            comp = ids + self._composite_offsets(batch, hots, ids.dtype, dev)
+            bag_of_pos, comb_of_bag = self._bag_tables(batch, hots, dev)
+        else:  # ragged bags: CSR offsets over the feature-major bags
+            lens = torch.diff(offsets)
+            bag_of_pos = torch.repeat_interleave(torch.arange(n_bags, dtype=torch.int32, device=dev), lens)
+            _, comb_of_bag = self._bag_tables(batch, (1,) * n_feats, dev)
+            feat_off = torch.tensor([t * self.vloc * self.world for t in self._table_of_feature], dtype=ids.dtype,
+                                    device=dev)
+            comp = ids + feat_off[(bag_of_pos // batch).long()]
         local_rows, perm, counts = k.bucketize(comp, n)
-        bag_of_pos, comb_of_bag = self._bag_tables(batch, hots, dev)
         w_eff = self._lookup_weights(weights, bag_of_pos, comb_of_bag, n_bags)
         # segments: runs of one bag inside a bucket (the bucketise is stable, so bags ascend in a bucket)
         order = perm.long()

@@ -70,7 +70,8 @@ def main():
     from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
     kind = sys.argv[1]
-    use_w = len(sys.argv) < 3 or sys.argv[2] == "w"
+    use_w = len(sys.argv) < 3 or sys.argv[2] in ("w", "wragged")
+    ragged = len(sys.argv) >= 3 and sys.argv[2].endswith("ragged")
     opt = {"sgd": kl.SGD(0.1), "adagrad": kl.Adagrad(0.1, 0.1), "adam": kl.Adam(0.1, 0.9, 0.999, 1e-7),
            "ftrl": kl.Ftrl(0.1, -0.5, 0.1, 0.01, 0.02, 0.3)}[kind]
     V, D, B = [37, 10, 64], 8, 6
@@ -97,20 +98,32 @@ def main():
     ids = {f"f{i}": rng_r.integers(0, V[tix[i]], (B, hots[i])).astype(np.int32) for i in range(4)}
     w = {f"f{i}": rng_r.uniform(0.1, 1, (B, hots[i])).astype(np.float32) if use_w
          else np.ones((B, hots[i]), np.float32) for i in range(4)}
-    out = layer(ids, w if use_w else None)
+    if ragged:
+        # ragged bags (some empty): the reference's form is pad-to-dense with weight 0 (base:31-92), which is
+        # what the unsharded oracle below computes from the masked weights
+        from keras_rs_amd.layers.embed_reduce import Ragged
+
+        keep = {k: np.arange(v.shape[1])[None, :] < rng_r.integers(0, v.shape[1] + 1, (B, 1)) for k, v in ids.items()}
+        r_ids = {k: Ragged.from_rows([row[m] for row, m in zip(ids[k], keep[k])]) for k in ids}
+        r_w = {k: Ragged.from_rows([row[m] for row, m in zip(w[k], keep[k])], dtype=np.float32) for k in ids}
+        out = layer(r_ids, r_w if use_w else None)
+        w = {k: w[k] * keep[k] for k in ids}
+    else:
+        keep = {k: np.ones(v.shape, bool) for k, v in ids.items()}
+        out = layer(ids, w if use_w else None)
     g = {k: torch.from_numpy(rng_r.uniform(0, 1, (B, D)).astype(np.float32)) for k in out}
     sum((o * g[k]).sum() for k, o in out.items()).backward()
 
     # unsharded oracle: forward per rank, table update from the contributions of ALL ranks
     gathered = [None] * world
-    dist.all_gather_object(gathered, (ids, w, {k: v.numpy() for k, v in g.items()}))
+    dist.all_gather_object(gathered, (ids, w, {k: v.numpy() for k, v in g.items()}, keep))
     for i in range(4):
         comb = tcs[tix[i]].combiner
         exp = ko.embed_reduce(full[f"t{tix[i]}"], ids[f"f{i}"], w[f"f{i}"], comb)
         np.testing.assert_allclose(out[f"f{i}"].detach().numpy(), exp, rtol=1e-6, atol=1e-6)
     dense = {k: np.zeros_like(v) for k, v in full.items()}
     touched = {k: np.zeros(v.shape[0], np.uint8) for k, v in full.items()}
-    for r_ids, r_w, r_g in gathered:
+    for r_ids, r_w, r_g, r_keep in gathered:
         for i in range(4):
             comb = tcs[tix[i]].combiner
             tabs = ko.make_tables([dense[f"t{tix[i]}"]])
@@ -121,7 +134,7 @@ def main():
                                  r_w[f"f{i}"].reshape(-1), B, D, tmp, scale)
             ko.embed_bag_bwd_dense(tabs, f, r_ids[f"f{i}"].reshape(-1), None, r_w[f"f{i}"].reshape(-1), scale,
                                    r_g[f"f{i}"], B, D)
-            touched[f"t{tix[i]}"][r_ids[f"f{i}"].reshape(-1)] = 1
+            touched[f"t{tix[i]}"][r_ids[f"f{i}"][r_keep[f"f{i}"]]] = 1
     after = layer.get_embedding_tables()
     for k in full:
         exp = full[k].copy()

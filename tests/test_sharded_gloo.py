@@ -18,9 +18,11 @@ def _free_port():
 
 
 @pytest.mark.parametrize("kind,weighted,world", [("sgd", "w", 2), ("adagrad", "w", 2), ("adagrad", "now", 2),
-                                                 ("sgd", "now", 3), ("adam", "w", 2), ("ftrl", "now", 2)])
+                                                 ("sgd", "now", 3), ("adam", "w", 2), ("ftrl", "now", 2),
+                                                 ("adagrad", "wragged", 2), ("sgd", "nowragged", 2)])
 def test_sharded_embedding_matches_unsharded_oracle(kind, weighted, world):
-    # weighted: user weights on every feature; "now": none (mean / sqrtn scales are still folded in)
+    # weighted: user weights on every feature; "now": none (mean / sqrtn scales are still folded in);
+    # "...ragged": bags of varying length (some empty) given as Ragged values + row offsets
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
