@@ -665,8 +665,12 @@ def concat_features(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
         ordered = len(run) == n_views and all(r[1] == lead + i * dim for i, r in enumerate(run))
         heads = tensors[:start]
         if ordered and all(h.dim() == 2 and h.shape[0] == slab.shape[0] and h.dtype == slab.dtype for h in heads):
-            if sum(h.shape[1] for h in heads) == lead:
-                return SlabFillFn.apply(slab, *heads) if heads else slab
+            # the reserved columns can be handed out once: a second concat with other heads gets a copy
+            if sum(h.shape[1] for h in heads) == lead and not getattr(slab, "_krs_lead_taken", False):
+                if not heads:
+                    return slab
+                slab._krs_lead_taken = True
+                return SlabFillFn.apply(slab, *heads)
             return torch.cat(heads + [slab[:, lead:]], dim=-1)
     return torch.cat(tensors, dim=-1)
 

@@ -449,6 +449,16 @@ def test_concat_features_uses_the_slab_and_trains_like_torch_cat(lead):
     np.testing.assert_allclose(gd_a.cpu().numpy(), gd_b.cpu().numpy(), rtol=1e-5, atol=1e-6)
     for k in t_a:
         np.testing.assert_allclose(t_a[k].cpu().numpy(), t_b[k].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # the reserved columns are handed out once per forward pass: a second concat with another head is a copy
+    if lead == 8:
+        t = kl.TableConfig("t", 40, 8, placement="sparsecore", optimizer="sgd", combiner="sum")
+        layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t, (12, 1), (12, 8))}, slab_lead_cols=8)
+        emb = layer({"a": ids["b"]})
+        d1, d2 = torch.ones(12, 8, device=DEV), torch.full((12, 8), 2.0, device=DEV)
+        c1 = kl.concat_features([d1, emb["a"]])
+        c2 = kl.concat_features([d2, emb["a"]])
+        assert c1.data_ptr() != c2.data_ptr() and torch.all(c1[:, :8] == 1) and torch.all(c2[:, :8] == 2)
+        assert torch.equal(c1[:, 8:], c2[:, 8:])
     # anything that is not "all features of one slab, in order, at the end" is a plain concat
     plain = [torch.ones(2, 3, device=DEV), torch.zeros(2, 2, device=DEV)]
     assert torch.equal(kl.concat_features(plain), torch.cat(plain, dim=-1))
