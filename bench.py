@@ -432,7 +432,7 @@ def main():
         out["host_inputs"] = host
     if full is not None:
         out["full_model"] = full
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:   # the host-CPU leg is timed on rank 0 of the single-GPU run only
         out["cpu_baseline"] = cpu_baseline(a, primary)
     print(json.dumps(out))
 
