@@ -108,6 +108,18 @@ __device__ __forceinline__ void store8(void* base, int dt, int64_t off, const fl
   }
 }
 
+// The streams of the specialised epilogues (x0, x, R in; u, y out) are touched once per launch and
+// are two orders of magnitude larger than L2: non-temporal accesses keep them from evicting the
+// operand panels the other N tiles of the same M panel are about to re-read.
+__device__ __forceinline__ void store8_bf16_nt(void* base, int64_t off, const float (&f)[8]) {
+  const u32x4 v = {pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(base) + off));
+}
+__device__ __forceinline__ uint4 load8_bf16_nt(const void* base, int64_t off) {
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(base) + off));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 __device__ __forceinline__ void unpack_bf16x8(const uint4& r, float (&f)[8]) {
   f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
   f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
@@ -262,11 +274,11 @@ __device__ __forceinline__ void epi_prefetch(const GemmParams& p, EpiOperands& o
     for (int it = 0; it < 4; ++it) {
       const int64_t gmc = min(row0 + it * 8 + (lane >> 3), p.m - 1);
       if constexpr (EPI == 1) {
-        o.ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x) + gmc * p.ep.ldx + gnc);
+        o.ex[it] = load8_bf16_nt(p.ep.x, gmc * p.ep.ldx + gnc);
         // (unconditional even when x is x0: a predicated load makes hipcc drain the whole load queue)
-        o.ex0[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.x0) + gmc * p.ep.ldx + gnc);
+        o.ex0[it] = load8_bf16_nt(p.ep.x0, gmc * p.ep.ldx + gnc);
       } else {
-        o.ex[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.ep.r) + gmc * p.ep.ldr + gnc);
+        o.ex[it] = load8_bf16_nt(p.ep.r, gmc * p.ep.ldr + gnc);
       }
     }
   }
@@ -309,19 +321,19 @@ __device__ __forceinline__ void epi_process(const GemmParams& p, f32x16 (&acc2)[
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = apply_act(p.ep.act, v[q]);
       }
-      if (p.ep.u_out) store8(p.ep.u_out, KRS_BF16, gm * p.ep.ldu + gn, v);
+      if (p.ep.u_out) store8_bf16_nt(p.ep.u_out, gm * p.ep.ldu + gn, v);
       float xv[8], x0v[8];
       unpack_bf16x8(o.ex[it], xv);
       unpack_bf16x8(o.ex0[it], x0v);
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = x0v[q] * (v[q] + p.ep.diag_scale * xv[q]) + xv[q];
-      store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
+      store8_bf16_nt(p.c, gm * p.ldc + gn, v);
     } else if constexpr (EPI == 2) {
       float rv[8];
       unpack_bf16x8(o.ex[it], rv);
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
-      store8(p.c, KRS_BF16, gm * p.ldc + gn, v);
+      store8_bf16_nt(p.c, gm * p.ldc + gn, v);
     } else if (p.splits > 1) {
       float* dst = p.slabs + ((int64_t)split * p.m + gm) * p.n + gn;
       if (p.ep_vec) {
@@ -1173,6 +1185,7 @@ struct RowVec<uint16_t, 8> {
     f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
     f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
   }
+  // (plain accesses: non-temporal ones made these streaming passes 10-15 % slower)
   static __device__ __forceinline__ void store(void* p, int64_t o, const float (&f)[8]) {
     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p) + o) =
         make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
