@@ -235,6 +235,9 @@ struct Piece<uint16_t> {
   }
 };
 
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4n __attribute__((ext_vector_type(4)));
+
 // N consecutive elements <-> fp32; `aligned` = the address is a multiple of N*sizeof(TT)
 // (<= 32 bytes), in which case the access is one or two wide vector instructions.
 template <typename TT, int N>
@@ -243,8 +246,8 @@ __device__ __forceinline__ void load_elems(const TT* src, float (&f)[N], bool al
     if (aligned) {
 #pragma unroll
       for (int i = 0; i < N; i += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src + i);
-        f[i] = v.x; f[i + 1] = v.y; f[i + 2] = v.z; f[i + 3] = v.w;
+        const f32x4n v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(src + i));
+        f[i] = v[0]; f[i + 1] = v[1]; f[i + 2] = v[2]; f[i + 3] = v[3];
       }
     } else {
 #pragma unroll
@@ -253,7 +256,8 @@ __device__ __forceinline__ void load_elems(const TT* src, float (&f)[N], bool al
   } else {
     if (aligned) {
       if constexpr (N == 8) {
-        const uint4 r = *reinterpret_cast<const uint4*>(src);
+        const u32x4n rr = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(src));
+        const uint4 r = make_uint4(rr[0], rr[1], rr[2], rr[3]);
         Piece<uint16_t>::unpack(r, f);
       } else {
         const uint2 r = *reinterpret_cast<const uint2*>(src);
@@ -272,7 +276,7 @@ __device__ __forceinline__ void store_elems(TT* dst, const float (&f)[N], bool a
     if (aligned) {
 #pragma unroll
       for (int i = 0; i < N; i += 4)
-        *reinterpret_cast<float4*>(dst + i) = make_float4(f[i], f[i + 1], f[i + 2], f[i + 3]);
+        __builtin_nontemporal_store(f32x4n{f[i], f[i + 1], f[i + 2], f[i + 3]}, reinterpret_cast<f32x4n*>(dst + i));
     } else {
 #pragma unroll
       for (int i = 0; i < N; ++i) dst[i] = f[i];
@@ -280,8 +284,8 @@ __device__ __forceinline__ void store_elems(TT* dst, const float (&f)[N], bool a
   } else {
     if (aligned) {
       if constexpr (N == 8)
-        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
-                                                    pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+        __builtin_nontemporal_store(u32x4n{pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                                           pack_bf16x2(f[6], f[7])}, reinterpret_cast<u32x4n*>(dst));
       else
         *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
     } else {
