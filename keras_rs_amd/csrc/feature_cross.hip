@@ -7,23 +7,28 @@
 //   elementwise passes over [B, d].
 //
 // krs_gemm: C[M,N] = epilogue(A[M,K] . B[K,N]) for the three operand layouts
-// the layer needs (forward, data gradient, weight gradient):
-//   * 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave
-//     2x2 fragments of v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32
-//     (fp32, exact fmaf chain); fp32 accumulators in registers;
-//   * both operand tiles live in LDS K-contiguous ([row][128 B + 16 B pad]: the
-//     padded 144-byte stride makes ds_read_b128 fragment reads conflict-free),
-//     so a lane's MFMA operand is one 16-byte LDS read; operands stored
-//     K-strided in HBM (keras kernel layout [K,N], or activations contracted
-//     over the batch) are transposed in registers on their way into LDS;
-//   * global->register->LDS staging, next tile's loads issued before the MFMA
-//     phase of the current one (one barrier per K tile, LDS double buffered);
-//   * weight-gradient shapes (tiny M x N, K = batch) are split along K into
-//     fp32 slabs reduced in a fixed order (deterministic, no atomics);
-//   * epilogue on the accumulator: + bias, activation, cross (x0*(v+diag*x)+x),
-//     + beta*R, one rounding to the output dtype.
-// Shapes that do not meet the alignment rules take a plain one-thread-per-
-// output kernel (the reference's toy shapes, d = 3).
+// the layer needs (forward, data gradient, weight gradient).  MFMA throughout:
+// v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, exact fmaf chain), fp32
+// accumulators in registers, a lane's operand = 16 bytes of LDS.  Kernels, by shape:
+//   * gemm_glds256_kernel   both operands K-contiguous, K % 64 == 0, M, N >= 256: 256x256 tile,
+//                           8 waves, two 64 KB stages filled by LDS-DMA (global_load_lds), XOR
+//                           swizzle on the source side;
+//   * gemm_glds_kernel      the same pipeline on a 128x128 tile for smaller M / N (K >= 1024);
+//   * gemm_tn_glds256_kernel / gemm_tn_glds_kernel
+//                           bf16 weight gradients (both operands K-strided): tiles DMA'd as they
+//                           lie in memory, fragments by the transposing ds_read_b64_tr_b16,
+//                           split along K into fp32 slabs (one split per XCD at a time) that are
+//                           reduced in a fixed order (deterministic, no atomics);
+//   * gemm_mfma_kernel      every other aligned shape: global -> register -> LDS staging
+//                           (K-strided operands transposed in registers), one 36 KB buffer,
+//                           three workgroups per CU;
+//   * gemm_thin_kernel      weight gradients with min(M, N) <= 16 (13 dense inputs, 1 unit);
+//   * gemm_generic_kernel   anything else (the reference's toy shapes, d = 3).
+// Epilogue on the accumulator, staged through LDS so that a lane owns 8 consecutive columns:
+// + bias, activation, cross (x0*(v+diag*x)+x), + beta*R, one rounding to the output dtype; the
+// cross / residual forms stream x0 / x / R / u / y with non-temporal accesses.
+// What bounds these products on MI355X is the L2 -> LDS operand path, not MFMA issue (DESIGN.md
+// section 3, scripts/exp/gemm_probe.hip): hence the large tiles.
 #include <algorithm>
 #include <cstring>
 #include <initializer_list>
