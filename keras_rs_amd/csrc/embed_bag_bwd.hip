@@ -10,14 +10,18 @@
 //   vals[p] = (bag(p) << 32) | p               (u64)
 //   stable LSD radix sort of (keys, vals) over ceil(log2(total_rows)) bits
 //   (rocPRIM device radix sort, compiled into this library).
-// Apply: the sorted stream is cut into fixed chunks of positions; a group of
-//   LPR lanes (one 16-byte piece of the gradient row per lane, as in K1) walks
-//   the segments that START in its chunk as one flat stream with four gradient
-//   rows in flight, and on every key change writes the finished row once:
+//   head flags -> exclusive scan -> segment list (first sorted position of every run of equal
+//   keys), and the work items of the segments longer than kLongSeg lookups.
+// Apply: a group of LPR lanes (one 16-byte piece of the gradient row per lane, as in K1) per
+//   SEGMENT = per touched table row: it issues the loads of the row (and optimizer slots) it will
+//   update, gathers and sums the segment's gradient rows, and writes the finished row once:
 //   no atomics, one owner per row, contributions summed in ascending p
-//   => run-to-run bit-identical.  The row write is the dense gradient row, or
-//   the SGD / Adagrad update of the table row in place.
-// Algorithmic bytes: bags*D*s_g + nnz*(4+8) + U*(2*D*s_t [+ 2*D*4 Adagrad]).
+//   => run-to-run bit-identical.  The row write is the dense gradient row, the compact
+//   (unique_rows, grads) entry, or the SGD / Adagrad / Adam / FTRL update of the table row in place.
+//   Hot rows (segments longer than kLongSeg) are summed by whole workgroups in chunks of kChunk
+//   lookups; rows spanning several chunks are finished from fp32 partial rows in chunk order.
+//   Table / slot rows are read and written non-temporally (each is touched once per launch).
+// Algorithmic bytes: bags*D*s_g + nnz*(4+8) + U*(2*D*s_t [+ 2*D*4 per slot plane]).
 #include <cstdlib>
 #include <cstring>
 
