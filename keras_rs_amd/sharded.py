@@ -64,15 +64,28 @@ class HipShardKernels:
 
         return D.mod_bucketize(ids, n_shards)
 
-    def gather_rows(self, table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
-        """table[rows] (K1 one-hot form).  `table` is a per-step tensor here (an output gradient), so its
-        descriptors are not cached."""
+    def _transient_bags(self, table, feats):
+        """FusedBags for a per-step `table` (returned vectors, an output gradient): one object per feature
+        list is kept and re-pointed, so that only the 32-byte table descriptor is uploaded per call."""
         from keras_rs_amd.embedding_ops import FusedBags
 
+        key = ("transient", tuple(feats), table.shape[1], table.dtype)
+        fb = self._shard_bags.get(key)
+        if fb is None:
+            fb = self._shard_bags[key] = FusedBags([table], list(feats))
+        fb.tables = [table]
+        fb.row_bases[:] = (0, table.shape[0])
+        fb.total_rows = int(table.shape[0])
+        return fb
+
+    def gather_rows(self, table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        """table[rows] (K1 one-hot form).  `table` is a per-step tensor here (an output gradient)."""
         n = rows.numel()
         if n == 0:
             return torch.empty((0, table.shape[1]), dtype=table.dtype, device=table.device)
-        out, _ = FusedBags([table], [(0, "sum", 0)]).forward(rows, n, hots=(1,))
+        fb = self._transient_bags(table, [(0, "sum", 0)])
+        out, _ = fb.forward(rows, n, hots=(1,))
+        fb.tables = []   # do not keep the step's tensor alive
         return out
 
     def pool_segments(self, table, rows, offsets, weights, out_dtype):
@@ -87,9 +100,9 @@ class HipShardKernels:
     def pool(self, vectors, ids, feats, batch, offsets, out_dtype, out=None):
         """Home side: bags (feature-major CSR over `ids`) summed out of `vectors` into [batch, n_feats*dim]
         (`out`: a row-major buffer of that shape, possibly a column window of a wider one)."""
-        from keras_rs_amd.embedding_ops import FusedBags
-
-        out, _ = FusedBags([vectors], feats).forward(ids, batch, offsets=offsets, out=out, out_dtype=out_dtype)
+        fb = self._transient_bags(vectors, feats)
+        out, _ = fb.forward(ids, batch, offsets=offsets, out=out, out_dtype=out_dtype)
+        fb.tables = []
         return out
 
     def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None):
@@ -362,7 +375,9 @@ class ShardedDistributedEmbedding(base.Layer):
         head_idx = torch.nonzero(head).squeeze(1)                                   # first lookup of every segment
         seg_bag = bag_b[head_idx]
         seg_len = torch.diff(head_idx, append=torch.tensor([nnz], device=dev)).to(torch.int32)
-        seg_counts = torch.bincount(torch.bucketize(head_idx, ends, right=True), minlength=n)
+        # (scatter_add_ instead of bincount: bincount reads its maximum back to the host)
+        seg_counts = torch.zeros(n, dtype=torch.int64, device=dev).scatter_add_(
+            0, torch.bucketize(head_idx, ends, right=True), torch.ones_like(head_idx))
         # sizes: every rank learns how many lookups / segments it receives (one tiny all-to-all + host sync)
         mine = torch.stack([counts.to(torch.int64), seg_counts.to(torch.int64)], dim=1).contiguous()   # [n, 2]
         theirs = torch.empty_like(mine)
@@ -384,7 +399,9 @@ class ShardedDistributedEmbedding(base.Layer):
         # every bag sums its partials: segments sorted by bag -> feature-major CSR over segment ids
         seg_sorted = torch.argsort(seg_bag, stable=True).to(torch.int32)
         bag_off = torch.zeros(n_bags + 1, dtype=torch.int32, device=dev)
-        bag_off[1:] = torch.cumsum(torch.bincount(seg_bag, minlength=n_bags), 0)
+        per_bag = torch.zeros(n_bags, dtype=torch.int32, device=dev).scatter_add_(
+            0, seg_bag.long(), torch.ones_like(seg_bag, dtype=torch.int32))
+        bag_off[1:] = torch.cumsum(per_bag, 0)
         feats = [(0, "sum", i * self.dim) for i in range(len(self._combiners))]
         lead = self.slab_lead_cols
         slab = torch.empty((batch, lead + len(feats) * self.dim), dtype=back.dtype, device=dev)
