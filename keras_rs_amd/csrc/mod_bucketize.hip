@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void bucket_hist_kernel(const void* ids, int i
     }
   }
   __syncthreads();
-  if (threadIdx.x < n_shards) block_counts[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
+  if ((int)threadIdx.x < n_shards) block_counts[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
 }
 
 // exclusive scan of block_counts laid out [shard][block] (shard-major = final order); also bucket totals
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void bucket_scan_kernel(int* block_counts, int
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const long long y = __shfl_up(x, o, 64);
-      if ((threadIdx.x & 63) >= o) x += y;
+      if ((int)(threadIdx.x & 63) >= o) x += y;
     }
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
     __syncthreads();
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const void* ids, in
                                                              int32_t* perm) {
   __shared__ int run[kMaxShards];        // next free slot of each shard for this block
   __shared__ int wcnt[4][kMaxShards];    // per-wave counts of the current sub-round
-  if (threadIdx.x < n_shards) run[threadIdx.x] = block_offsets[(int64_t)threadIdx.x * gridDim.x + blockIdx.x];
+  if ((int)threadIdx.x < n_shards) run[threadIdx.x] = block_offsets[(int64_t)threadIdx.x * gridDim.x + blockIdx.x];
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kChunk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const void* ids, in
       perm[pos] = (int32_t)q;
     }
     __syncthreads();
-    if (threadIdx.x < n_shards)
+    if ((int)threadIdx.x < n_shards)
       run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
     __syncthreads();
   }
