@@ -213,9 +213,14 @@ class ShardedDistributedEmbedding(base.Layer):
         """Unsharded [V, D] tables by name (all-gather + un-interleave), base:810-825 contract."""
         if not self.built:
             self.build()
-        parts = [torch.empty_like(self.shard.data) for _ in range(self.world)]
         if self.world > 1:
-            dist.all_gather(parts, self.shard.data.contiguous(), group=self._pg)
+            mine = self.shard.data.contiguous()
+            staged = mine.is_cuda and dist.get_backend(self._pg) == "gloo"   # gloo gathers host tensors only
+            src = mine.cpu() if staged else mine
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(parts, src, group=self._pg)
+            if staged:
+                parts = [q.to(mine.device) for q in parts]
         else:
             parts = [self.shard.data]
         out = {}
@@ -315,6 +320,13 @@ class ShardedDistributedEmbedding(base.Layer):
         recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         if self.world == 1:
             recv.copy_(send)
+        elif send.is_cuda and dist.get_backend(self._pg) == "gloo":
+            # gloo has no device all-to-all: stage through the host (debugging / single-GPU test rigs only;
+            # production runs use the nccl = RCCL backend)
+            host = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(host, send.contiguous().cpu(), output_split_sizes=recv_counts,
+                                   input_split_sizes=send_counts, group=self._pg)
+            recv.copy_(host)
         else:
             dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts,
                                    input_split_sizes=send_counts, group=self._pg)
@@ -380,11 +392,10 @@ class ShardedDistributedEmbedding(base.Layer):
             0, torch.bucketize(head_idx, ends, right=True), torch.ones_like(head_idx))
         # sizes: every rank learns how many lookups / segments it receives (one tiny all-to-all + host sync)
         mine = torch.stack([counts.to(torch.int64), seg_counts.to(torch.int64)], dim=1).contiguous()   # [n, 2]
-        theirs = torch.empty_like(mine)
         if n > 1:
-            dist.all_to_all_single(theirs, mine, group=self._pg)
+            theirs = self._a2a(mine, [1] * n, [1] * n)
         else:
-            theirs.copy_(mine)
+            theirs = mine.clone()
         sizes = torch.stack([mine, theirs]).cpu()   # ONE device-to-host copy / sync for all four lists
         send_counts, send_segs = sizes[0, :, 0].tolist(), sizes[0, :, 1].tolist()
         recv_counts, recv_segs = sizes[1, :, 0].tolist(), sizes[1, :, 1].tolist()
