@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the MOD-sharded embedding path even at N = 1 (dry run of the multi-GPU code)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2048)
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo stages through the host and lets "
+                         "several ranks share one GPU: a functional rig, not a measurement)")
     ap.add_argument("--full-model", action="store_true",
                     help="also time one training step of the whole DLRM-DCN-v2 model (examples/dlrm_dcn_v2.py: bottom "
                          "MLP, embeddings, 3 cross layers, top MLP, BCE), reported under `full_model`; never `value`")
@@ -71,7 +74,7 @@ def parse():
     return ap.parse_args()
 
 
-def dist_setup(n):
+def dist_setup(n, backend="nccl"):
     if n <= 1:
         return 0, 1, 0
     import torch.distributed as dist
@@ -79,8 +82,13 @@ def dist_setup(n):
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     world = int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if backend == "gloo":
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     return rank, world, local
 
 
@@ -315,7 +323,7 @@ def pmc_traffic(kernel):
 
 def main():
     a = parse()
-    rank, world, local = dist_setup(a.gpus)
+    rank, world, local = dist_setup(a.gpus, a.dist_backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     b_local = a.batch // world
