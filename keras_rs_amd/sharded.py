@@ -3,15 +3,15 @@
 Layout (the reference's own convention, sharding_strategy="MOD" at
 keras_rs/src/layers/embedding/jax/embedding_utils.py:194, reassembly code at
 tensorflow/distributed_embedding.py:316-328): global row r of every table lives on rank
-r % N at local row r // N.  Each rank keeps ONE stacked buffer [T * Vloc, D] (Vloc =
-ceil(V_max / N)) so that a lookup anywhere in the group is `t * Vloc + r // N`.
+r % N at local row r // N.  Each rank keeps ONE stacked buffer [sum_t ceil(V_t / N), D]; table t
+starts at row off_t = sum_{s<t} ceil(V_s / N), so a lookup anywhere in the group is `off_t + r // N`.
 
 Per step (one process per GPU, torch.distributed over RCCL/xGMI; xGMI is point-to-point, so the
 exchange is an all-to-all whose pairs each use their own link).  What crosses the links is one
 PARTIALLY POOLED vector per (bag, owner) pair that has lookups -- not one vector per lookup: with
 the ml_perf bag lengths (214 lookups per sample) that is 41 vectors per sample at N = 2 and 79 at
 N = 8.
-  fwd  1. composite id c = t*Vloc*N + r  (c % N = owner, c // N = stacked local row)
+  fwd  1. composite id c = off_t*N + r  (c % N = owner, c // N = stacked local row)
        2. K5 MOD-bucketise c (stable: inside a bucket the lookups stay in bag order); runs of equal
           bag inside a bucket are the SEGMENTS; combiner scale (mean / sqrtn) and user weights are
           folded into one weight per lookup; all-to-all of (lookup, segment) counts, all-to-all-v of
@@ -178,7 +178,11 @@ class ShardedDistributedEmbedding(base.Layer):
         self._fused = next(iter(kinds))
         self._opt_kind = self._fused.kind
         self._step = 0
-        self.vloc = max(math.ceil(tc.vocabulary_size / self.world) for tc in tcs)
+        # local rows of table t sit at [row_off[t], row_off[t] + ceil(V_t / N)) of this rank's stacked buffer
+        self._local_rows = [math.ceil(tc.vocabulary_size / self.world) for tc in tcs]
+        self._row_off = [0]
+        for n_loc in self._local_rows:
+            self._row_off.append(self._row_off[-1] + n_loc)
         self._combiners = [feature_configs[p].table.combiner for p in self._paths]
         self.register_parameter("shard", None)
         self._slot = None
@@ -190,7 +194,7 @@ class ShardedDistributedEmbedding(base.Layer):
         if self.shard is not None:
             self.built = True
             return
-        rows = len(self._table_configs) * self.vloc
+        rows = self._row_off[-1]
         shard = torch.zeros((rows, self.dim), dtype=self.variable_dtype, device=self._device)
         for t, tc in enumerate(self._table_configs):
             # rank r holds global rows r, r+N, r+2N, ...: initialise the full table deterministically
@@ -199,9 +203,9 @@ class ShardedDistributedEmbedding(base.Layer):
             init = base.get_initializer(tc.initializer)
             if tc.vocabulary_size * self.dim <= (1 << 24):
                 full = init((tc.vocabulary_size, self.dim), self.variable_dtype, self._device)
-                shard[t * self.vloc: t * self.vloc + n_local] = full[self.rank::self.world]
+                shard[self._row_off[t]: self._row_off[t] + n_local] = full[self.rank::self.world]
             else:
-                shard[t * self.vloc: t * self.vloc + n_local] = init((n_local, self.dim), self.variable_dtype,
+                shard[self._row_off[t]: self._row_off[t] + n_local] = init((n_local, self.dim), self.variable_dtype,
                                                                      self._device)
         self.shard = torch.nn.Parameter(shard, requires_grad=False)
         self._weight_order.append(self.shard)
@@ -228,7 +232,7 @@ class ShardedDistributedEmbedding(base.Layer):
             full = torch.empty((tc.vocabulary_size, self.dim), dtype=self.shard.dtype, device=self.shard.device)
             for r in range(self.world):
                 n_local = len(range(r, tc.vocabulary_size, self.world))
-                full[r::self.world] = parts[r][t * self.vloc: t * self.vloc + n_local]
+                full[r::self.world] = parts[r][self._row_off[t]: self._row_off[t] + n_local]
             out[tc.name] = full
         return out
 
@@ -240,7 +244,7 @@ class ShardedDistributedEmbedding(base.Layer):
                 if tc.name in tables:
                     full = torch.as_tensor(np.asarray(tables[tc.name])).to(self.shard.dtype).to(self.shard.device)
                     mine = full[self.rank::self.world]
-                    self.shard[t * self.vloc: t * self.vloc + mine.shape[0]] = mine
+                    self.shard[self._row_off[t]: self._row_off[t] + mine.shape[0]] = mine
 
     # ---------------------------------------------------------------- inputs
     def preprocess(self, inputs: dict, weights: dict | None = None, training: bool = False):
@@ -297,7 +301,7 @@ class ShardedDistributedEmbedding(base.Layer):
         key = (batch, hots, dtype, str(device))
         off = self._offset_cache.get(key)
         if off is None:
-            per_feat = torch.tensor([self._table_of_feature[i] * self.vloc * self.world for i in range(len(hots))],
+            per_feat = torch.tensor([self._row_off[self._table_of_feature[i]] * self.world for i in range(len(hots))],
                                     dtype=dtype)
             reps = torch.tensor([batch * h for h in hots])
             off = torch.repeat_interleave(per_feat, reps).to(device)
@@ -361,6 +365,8 @@ class ShardedDistributedEmbedding(base.Layer):
 
     def _forward_impl(self, ids, batch, hots, offsets, weights):
         k, n, dev = self.kernels, self.world, ids.device
+        if ids.dtype == torch.int32 and self._row_off[-1] * self.world >= 2 ** 31:
+            ids = ids.long()   # the composite id space (all tables, interleaved over the ranks) needs 64 bits
         n_feats = len(self._paths)
         nnz, n_bags = ids.numel(), batch * n_feats
         if offsets is None:
@@ -370,7 +376,7 @@ class ShardedDistributedEmbedding(base.Layer):
             lens = torch.diff(offsets)
             bag_of_pos = torch.repeat_interleave(torch.arange(n_bags, dtype=torch.int32, device=dev), lens)
             _, comb_of_bag = self._bag_tables(batch, (1,) * n_feats, dev)
-            feat_off = torch.tensor([t * self.vloc * self.world for t in self._table_of_feature], dtype=ids.dtype,
+            feat_off = torch.tensor([self._row_off[t] * self.world for t in self._table_of_feature], dtype=ids.dtype,
                                     device=dev)
             comp = ids + feat_off[(bag_of_pos // batch).long()]
         local_rows, perm, counts = k.bucketize(comp, n)
