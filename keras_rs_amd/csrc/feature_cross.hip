@@ -979,6 +979,19 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const GemmParams 
   for (int s = 0; s < p.splits; ++s) v += p.slabs[(int64_t)s * p.m * p.n + idx];
   epilogue_store(p, idx / p.n, idx % p.n, v);
 }
+// the common weight-gradient case (fp32 C, no epilogue, N % 4 == 0): four columns per thread, same order
+__global__ __launch_bounds__(256) void gemm_slab_reduce_vec4_kernel(const GemmParams p) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;   // group of 4 consecutive columns
+  const int64_t nq = p.n / 4;
+  if (q >= p.m * nq) return;
+  const int64_t i = q / nq, j = (q - i * nq) * 4;
+  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (int s = 0; s < p.splits; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(p.slabs + ((int64_t)s * p.m + i) * p.n + j);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.c) + i * p.ldc + j) = v;
+}
 
 // any shape / alignment: one thread per output element
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmParams p, int in_dtype) {
@@ -1400,7 +1413,12 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
     const int rc = es == 2 ? launch_mfma<2>(p, st) : launch_mfma<4>(p, st);
     if (rc != KRS_OK) return rc;
     if (p.splits > 1) {
-      hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p);
+      const bool vec4 = !p.has_ep && out_dtype == KRS_F32 && n % 4 == 0 && ldc % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(c) & 15) == 0;
+      if (vec4)
+        hipLaunchKernelGGL(gemm_slab_reduce_vec4_kernel, dim3((unsigned)ceil_div(m * (n / 4), 256)), dim3(256), 0, st, p);
+      else
+        hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p);
       KRS_CHECK_LAUNCH("gemm_slab_reduce_kernel");
     }
     return KRS_OK;
