@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -41,6 +42,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ML_PERF_HOTS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
+# Criteo-1TB vocabulary sizes of the 26 categorical features (data of examples/ml_perf/configs/v6e_8.py:15-172)
+CRITEO_VOCABS = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282, 10, 2209, 11938,
+                 155, 4, 976, 14, 40000000, 40000000, 40000000, 590152, 12973, 108, 36]
 HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -57,6 +61,13 @@ def parse():
     ap.add_argument("--cross-layers", type=int, default=3)
     ap.add_argument("--hotness", choices=["mlperf", "1"], default="mlperf",
                     help="primary bag lengths: the ml_perf list (sum L = 214, default) or L = 1; the other one is reported under `also`")
+    ap.add_argument("--criteo-vocab", type=int, default=0, metavar="CAP",
+                    help="per-table vocabularies = min(Criteo-1TB size, CAP) instead of --vocab everywhere: CAP 1000000 "
+                         "is SURVEY.md's C3', CAP 40000000 is C5 (204 M rows: 52 GB of bf16 tables + 105 GB of fp32 "
+                         "Adagrad accumulators on one GPU); needs --tables 26; no cpu_baseline leg")
+    ap.add_argument("--id-skew", type=float, default=0.0, metavar="E",
+                    help="power-law ids: id = perm(floor(V * u^E)) with a fixed affine permutation of the rows "
+                         "(E = 4: 1 %% of the rows draw 32 %% of the lookups); 0 = uniform ids")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the MOD-sharded embedding path even at N = 1 (dry run of the multi-GPU code)")
@@ -71,7 +82,14 @@ def parse():
                     help="also time the step with ids that start in HOST memory, fed through "
                          "keras_rs_amd.data.ThreadedDataLoader with this many loader threads (PCIe-inclusive rate, "
                          "reported under `host_inputs`; never `value`)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.criteo_vocab:
+        if a.tables != len(CRITEO_VOCABS):
+            ap.error("--criteo-vocab needs --tables 26")
+        a.vocabs = [min(v, a.criteo_vocab) for v in CRITEO_VOCABS]
+    else:
+        a.vocabs = [a.vocab] * a.tables
+    return a
 
 
 def dist_setup(n, backend="nccl"):
@@ -105,8 +123,10 @@ class Model(torch.nn.Module):
         opt = kl.Adagrad(learning_rate=0.0034, initial_accumulator_value=0.1)  # configs/v6e_8.py lr
         feats = {}
         for t in range(a.tables):
-            tc = kl.TableConfig(name=f"cat_{t}", vocabulary_size=a.vocab, embedding_dim=a.dim,
-                                initializer=base.RandomUniform(-0.05, 0.05, seed=1337 + t), optimizer=opt,
+            # the 40 M-row tables of C5 are drawn on the device, they never exist in host memory
+            init = base.RandomUniform(-0.05, 0.05, seed=1337 + t, device_rng=bool(a.criteo_vocab))
+            tc = kl.TableConfig(name=f"cat_{t}", vocabulary_size=a.vocabs[t], embedding_dim=a.dim,
+                                initializer=init, optimizer=opt,
                                 combiner="sum", placement="sparsecore")
             feats[f"cat_{t:02d}_id"] = kl.FeatureConfig(f"cat_{t}", tc, (a.batch // world, hots[t]),
                                                        (a.batch // world, a.dim))
@@ -137,8 +157,16 @@ class Model(torch.nn.Module):
 
 def make_inputs(a, hots, b_local, rank, dev):
     g = torch.Generator(device=dev).manual_seed(1338 + rank)
-    ids = {f"cat_{t:02d}_id": torch.randint(0, a.vocab, (b_local, hots[t]), device=dev, generator=g,
-                                            dtype=torch.int32) for t in range(a.tables)}
+    if a.id_skew > 0:
+        ids = {}
+        for t, v in enumerate(a.vocabs):
+            u = torch.rand(b_local, hots[t], device=dev, generator=g, dtype=torch.float64)
+            r = (u.pow(a.id_skew) * v).long().clamp_(max=v - 1)
+            mult = next(m for m in (7368787, 7368791, 7368793, 7368799, 7368803) if math.gcd(m, v) == 1)
+            ids[f"cat_{t:02d}_id"] = ((r * mult + 12345) % v).to(torch.int32)
+    else:
+        ids = {f"cat_{t:02d}_id": torch.randint(0, a.vocabs[t], (b_local, hots[t]), device=dev, generator=g,
+                                                dtype=torch.int32) for t in range(a.tables)}
     dense = (torch.rand(b_local, a.dim, device=dev, generator=g) * 0.9).to(torch.bfloat16)
     return ids, dense
 
@@ -302,7 +330,7 @@ def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False):
     alg = k1_bytes(nnz, nnz if gather_form else b_local * a.tables, a.dim, 2)
     achieved = alg / k1_s
     return {"kernel": kernel, "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": None if gather_form else pmc_traffic(kernel),
+            "frac": achieved / HBM_PEAK, "traffic": None if gather_form or a.criteo_vocab or a.id_skew > 0 else pmc_traffic(kernel),
             "launch_us": k1_s * 1e6,
             "algorithmic_bytes": alg}
 
@@ -404,6 +432,12 @@ def main():
             "embed_gather_hot1 (K1 one-hot form, krs_embed_bag_fwd)"
 
     lookups = a.batch * sum(primary)
+    if a.criteo_vocab:
+        shape_name = "C5 Criteo-1TB scale" if a.criteo_vocab >= 40_000_000 else "C3' (Criteo vocabularies, capped)"
+        rows_desc = "min(Criteo-1TB vocabulary, %d) (%d rows in all)" % (a.criteo_vocab, sum(a.vocabs))
+    else:
+        shape_name, rows_desc = "C3 DLRM-small", "%d" % a.vocab
+    ids_desc = "power-law ids (id = perm(floor(V u^%g)))" % a.id_skew if a.id_skew > 0 else "uniform ids"
     out = {
         "metric": "embedding lookups/sec + DCN fwd+bwd step time, 26-table DLRM batch 65 536",
         "value": lookups / (elapsed / a.steps),
@@ -416,10 +450,10 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": ("C3 DLRM-small: %d tables x %d rows x %d (bf16), global batch %d, %s, "
+            "workload": ("%s: %d tables x %s rows x %d (bf16), global batch %d, %s, %s, "
                          "DotInteraction(F=%d) + %d x FeatureCross(d=%d, projection=%d), fused Adagrad on tables"
-                         % (a.tables, a.vocab, a.dim, a.batch, describe(primary), a.tables + 1, a.cross_layers,
-                            (a.tables + 1) * a.dim, a.projection)),
+                         % (shape_name, a.tables, rows_desc, a.dim, a.batch, describe(primary), ids_desc, a.tables + 1,
+                            a.cross_layers, (a.tables + 1) * a.dim, a.projection)),
             "global_batch": a.batch,
             "parallelism": "single GPU" if world == 1 else f"tables MOD row-sharded over {world} GPUs, dense part DP",
         },
@@ -440,7 +474,7 @@ def main():
         out["host_inputs"] = host
     if full is not None:
         out["full_model"] = full
-    if not a.no_cpu_baseline and world == 1:   # the host-CPU leg is timed on rank 0 of the single-GPU run only
+    if not a.no_cpu_baseline and world == 1 and not a.criteo_vocab:   # the host-CPU leg is timed on rank 0 of the single-GPU run only
         out["cpu_baseline"] = cpu_baseline(a, primary)
     print(json.dumps(out))
 

@@ -94,16 +94,26 @@ class Constant(Initializer):
 
 
 class RandomUniform(Initializer):
-    def __init__(self, minval=-0.05, maxval=0.05, seed=None):
-        self.minval, self.maxval, self.seed = minval, maxval, seed
+    """`device_rng=True` (an extension) draws on the target device in the target dtype, for tables too
+    large to stage through host memory (a 40 M x 128 table is 20 GB in fp32); the values then come from
+    the device generator instead of the host one."""
+
+    def __init__(self, minval=-0.05, maxval=0.05, seed=None, device_rng=False):
+        self.minval, self.maxval, self.seed, self.device_rng = minval, maxval, seed, bool(device_rng)
 
     def __call__(self, shape, dtype=torch.float32, device=None):
+        if self.device_rng and device is not None and torch.device(device).type != "cpu":
+            g = None if self.seed is None else torch.Generator(device=device).manual_seed(int(self.seed))
+            return torch.empty(tuple(shape), dtype=dtype, device=device).uniform_(self.minval, self.maxval, generator=g)
         g = None if self.seed is None else torch.Generator().manual_seed(int(self.seed))
         t = torch.rand(shape, generator=g, dtype=torch.float32) * (self.maxval - self.minval) + self.minval
         return t.to(dtype).to(device)
 
     def get_config(self):
-        return {"minval": self.minval, "maxval": self.maxval, "seed": self.seed}
+        cfg = {"minval": self.minval, "maxval": self.maxval, "seed": self.seed}
+        if self.device_rng:
+            cfg["device_rng"] = True
+        return cfg
 
 
 class VarianceScaling(Initializer):
