@@ -381,23 +381,30 @@ class ShardedDistributedEmbedding(base.Layer):
             comp = ids + feat_off[(bag_of_pos // batch).long()]
         local_rows, perm, counts = k.bucketize(comp, n)
         w_eff = self._lookup_weights(weights, bag_of_pos, comb_of_bag, n_bags)
-        # segments: runs of one bag inside a bucket (the bucketise is stable, so bags ascend in a bucket)
+        # segments: runs of one bag inside a bucket (the bucketise is stable, so bags ascend in a bucket).
+        # Everything up to the size exchange has a data-independent shape (length nnz, valid in the first
+        # n_seg entries), so the host waits for the device exactly once per lookup: for the sizes.
         order = perm.long()
         bag_b = bag_of_pos[order]
         ends = torch.cumsum(counts, 0)
-        head = torch.ones(nnz, dtype=torch.bool, device=dev)
+        starts = ends - counts
+        head = torch.ones(nnz + 1, dtype=torch.bool, device=dev)
         if nnz > 1:
-            head[1:] = bag_b[1:] != bag_b[:-1]
-            starts = ends - counts
-            head[starts[(counts > 0) & (starts < nnz)]] = True
-        head_idx = torch.nonzero(head).squeeze(1)                                   # first lookup of every segment
-        seg_bag = bag_b[head_idx]
-        seg_len = torch.diff(head_idx, append=torch.tensor([nnz], device=dev)).to(torch.int32)
-        # (scatter_add_ instead of bincount: bincount reads its maximum back to the host)
-        seg_counts = torch.zeros(n, dtype=torch.int64, device=dev).scatter_add_(
-            0, torch.bucketize(head_idx, ends, right=True), torch.ones_like(head_idx))
+            head[1:nnz] = bag_b[1:] != bag_b[:-1]
+        head[starts] = True          # an empty bucket's start is the next bucket's (or the spare slot nnz)
+        heads_before = torch.zeros(nnz + 1, dtype=torch.int64, device=dev)
+        heads_before[1:] = torch.cumsum(head[:nnz], 0)                               # segments in front of position p
+        seg_counts = heads_before[ends] - heads_before[starts]                       # per destination bucket
+        # slot s < n_seg: first lookup of segment s; slots n_seg..nnz keep the sentinel nnz; slot nnz + 1
+        # swallows the writes of the non-head positions
+        pos = torch.arange(nnz, dtype=torch.int64, device=dev)
+        slot = torch.where(head[:nnz], heads_before[:nnz], torch.full_like(pos, nnz + 1))
+        first = torch.full((nnz + 2,), nnz, dtype=torch.int64, device=dev)
+        first[slot] = pos
+        seg_len_all = (first[1:nnz + 1] - first[:nnz]).to(torch.int32)
+        seg_bag_all = bag_b[first[:nnz].clamp_(max=max(nnz - 1, 0))]
         # sizes: every rank learns how many lookups / segments it receives (one tiny all-to-all + host sync)
-        mine = torch.stack([counts.to(torch.int64), seg_counts.to(torch.int64)], dim=1).contiguous()   # [n, 2]
+        mine = torch.stack([counts.to(torch.int64), seg_counts], dim=1).contiguous()   # [n, 2]
         if n > 1:
             theirs = self._a2a(mine, [1] * n, [1] * n)
         else:
@@ -405,6 +412,8 @@ class ShardedDistributedEmbedding(base.Layer):
         sizes = torch.stack([mine, theirs]).cpu()   # ONE device-to-host copy / sync for all four lists
         send_counts, send_segs = sizes[0, :, 0].tolist(), sizes[0, :, 1].tolist()
         recv_counts, recv_segs = sizes[1, :, 0].tolist(), sizes[1, :, 1].tolist()
+        n_seg = sum(send_segs)
+        seg_bag, seg_len = seg_bag_all[:n_seg], seg_len_all[:n_seg]
         # to the owners: rows, segment lengths, weights (bucket order)
         recv_rows = self._a2a(local_rows, send_counts, recv_counts)
         recv_len = self._a2a(seg_len, send_segs, recv_segs)
