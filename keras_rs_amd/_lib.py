@@ -137,4 +137,9 @@ def itype(t: torch.Tensor) -> int:
 def struct_to_device(arr: np.ndarray, device) -> torch.Tensor:
     """Uploads a numpy structured array (krs_table / krs_feature) as raw bytes."""
     host = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy())
+    if torch.device(device).type == "cuda":
+        # page-locked staging + asynchronous copy: a pageable upload makes the host wait for everything
+        # queued on the stream (a pipeline drain per descriptor; the host allocator keeps the staging
+        # block alive until the copy has run)
+        return host.pin_memory().to(device, non_blocking=True)
     return host.to(device)
