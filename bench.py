@@ -246,13 +246,20 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         # gradients: the reduction to a scalar is not part of the hot path
         torch.autograd.backward([xl, inter], [g_xl, g_inter])
         if opt_box[0] is None:  # the first step has built the cross layers
-            opt_box[0] = torch.optim.Adagrad([p for layer in model.cross for p in layer.parameters()], lr=0.0034,
-                                             initial_accumulator_value=0.1, foreach=True)
+            params = [p for layer in model.cross for p in layer.parameters()]
+            opt_box[0] = torch.optim.Adagrad(params, lr=0.0034, initial_accumulator_value=0.1, foreach=True)
+            if world > 1:
+                # dense weights are data-parallel: from the next backward on, each gradient's all-reduce starts
+                # the moment autograd has produced it and overlaps the rest of the backward pass
+                from keras_rs_amd.dp import GradAllReduce
+
+                # (on a communicator of their own, so that they do not queue in front of the embedding's all-to-alls)
+                opt_box.append(GradAllReduce(params, group=torch.distributed.new_group()))
+                for p in params:
+                    opt_box[1].launch(p)
         opt = opt_box[0]
         if world > 1:
-            for p in opt.param_groups[0]["params"]:
-                torch.distributed.all_reduce(p.grad)
-                p.grad.div_(world)
+            opt_box[1].wait()
         opt.step()
         opt.zero_grad(set_to_none=True)
 
