@@ -56,16 +56,40 @@ def _gather_feature_grads(grads, batch: int, dim: int, dtype, device):
     return torch.cat(parts, dim=1)
 
 
+class Dx0Relay:
+    """Carries dL/dx0 down a stack of cross layers that share x0 (`xl = layer(x0, xl)` repeated,
+    examples/ml_perf/model.py:332-336).  Every layer of the stack contributes a [B, d] term to dL/dx0;
+    left to autograd these are summed by separate elementwise adds (1.4 GB of traffic each at C3).
+    Instead the layer whose backward runs first writes its term into a buffer and leaves it here, on the
+    relay it shares with the layer that produced its `x`; that layer's backward -- which autograd is bound
+    to run next on this path, since it is handed dL/dx -- accumulates into the buffer inside its
+    elementwise kernel (`dx0_accumulate` of krs_cross_epilogue_bwd) and passes it on, and the bottom layer
+    of the stack returns the total.  `task` is the autograd graph-task id of the pass that filled `buf`:
+    a buffer left over from another backward pass is ignored."""
+
+    __slots__ = ("x0", "buf", "task")
+
+    def __init__(self, x0: torch.Tensor):
+        self.x0, self.buf, self.task = x0, None, -1
+
+    def matches(self, x0: torch.Tensor) -> bool:
+        a = self.x0
+        return (a.data_ptr() == x0.data_ptr() and a.shape == x0.shape and a.stride() == x0.stride()
+                and a.dtype == x0.dtype and a._version == x0._version)
+
+
 class CrossLayerFn(torch.autograd.Function):
     """y = x0 * (act(h @ K + b) + diag * x) + x,  h = x (full rank) or x @ U (low rank).
 
     Reference: FeatureCross.call, feature_cross.py:182-194.  Forward = one MFMA GEMM
     per Dense with the cross epilogue fused; backward = one elementwise pass
     (dz, dx0, bias gradient) + the data/weight-gradient GEMMs.
-    Weight layouts are the keras ones: U [d, p], K [p or d, d], b [d]."""
+    Weight layouts are the keras ones: U [d, p], K [p or d, d], b [d].
+    relay_in: the Dx0Relay a consumer of y may fill; relay_up: the relay of the layer that produced x
+    (None when x does not come from a cross layer on the same x0)."""
 
     @staticmethod
-    def forward(ctx, x0, x, down, kernel, bias, diag_scale, act, compute_dtype):
+    def forward(ctx, x0, x, down, kernel, bias, diag_scale, act, compute_dtype, relay_in=None, relay_up=None):
         same = x is x0 or (x.data_ptr() == x0.data_ptr() and x.shape == x0.shape and x.stride() == x0.stride())
         cd = compute_dtype
         x0c = x0.to(cd).contiguous()
@@ -84,6 +108,9 @@ class CrossLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x0c, xc, h if down is not None else None, u, dc, kc)
         ctx.meta = (diag_scale, act, same, down is not None, bias is not None,
                     x0.dtype, x.dtype, None if down is None else down.dtype, kernel.dtype)
+        ctx.relay_in = relay_in
+        both = ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        ctx.relay_up = relay_up if (relay_up is not None and not same and both and relay_up.matches(x0)) else None
         return y
 
     @staticmethod
@@ -92,10 +119,23 @@ class CrossLayerFn(torch.autograd.Function):
         diag, act, same, low_rank, has_bias, x0_dt, x_dt, down_dt, k_dt = ctx.meta
         g = g.to(x0c.dtype).contiguous()
         need_dxd = bool(diag) and not same
+        task = torch._C._current_graph_task_id()
+        # dL/dx0 of the layers above, left by the consumer of y during this backward pass
+        incoming, extra = None, None
+        rin = ctx.relay_in
+        if rin is not None and rin.buf is not None:
+            if rin.task == task and task != -1:
+                if rin.buf.dtype == x0c.dtype and rin.buf.shape == x0c.shape and rin.buf.is_contiguous():
+                    incoming = rin.buf
+                else:
+                    extra = rin.buf
+            rin.buf = None
         # x is x0 (the first layer of a stack): both halves of dL/dx0 go through one buffer, which
         # the data-gradient GEMM then takes as its residual -- no separate add.
         dz, dx0, dxd, dbias = D.cross_epilogue_bwd(g, u, x0c, xc, diag, act=act, want_dxd=need_dxd,
-                                                   want_dbias=has_bias, fold_direct=same)
+                                                   want_dbias=has_bias, fold_direct=same, dx0_into=incoming)
+        if extra is not None:
+            dx0 = dx0 + extra.to(dx0.dtype)
         direct = dx0 if same else (dxd if need_dxd else g)  # dL/dx through "+ x" and "diag * x"
         if low_rank:
             dk, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)      # dK = h^T dz     [p, d]
@@ -109,9 +149,17 @@ class CrossLayerFn(torch.autograd.Function):
         if same:
             gx0, gx = dx.to(x0_dt), None
         else:
-            gx0, gx = dx0.to(x0_dt), dx.to(x_dt)
+            gx, up = dx.to(x_dt), ctx.relay_up
+            if up is not None and task != -1:
+                # the producer of x takes it from here (its backward runs later in this pass: it is owed dL/dx)
+                if up.buf is not None and up.task == task:
+                    dx0 = dx0 + up.buf      # x has a second cross-layer consumer that already left its term
+                up.buf, up.task = dx0, task
+                gx0 = None
+            else:
+                gx0 = dx0.to(x0_dt)
         return (gx0, gx, None if dd is None else dd.to(down_dt), dk.to(k_dt),
-                dbias if has_bias else None, None, None, None)
+                dbias if has_bias else None, None, None, None, None, None)
 
 
 class DenseFn(torch.autograd.Function):

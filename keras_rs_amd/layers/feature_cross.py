@@ -12,7 +12,7 @@ from typing import Any
 import torch
 
 from keras_rs_amd import _lib as L
-from keras_rs_amd.autograd import CrossEpilogueFn, CrossLayerFn
+from keras_rs_amd.autograd import CrossEpilogueFn, CrossLayerFn, Dx0Relay
 from keras_rs_amd.layers import base
 
 _FUSED_ACTS = {None: L.ACT_NONE, base.linear: L.ACT_NONE, base.relu: L.ACT_RELU,
@@ -73,8 +73,13 @@ class FeatureCross(base.Layer):
         diag = float(self.diag_scale) if self.diag_scale else 0.0
         act = self.pre_activation
         if act in _FUSED_ACTS:
+            # dL/dx0 travels down a stack of layers on the same x0 through relays instead of autograd adds
+            relay = Dx0Relay(x02)
             y = CrossLayerFn.apply(x02, x2, self.down_kernel, self.kernel, self.bias, diag, _FUSED_ACTS[act],
-                                   self.compute_dtype)
+                                   self.compute_dtype, relay, None if same else getattr(x, "_krs_dx0_relay", None))
+            out = y.reshape(*lead, d)
+            out._krs_dx0_relay = relay
+            return out
         else:
             # arbitrary callable: GEMM(+bias) on MFMA, the callable on the host framework, cross kernel fused
             cd = self.compute_dtype

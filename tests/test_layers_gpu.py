@@ -97,6 +97,77 @@ def test_feature_cross_same_tensor_twice_and_dcn_stack():
     np.testing.assert_allclose(x0.grad.cpu().numpy(), r0.grad.cpu().numpy(), rtol=5e-5, atol=5e-5)
 
 
+def _stack_reference(layers, x0, top, diag, act):
+    """float64 composition of `top(xl)` through the stack; returns d/dx0 and the weight gradients."""
+    r0 = x0.detach().double().requires_grad_()
+    ws = [[t.detach().double().requires_grad_() for t in layer.weights] for layer in layers]
+    outs, rl = [], r0
+    for w in ws:
+        rl = _torch_cross(r0, rl, w[0], w[1], w[2], diag, act)
+        outs.append(rl)
+    top(outs).backward()
+    return r0.grad, [[t.grad for t in w] for w in ws]
+
+
+@pytest.mark.parametrize("shape", [(45, 40), (3, 7, 24)])
+def test_cross_stack_hands_dx0_down_the_layers(shape):
+    """A stack on one x0 passes dL/dx0 from layer to layer (autograd.Dx0Relay) instead of leaving three
+    adds to autograd: same numbers as the float64 composition, also when an intermediate output has a
+    second consumer, and a buffer left behind by a partial backward pass is not picked up later."""
+    kl = _layers()
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(shape, generator=g).to(DEV).requires_grad_()
+    layers = [kl.FeatureCross(projection_dim=8, diag_scale=0.2, pre_activation="tanh", bias_initializer="uniform")
+              for _ in range(3)]
+    gy = torch.randn(shape, generator=g).to(DEV)
+
+    def run(top):
+        x0.grad = None
+        for layer in layers:
+            for w in layer.weights:
+                w.grad = None
+        outs, xl = [], x0
+        for layer in layers:
+            xl = layer(x0, xl)
+            outs.append(xl)
+        return outs, top(outs)
+
+    def check(top, rtol=5e-5):
+        ref0, refw = _stack_reference(layers, x0, top, 0.2, "tanh")
+        np.testing.assert_allclose(x0.grad.cpu().numpy(), ref0.cpu().numpy(), rtol=rtol, atol=rtol)
+        for layer, rw in zip(layers, refw):
+            for w, r in zip(layer.weights, rw):
+                if r is not None:
+                    np.testing.assert_allclose(w.grad.cpu().numpy(), r.cpu().numpy(), rtol=rtol, atol=rtol)
+
+    plain = lambda outs: (outs[-1] * gy.to(outs[-1].dtype)).sum()                      # noqa: E731
+    outs, loss = run(plain)
+    assert all(hasattr(o, "_krs_dx0_relay") for o in outs)
+    loss.backward()
+    check(plain)
+    # the middle output feeds the next layer AND the loss
+    forked = lambda outs: (outs[-1] * gy.to(outs[-1].dtype)).sum() + (outs[1] ** 2).sum()  # noqa: E731
+    outs, loss = run(forked)
+    loss.backward()
+    check(forked)
+    # partial pass first (gradient w.r.t. the middle output only: the top layer leaves its dx0 term behind),
+    # then the full pass on the same graph, then a pass that stops below the top layer
+    outs, loss = run(plain)
+    torch.autograd.grad(loss, [outs[1]], retain_graph=True)
+    loss.backward(retain_graph=True)
+    check(plain)
+    outs, loss = run(plain)
+    torch.autograd.grad(loss, [outs[1]], retain_graph=True)       # leaves a buffer on the middle layer's relay
+    x0.grad = None
+    for layer in layers:
+        for w in layer.weights:
+            w.grad = None
+    (outs[1] * gy).sum().backward()                               # must not pick it up
+    lower = lambda o: (o[1] * gy.to(o[1].dtype)).sum()            # noqa: E731
+    ref0, _ = _stack_reference(layers[:2], x0, lower, 0.2, "tanh")
+    np.testing.assert_allclose(x0.grad.cpu().numpy(), ref0.cpu().numpy(), rtol=5e-5, atol=5e-5)
+
+
 def test_feature_cross_bf16_policy():
     kl = _layers()
     g = torch.Generator().manual_seed(2)
