@@ -253,8 +253,9 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
                 # the moment autograd has produced it and overlaps the rest of the backward pass
                 from keras_rs_amd.dp import GradAllReduce
 
-                # (on a communicator of their own, so that they do not queue in front of the embedding's all-to-alls)
-                opt_box.append(GradAllReduce(params, group=torch.distributed.new_group()))
+                # (same communicator as the embedding's all-to-alls: RCCL runs them in issue order, no second
+                # communicator whose kernels could interleave differently on different ranks)
+                opt_box.append(GradAllReduce(params))
                 for p in params:
                     opt_box[1].launch(p)
         opt = opt_box[0]
