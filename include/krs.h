@@ -261,6 +261,13 @@ int krs_gemm(const void* a, int64_t lda, int a_is_km,
              void* workspace, size_t workspace_bytes, void* stream);
 size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
 
+/* Tuning / diagnostic switches of krs_gemm (process-wide; results never depend on them).
+ *   KRS_GEMM_OPT_PIPELINE: main loop of the 256x256 bf16 tiles -- 0 = two-stage loop that drains the
+ *   DMA queue once per K tile, 4 / 5 = ping-pong ring with that many 32-deep stages (default 4, or
+ *   the environment variable KRS_GEMM_PIPE at first use). */
+enum { KRS_GEMM_OPT_PIPELINE = 0 };
+int krs_gemm_set_option(int key, int value);
+
 /* Elementwise halves of FeatureCross for the host-composed path (arbitrary
  * pre_activation callables) and for the backward:
  *   fwd: y = x0 * (u + diag_scale*x) + x                     feature_cross.py:191-194

@@ -9,7 +9,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int ROW_BYTES = 128;
 template <int MODE, int NSTAGE, int BKB, bool TILED>  // BKB: bytes of K per row per stage (128 or 64); TILED: [K/BK][rows][BK] operand layout
 __global__ __launch_bounds__(512) void k(const char* a, const char* b, float* c, int64_t m, int64_t n, int64_t kk,
-                                          int64_t lda, int64_t ldb) {
+                                          int64_t lda, int64_t ldb, int64_t mwrap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = 2;
   constexpr int OPA = 256 * BKB;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512) void k(const char* a, const char* b, float* c,
   const int wm = wave >> 2, wn = wave & 3;
   const int64_t nt = n / 256;
   const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int64_t m0 = ((slot / nt) * 8 + xcd) * 256, n0 = (slot % nt) * 256;
+  const int64_t m0 = (((slot / nt) * 8 + xcd) * 256) % mwrap, n0 = (slot % nt) * 256;
   const int64_t ntiles = kk * ES / BKB;
   const char* asrc[NI]; const char* bsrc[NI];
 #pragma unroll
@@ -97,15 +97,17 @@ __global__ __launch_bounds__(512) void k(const char* a, const char* b, float* c,
   if (s == 12345.678f) c[threadIdx.x] = s;
 }
 template <int MODE, int NSTAGE, int BKB, bool TILED = false>
-void run(const char* name, const char* a, const char* b, float* c, int64_t m, int64_t n, int64_t kk) {
+void run(const char* name, const char* a, const char* b, float* c, int64_t m, int64_t n, int64_t kk, int64_t ld = 0, int64_t mwrap = 0) {
+  if (!ld) ld = kk;
+  if (!mwrap) mwrap = m;
   const size_t lds = (size_t)NSTAGE * 512 * BKB;
   auto kern = k<MODE, NSTAGE, BKB, TILED>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = (unsigned)((m / 256) * (n / 256));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, a, b, c, m, n, kk, kk, kk);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, a, b, c, m, n, kk, ld, ld, mwrap);
   hipEventRecord(e0);
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, a, b, c, m, n, kk, kk, kk);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, a, b, c, m, n, kk, ld, ld, mwrap);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("%-34s %8.1f us  %7.1f TF/s  (err %s)\n", name, ms * 100, 2.0 * m * n * kk / (ms * 1e-4) / 1e12, hipGetErrorString(hipGetLastError()));
@@ -113,7 +115,7 @@ void run(const char* name, const char* a, const char* b, float* c, int64_t m, in
 int main() {
   const int64_t m = 65536, n = 512, kk = 3456;
   char *a, *b; float* c;
-  hipMalloc(&a, m * kk * 2); hipMalloc(&b, n * kk * 2); hipMalloc(&c, 4096);
+  hipMalloc(&a, m * 4096 * 2); hipMalloc(&b, n * 4096 * 2); hipMalloc(&c, 4096);
   std::vector<uint16_t> h(m * kk);
   uint32_t x = 12345;
   for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((x >> 16) & 0x3ff) | ((x >> 31) << 15)); }
@@ -129,5 +131,20 @@ int main() {
   run<1, 2, 128, true>("DMA    2 stages BK=64 tiled", a, b, c, m, n, kk);
   run<0, 4, 64, true>("full   4 stages BK=32 tiled", a, b, c, m, n, kk);
   run<1, 4, 64, true>("DMA    4 stages BK=32 tiled", a, b, c, m, n, kk);
+  // row stride of the operands (elements): 54 / 55 / 56 / 64 lines of 128 B per row
+  run<1, 2, 128>("DMA    2 stages BK=64 ld=3456", a, b, c, m, n, kk, 3456);
+  run<1, 2, 128>("DMA    2 stages BK=64 ld=3520", a, b, c, m, n, kk, 3520);
+  run<1, 2, 128>("DMA    2 stages BK=64 ld=3584", a, b, c, m, n, kk, 3584);
+  run<1, 2, 128>("DMA    2 stages BK=64 ld=4096", a, b, c, m, n, kk, 4096);
+  run<0, 2, 128>("full   2 stages BK=64 ld=3520", a, b, c, m, n, kk, 3520);
+  run<1, 4, 64>("DMA    4 stages BK=32 ld=3520", a, b, c, m, n, kk, 3520);
+  // A confined to its first rows (cache-resident after the first touch): is the row-major limit HBM-side?
+  run<1, 2, 128>("DMA    2 stages BK=64 A=8192 rows", a, b, c, m, n, kk, 0, 8192);
+  run<1, 4, 64>("DMA    4 stages BK=32 A=8192 rows", a, b, c, m, n, kk, 0, 8192);
+  run<1, 2, 128, true>("DMA    2 stages BK=64 tiled A=8192 rows", a, b, c, m, n, kk, 0, 8192);
+  run<1, 4, 64, true>("DMA    4 stages BK=32 tiled A=8192 rows", a, b, c, m, n, kk, 0, 8192);
+  run<1, 2, 128>("DMA    2 stages BK=64 A=2048 rows", a, b, c, m, n, kk, 0, 2048);
+  run<1, 4, 64>("DMA    4 stages BK=32 A=2048 rows", a, b, c, m, n, kk, 0, 2048);
+  run<0, 2, 128>("full   2 stages BK=64 A=2048 rows", a, b, c, m, n, kk, 0, 2048);
   return 0;
 }
