@@ -48,22 +48,42 @@ class DCNBlock(torch.nn.Module):
 
 
 class DLRMDCNV2(torch.nn.Module):
+    """model.py:30-212.  small_emb_features: the tables under `embedding_threshold` (main.py:135-141), a list of
+    {"name", "new_name", "vocabulary_size"}: plain Embedding layers, LecunNormal(seed) tables, bags pooled
+    with a sum over axis -2, concatenated behind the large embeddings (model.py:128-148, 185-207)."""
+
     def __init__(self, large_emb_feature_configs, embedding_dim, bottom_mlp_dims, top_mlp_dims, num_dcn_layers,
-                 dcn_projection_dim, seed=1337, dtype="mixed_bfloat16", embedding_dtype="bfloat16"):
+                 dcn_projection_dim, seed=1337, dtype="mixed_bfloat16", embedding_dtype="bfloat16",
+                 small_emb_features=None):
         super().__init__()
         assert bottom_mlp_dims[-1] == embedding_dim, "the bottom MLP output is one more 'feature' of the interaction"
         self.bottom_mlp = mlp_layers(bottom_mlp_dims, "relu", "relu", seed, dtype)
         self.embedding_layer = kl.DistributedEmbedding(large_emb_feature_configs, table_stacking="auto",
                                                        dtype=embedding_dtype, name="embedding_layer",
                                                        slab_lead_cols=embedding_dim)
+        self.small_emb_features = small_emb_features
+        self.small_embedding_layers = None
+        if small_emb_features:
+            # EmbedReduce(combiner="sum") = keras.layers.Embedding followed by ops.sum(axis=-2) (model.py:195-198)
+            # as ONE gather+pool launch per feature
+            self.small_embedding_layers = torch.nn.ModuleDict({
+                f"{f['new_name']}_id": kl.EmbedReduce(f["vocabulary_size"], embedding_dim, combiner="sum",
+                                                      embeddings_initializer=base.LecunNormal(seed=seed),
+                                                      dtype=embedding_dtype,
+                                                      name=f"small_embedding_layer_{f['new_name']}")
+                for f in small_emb_features})
         self.dcn_block = DCNBlock(num_dcn_layers, dcn_projection_dim, seed, dtype)
         self.top_mlp = mlp_layers(top_mlp_dims, "relu", "sigmoid", seed, dtype)
 
     def forward(self, inputs):
         dense_output = self.bottom_mlp(inputs["dense_input"])                     # model.py:183
         large_embeddings = self.embedding_layer(inputs["large_emb_inputs"])      # model.py:184
-        x = kl.concat_features([dense_output.to(next(iter(large_embeddings.values())).dtype),
-                                *large_embeddings.values()])                      # model.py:204-207
+        emb_dtype = next(iter(large_embeddings.values())).dtype
+        x = kl.concat_features([dense_output.to(emb_dtype), *large_embeddings.values()])   # model.py:204-207
+        if self.small_embedding_layers is not None:
+            small = [self.small_embedding_layers[k](v).to(emb_dtype)                       # model.py:189-201
+                     for k, v in inputs["small_emb_inputs"].items()]
+            x = torch.cat([x, *small], dim=-1)
         x = self.dcn_block(x)
         return self.top_mlp(x)                                                    # model.py:211
 
@@ -78,16 +98,24 @@ def synthetic_batch(batch, n_dense, vocab, hots, device, seed=0):
 
 
 def build_model(batch, vocab, hots, embedding_dim=128, projection=512, cross_layers=3, table_optimizer=None,
-                bottom=(512, 256, 128), top=(1024, 1024, 512, 256, 1)):
+                bottom=(512, 256, 128), top=(1024, 1024, 512, 256, 1), embedding_threshold=0, dtype="mixed_bfloat16",
+                embedding_dtype="bfloat16"):
+    """vocab: one size for every table or a list (the Criteo vocabularies of configs/v6e_8.py); tables smaller
+    than `embedding_threshold` become small (plain, trainable) embeddings as in main.py:135-141."""
     opt = table_optimizer or kl.Adagrad(learning_rate=0.0034, initial_accumulator_value=0.1)  # configs/v6e_8.py
-    feats = {}
+    vocabs = list(vocab) if isinstance(vocab, (list, tuple)) else [vocab] * len(hots)
+    feats, small = {}, []
     for t, h in enumerate(hots):
-        tc = kl.TableConfig(name=f"cat_{t}", vocabulary_size=vocab, embedding_dim=embedding_dim,
+        if vocabs[t] < embedding_threshold:
+            small.append({"name": f"cat_{t}", "new_name": f"cat_{t:02d}", "vocabulary_size": vocabs[t]})
+            continue
+        tc = kl.TableConfig(name=f"cat_{t}", vocabulary_size=vocabs[t], embedding_dim=embedding_dim,
                             initializer=base.RandomUniform(-0.05, 0.05, seed=1337 + t), optimizer=opt,
                             combiner="sum", placement="sparsecore")
         feats[f"cat_{t:02d}_id"] = kl.FeatureConfig(f"cat_{t}", tc, (batch, h), (batch, embedding_dim))
     bottom = tuple(bottom[:-1]) + (embedding_dim,)
-    return DLRMDCNV2(feats, embedding_dim, list(bottom), list(top), cross_layers, projection)
+    return DLRMDCNV2(feats, embedding_dim, list(bottom), list(top), cross_layers, projection, dtype=dtype,
+                     embedding_dtype=embedding_dtype, small_emb_features=small or None)
 
 
 def train_step(model, opt_box, inputs, labels):

@@ -243,11 +243,15 @@ class EmbedBagFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, check_ids, *tables):
-        # `tables` are passed explicitly so autograd tracks them; `bags.tables` hold the same storage
-        err = torch.zeros(1, dtype=torch.int32, device=ids.device) if check_ids else None
+        # `tables` are passed explicitly so autograd tracks them; `bags.tables` hold the same storage.
+        # check_ids: True = read the kernel's error word now (one host sync; EmbedReduce does that);
+        # a device int32[1] tensor = let the kernel OR its bits into it and return (the caller reads it
+        # later: DistributedEmbedding.check_ids); False / None = no report.
+        lazy = isinstance(check_ids, torch.Tensor)
+        err = check_ids if lazy else (torch.zeros(1, dtype=torch.int32, device=ids.device) if check_ids else None)
         out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
                                   out_dtype=out_dtype, want_scale=True, err_flag=err)
-        if check_ids and int(err.item()) & L.FLAG_ID_OUT_OF_RANGE:
+        if check_ids is True and int(err.item()) & L.FLAG_ID_OUT_OF_RANGE:
             raise IndexError("embedding id out of range for its table (ids are never clamped)")
         ctx.bags, ctx.batch, ctx.hots = bags, batch, hots
         ctx.save_for_backward(ids, offsets, weights, scale)
@@ -274,14 +278,16 @@ class EmbedBagFusedFn(torch.autograd.Function):
     backward runs; it receives a zero gradient."""
 
     @staticmethod
-    def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, optimizer, anchor, lead=0):
+    def forward(ctx, bags, ids, batch, hots, offsets, weights, out_dtype, optimizer, anchor, lead=0, err_flag=None):
         # outputs: the whole slab [B, lead + n*dim] (columns 0..lead are left for the caller, see
         # layers.concat_features) followed by the per-feature column views
         ctx.set_materialize_grads(False)  # unused outputs (slab or views) arrive as None, not as zero tensors
         n = len(bags.features)
         slab = torch.empty((batch, lead + n * bags.dim), dtype=out_dtype or bags.dtype, device=ids.device)
+        # err_flag: device int32[1] the kernel ORs KRS_FLAG_* into (out-of-range ids contribute nothing and are
+        # never clamped); read later by the layer, so the step keeps running without a host sync
         out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
-                                  out=slab[:, lead:], want_scale=True)
+                                  out=slab[:, lead:], want_scale=True, err_flag=err_flag)
         ctx.bags, ctx.batch, ctx.hots, ctx.optimizer, ctx.lead = bags, batch, hots, optimizer, lead
         ctx.save_for_backward(ids, offsets, weights, scale)
         ctx.out_meta = (out.dtype, out.device)
@@ -319,7 +325,7 @@ class EmbedBagFusedFn(torch.autograd.Function):
         hyper = None if isinstance(opt, str) else opt.next_hyper()   # also refreshes scheduled learning rates
         bags.backward_fused(kind, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                             bag_scale=scale, hyper=hyper)
-        return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device), None)
+        return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device), None, None)
 
 
 class SlabFillFn(torch.autograd.Function):

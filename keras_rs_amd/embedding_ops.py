@@ -51,8 +51,11 @@ class FusedBags:
         """krs_table array on the device (rebuilt when a storage pointer moved)."""
         weights = self.tables if weights is None else weights
         slots = self.slots if slots is None else slots
+        # everything a descriptor carries is in the key: a caller may re-point `self.tables` at a tensor that the
+        # caching allocator placed at the previous step's address with a different row count (the sharded layer's
+        # transient tables do: their height is the data-dependent number of segments)
         key = tuple(w.data_ptr() for w in weights) + tuple(0 if s is None else s.data_ptr() for s in slots) \
-            + tuple(self.lrs)
+            + tuple(self.lrs) + tuple(int(w.shape[0]) for w in weights) + tuple(int(b) for b in self.row_bases)
         cacheable = weights is self.tables
         if cacheable and key == self._tab_key:
             return self._tab_dev

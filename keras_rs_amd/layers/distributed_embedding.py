@@ -245,6 +245,9 @@ class DistributedEmbedding(base.Layer):
         self.update_stats = update_stats
         self._lock = threading.Lock()
         self._anchor = None
+        self._err_dev = None      # device int32[1]: the lookup kernels OR their KRS_FLAG_* bits into it
+        self._err_host = None     # its page-locked mirror, refreshed asynchronously after every call
+        self._err_event = None
         self._init_feature_configs_structures(feature_configs)
         self._groups: dict[str, list[_Group]] = {}
         self._table_params: dict[int, torch.nn.Parameter] = {}
@@ -436,6 +439,41 @@ class DistributedEmbedding(base.Layer):
         del training
         return self._fuse_inputs("default_device", inputs, weights)
 
+    # ---- out-of-range ids: flagged by the kernels, raised lazily (no per-step host sync) ---------------
+    def _err_flag(self, device) -> torch.Tensor | None:
+        if device.type != "cuda":
+            return None
+        if self._err_dev is None:
+            self._err_dev = torch.zeros(1, dtype=torch.int32, device=device)
+            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._err_dev
+
+    def _err_snapshot(self) -> None:
+        """Queues a copy of the error word into page-locked memory behind the lookups just launched."""
+        if self._err_dev is not None:
+            self._err_host.copy_(self._err_dev, non_blocking=True)
+            self._err_event = torch.cuda.Event()
+            self._err_event.record()
+
+    def check_ids(self, wait: bool = False) -> None:
+        """Raises IndexError if a lookup launched by an earlier call met an id outside [0, vocabulary_size)
+        (such ids contribute nothing; they are never clamped).  Called at the start of every `call` without
+        waiting for the GPU (only snapshots that have already arrived are looked at), with wait=True from
+        get_embedding_tables() and by callers that want the verdict on the last step now."""
+        ev = self._err_event
+        if ev is None:
+            return
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._err_event = None
+        if int(self._err_host.item()) & L.FLAG_ID_OUT_OF_RANGE:
+            self._err_dev.zero_()
+            self._err_host.zero_()
+            raise IndexError("DistributedEmbedding: an embedding id was out of range for its table "
+                             "(ids are never clamped; the lookup contributed nothing)")
+
     def _call_groups(self, placement: str, inputs: dict, weights: dict | None):
         outputs = {}
         for gi, g in enumerate(self._groups[placement]):
@@ -443,15 +481,16 @@ class DistributedEmbedding(base.Layer):
             fi = inputs[key]
             w = None if weights is None else weights[key]
             out_dtype = self.compute_dtype
+            err = self._err_flag(fi["ids"].device)
             if placement == "sparsecore":
                 lead = self.slab_lead_cols if len(self._groups[placement]) == 1 else 0
                 slab, *out = EmbedBagFusedFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w,
-                                                   out_dtype, g, self._anchor, lead)
+                                                   out_dtype, g, self._anchor, lead, err)
                 for i, o in enumerate(out):  # lets layers.concat_features find the slab (zero-copy concat)
                     o._krs_slab = (slab, lead + i * g.dim, len(out), lead)
             else:
                 out = EmbedBagFn.apply(g.bags, fi["ids"], fi["batch"], fi["hots"], fi["offsets"], w, out_dtype,
-                                       False, *g.bags.tables)
+                                       err if err is not None else False, *g.bags.tables)
             for path, o in zip(g.paths, out):
                 outputs[path] = o
         return outputs
@@ -531,6 +570,7 @@ class DistributedEmbedding(base.Layer):
         return isinstance(inputs, dict) and "preprocessed_inputs_per_placement" in inputs
 
     def call(self, inputs, weights=None, training: bool = False):
+        self.check_ids()   # verdict on earlier steps, if it has arrived (no wait)
         pre = inputs if self._is_preprocessed(inputs) else self.preprocess(inputs, weights, training)
         pre = pre["preprocessed_inputs_per_placement"]
         outs = {}
@@ -538,6 +578,7 @@ class DistributedEmbedding(base.Layer):
             outs["sparsecore"] = self._sparsecore_call(**pre["sparsecore"], training=training)
         if "default_device" in pre:
             outs["default_device"] = self._default_device_call(**pre["default_device"], training=training)
+        self._err_snapshot()
         return base.map_structure_up_to(
             self._feature_deeply_nested_placement_and_paths, lambda pp: outs[pp.placement][pp.path],
             self._feature_deeply_nested_placement_and_paths, is_leaf=_is_placement_leaf)
@@ -546,6 +587,7 @@ class DistributedEmbedding(base.Layer):
         """{TableConfig.name: [vocabulary_size, embedding_dim]} (base:810-825)."""
         if not self.built:
             self.build(None)
+        self.check_ids(wait=True)
         tables = {}
         if "sparsecore" in self._placement_to_path_to_feature_config:
             tables.update(self._sparsecore_get_embedding_tables())

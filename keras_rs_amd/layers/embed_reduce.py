@@ -131,11 +131,41 @@ class EmbedReduce(base.Layer):
         else:
             hot = ids.shape[1]
         batch = ids.shape[0]
+        if w is not None and w.dim() > ids.dim():
+            return self._call_per_dimension_weights(ids, w, combiner, out_dtype)
+        if w is not None and w.dim() < ids.dim():
+            # [B] weights with [B, L] ids.  The reference appends axes at the END (embed_reduce.py:244-248):
+            # one weight per ROW, and the divisor sums the expanded [B, 1, 1] weights over an axis of length
+            # one -- mean divides by w_b (not L * w_b), sqrtn by |w_b|, both divide_no_nan.  In per-lookup
+            # weights of a plain sum: sum -> w_b, mean -> [w_b != 0], sqrtn -> sign(w_b).
+            wb = w.float().reshape(-1, 1)
+            wb = wb if combiner == "sum" else ((wb != 0).float() if combiner == "mean" else torch.sign(wb))
+            w, combiner = wb.expand(ids.shape), "sum"
         if w is not None:
-            w = w.float().expand(ids.shape).contiguous().reshape(-1) if w.dim() < ids.dim() else \
-                w.float().contiguous().reshape(-1)
+            w = w.float().contiguous().reshape(-1)
         return EmbedBagFn.apply(self._fused(combiner), ids.contiguous().reshape(-1), batch, (hot,), None, w,
                                 out_dtype, True, self.embeddings)[0]
+
+    def _call_per_dimension_weights(self, ids, w, combiner, out_dtype):
+        """Weights of the rank of the embedded inputs ([B, D] with 1-D ids, [B, L, D] with 2-D ids: one weight
+        per embedding COLUMN, embed_reduce.py:181-190 accepts them).  The bag kernel carries one weight per
+        lookup, so this rare form gathers the rows with it (L = 1 bags) and applies embed_reduce.py:253-274 as
+        device tensor ops on the gathered block."""
+        n = ids.numel()
+        rows = EmbedBagFn.apply(self._fused("sum"), ids.contiguous().reshape(-1), n, (1,), None, None,
+                                torch.float32, True, self.embeddings)[0]
+        x = rows.reshape(tuple(ids.shape) + (self.output_dim,))
+        wf = w.float().expand(x.shape)
+        if ids.dim() == 1:                       # no reduction; weights only survive for "sum"
+            return (x * wf if self.combiner == "sum" else x).to(out_dtype)
+        s = (x * wf).sum(dim=-2)
+        if combiner == "mean":
+            d = wf.sum(dim=-2)
+        elif combiner == "sqrtn":
+            d = wf.square().sum(dim=-2).sqrt()
+        else:
+            return s.to(out_dtype)
+        return torch.where(d != 0, s / torch.where(d != 0, d, torch.ones_like(d)), torch.zeros_like(s)).to(out_dtype)
 
     def _out_dtype(self, w):
         cd = self.compute_dtype

@@ -59,9 +59,16 @@ struct Buf {
   size_t bytes() const { return (size_t)rows * ld * es; }
 };
 Buf alloc(int64_t rows, int64_t cols, int64_t ld, size_t es = 2) {
+  // KRS_STAGGER=bytes: the i-th buffer starts (i % 16) * bytes into its allocation (do equal-sized streams
+  // that start on the same DRAM bank / channel phase slow each other down?)
+  static const size_t stagger = getenv("KRS_STAGGER") ? (size_t)atoll(getenv("KRS_STAGGER")) : 0;
+  static int count = 0;
   Buf b; b.rows = rows; b.cols = cols; b.ld = ld; b.es = es;
-  CK(hipMalloc(&b.p, b.bytes()));
-  CK(hipMemset(b.p, 0, b.bytes()));
+  const size_t off = (size_t)(count++ % 16) * stagger;
+  char* base;
+  CK(hipMalloc(&base, b.bytes() + 16 * stagger));
+  CK(hipMemset(base, 0, b.bytes() + 16 * stagger));
+  b.p = base + off;
   return b;
 }
 void fill(Buf& b, uint32_t seed, float scale) {

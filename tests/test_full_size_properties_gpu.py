@@ -149,8 +149,12 @@ def test_backward_identities_at_full_size():
     dz = (g.float() * x0.detach().float()).to(torch.bfloat16)          # what the elementwise pass hands the GEMMs
     h = (x.detach().float() @ layer.down_kernel.detach().to(torch.bfloat16).float()).to(torch.bfloat16)
     cols = slice(1000, 1256)
-    exp = h.float().t() @ dz[:, cols].float()                          # fp32 reference of dV[:, cols]
-    torch.testing.assert_close(layer.kernel.grad[:, cols], exp, rtol=2e-2, atol=0.5)
+    exp = (h.double().t() @ dz[:, cols].double()).float()             # the same bf16 products, summed in fp64
+    # fp32 accumulation of 65,536 exact products (|sum| ~ 5): split-K partial sums + fixed-order reduce.  `h` above is
+    # torch's rounding of x U; the layer's own h differs from it by one bf16 ulp in a few elements (different
+    # summation order), which moves a sum by up to ~ 5e-3 -- test_c3_gemm_slices_against_fp64 below checks the same
+    # product on the kernel's own operands to 2e-3
+    torch.testing.assert_close(layer.kernel.grad[:, cols], exp, rtol=2e-4, atol=8e-3)
     # the bias gradient sums the unrounded fp32 products (the bf16 dz only feeds the GEMMs)
     torch.testing.assert_close(layer.bias.grad, (g.double() * x0.detach().double()).sum(0).float(), rtol=1e-3, atol=5e-3)
     # DotInteraction backward on the full batch, checked on 512 samples
@@ -166,3 +170,40 @@ def test_backward_identities_at_full_size():
     dX = torch.matmul(G + G.transpose(1, 2), X)
     for f in (0, 13, 26):
         torch.testing.assert_close(feats[f].grad[sl].float(), dX[:, f], rtol=2 ** -6, atol=2e-2)
+
+
+def test_c3_gemm_slices_against_fp64():
+    """The six products of one C3 cross layer (65,536 x 3456, projection 512, bf16 in / fp32 accumulate) on the
+    256x256-tile kernels, checked on row / column slices against float64 sums of the same bf16 operands:
+    bf16 outputs to one rounding of the fp64 value (2^-8 relative) plus the fp32 accumulation error, fp32
+    weight gradients to 2e-4 relative."""
+    from keras_rs_amd import dense_ops as Dn
+
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    d, p = 27 * D, 512
+    rn = lambda *s: (torch.rand(*s, device=DEV, generator=gen) - 0.5).to(torch.bfloat16)  # noqa: E731
+    x0, x, g = rn(B, d), rn(B, d), rn(B, d)
+    U, V = (rn(d, p).float() * 0.1).to(torch.bfloat16), (rn(p, d).float() * 0.1).to(torch.bfloat16)
+    bias = torch.rand(d, device=DEV, generator=gen) - 0.5
+    rows = slice(40_000, 40_000 + 384)          # straddles a tile boundary (40,000 = 156.25 tiles)
+    bf = lambda t: t.to(torch.bfloat16)         # noqa: E731
+    tol16 = dict(rtol=2 ** -8 + 1e-4, atol=1e-3)
+
+    h, _ = Dn.gemm(x, U.t().contiguous(), b_is_nk=True)                                   # h = x U
+    h64 = x[rows].double() @ U.double()
+    torch.testing.assert_close(h[rows].double(), h64, **tol16)
+    y, u = Dn.gemm(h, V.t().contiguous(), b_is_nk=True, bias=bias, x0=x0, x=x, want_u=True)  # cross epilogue
+    u64 = h[rows].double() @ V.double() + bias.double()
+    torch.testing.assert_close(u[rows].double(), u64, **tol16)
+    y64 = x0[rows].double() * u64 + x[rows].double()
+    torch.testing.assert_close(y[rows].double(), y64, **tol16)
+    dz = bf(g.float() * x0.float())
+    dh, _ = Dn.gemm(dz, V, b_is_nk=True)                                                  # dh = dz V^T
+    torch.testing.assert_close(dh[rows].double(), dz[rows].double() @ V.double().t(), **tol16)
+    dx, _ = Dn.gemm(dh, U, b_is_nk=True, r=g, beta=1.0)                                   # dx = dh U^T + g
+    torch.testing.assert_close(dx[rows].double(), dh[rows].double() @ U.double().t() + g[rows].double(), **tol16)
+    cols = slice(2900, 3200)
+    dk, _ = Dn.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)                         # dV = h^T dz
+    torch.testing.assert_close(dk[:, cols].double(), h.double().t() @ dz[:, cols].double(), rtol=2e-4, atol=2e-3)
+    du, _ = Dn.gemm(x, dh, a_is_km=True, out_dtype=torch.float32)                         # dU = x^T dh
+    torch.testing.assert_close(du[cols].double(), x[:, cols].double().t() @ dh.double(), rtol=2e-4, atol=2e-3)

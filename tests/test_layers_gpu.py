@@ -241,6 +241,73 @@ def test_embed_reduce_out_of_range_raises_and_dense_gradient():
     np.testing.assert_allclose(layer.embeddings.grad.cpu().numpy(), e.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("combiner", ["sum", "mean", "sqrtn"])
+def test_embed_reduce_weights_of_lower_and_higher_rank(combiner):
+    # embed_reduce.py:181-190 accepts weights of any rank up to that of the embedded inputs and appends the
+    # missing axes at the END (:244-248): [B] weights with [B, L] ids are one weight per row.  Expected values:
+    # a float64 restatement of :253-274 on the expanded weights.
+    kl = _layers()
+    rng = np.random.default_rng(5)
+    B, L, V, D = 6, 4, 11, 8
+    layer = kl.EmbedReduce(V, D, combiner=combiner)
+    ids = rng.integers(0, V, (B, L)).astype(np.int32)
+    layer(torch.tensor(ids, device=DEV))
+    e = layer.embeddings.detach().cpu().numpy().astype(np.float64)
+
+    def ref(idv, w):
+        x = e[idv]
+        w = w.reshape(w.shape + (1,) * (x.ndim - w.ndim)).astype(np.float64)   # NOT broadcast: the divisor sums it as is
+        if x.ndim <= 2:
+            return x * w if combiner == "sum" else x
+        s = (x * w).sum(-2)
+        if combiner == "sum":
+            return s
+        d = w.sum(-2) if combiner == "mean" else np.sqrt((w * w).sum(-2))
+        return np.where(d != 0, s / np.where(d != 0, d, 1), 0)
+
+    w_row = rng.uniform(-1, 1, B).astype(np.float32)
+    w_row[2] = 0.0                                                    # divide_no_nan
+    got = layer(torch.tensor(ids, device=DEV), torch.tensor(w_row, device=DEV))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref(ids, w_row), rtol=1e-5, atol=1e-6)
+    w_full = rng.uniform(0.1, 1, (B, L, D)).astype(np.float32)         # one weight per embedding column
+    got = layer(torch.tensor(ids, device=DEV), torch.tensor(w_full, device=DEV))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref(ids, w_full), rtol=1e-5, atol=1e-6)
+    ids1 = ids[:, 0].copy()
+    w_bd = rng.uniform(0.1, 1, (B, D)).astype(np.float32)
+    got = layer(torch.tensor(ids1, device=DEV), torch.tensor(w_bd, device=DEV))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref(ids1, w_bd), rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):                                    # [L]-shaped weights do not match axis 0
+        layer(torch.tensor(ids, device=DEV), torch.tensor(np.ones(L + 1, np.float32), device=DEV))
+
+
+@pytest.mark.parametrize("placement", ["default_device", "sparsecore"])
+def test_distributed_embedding_reports_out_of_range_ids_lazily(placement):
+    # out-of-range ids are never clamped; the lookup contributes nothing and the layer
+    # raises -- without a host sync in the step: at a later call once the flag has arrived, or on request
+    kl = _layers()
+    t = kl.TableConfig("t", 20, 8, placement=placement, optimizer="sgd", combiner="sum")
+    layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t, (4, 2), (4, 8))})
+    good = np.array([[1, 2], [3, 4], [5, 6], [7, 8]], np.int32)
+    bad = good.copy()
+    bad[2, 1] = 20
+    out = layer({"a": good})["a"]
+    layer.check_ids(wait=True)                                         # nothing to report
+    tab = layer.get_embedding_tables()["t"].clone()
+    out_bad = layer({"a": bad})["a"]
+    # the bad lookup contributed nothing (not row 0, not the last row)
+    torch.testing.assert_close(out_bad[2].float(), tab[5].float())
+    torch.testing.assert_close(out_bad[0].float(), out[0].float())
+    with pytest.raises(IndexError):
+        layer.check_ids(wait=True)
+    layer.check_ids(wait=True)                                         # the flag was consumed
+    layer({"a": bad})
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):                                    # ... or it surfaces at the next call
+        layer({"a": good})
+    layer({"a": good})
+    layer.check_ids(wait=True)
+
+
 def _de_configs(placement, optimizer="sgd", combiner="mean"):
     kl = _layers()
     de = KAT["distributed_embedding"]
