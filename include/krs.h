@@ -332,6 +332,70 @@ int krs_mod_bucketize(const void* ids, int id_type, int64_t nnz, int n_shards,
                       void* local_ids, int32_t* perm, int64_t* bucket_counts,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * K6  Row-sharded lookup: route / unpack / combine (the id side of the exchange)
+ *
+ * The reference's accelerated path hands per-partition id lists to the SparseCore library
+ * (embedding.preprocess_sparse_dense_matmul_input, sharding_strategy="MOD":
+ * jax/embedding_utils.py:144-217) and looks them up with tpu_sparse_dense_matmul
+ * (jax/embedding_lookup.py:134-147).  Here the ranks exchange one PARTIALLY POOLED vector per
+ * (bag, owner) pair (keras_rs_amd/sharded.py); these three calls are everything around the two
+ * all-to-alls, each a fixed sequence of kernels on `stream` (no allocation, no host sync).
+ *
+ * krs_shard_route (home rank).  Lookups are given as for krs_embed_bag_fwd: ONE flat id buffer,
+ * feature-major, dense bags (feats[f].hot ids per bag, feats[f].ids_base = first id of the feature)
+ * or CSR (offsets[n_feats*batch + 1]).  Per lookup: id outside [0, feats[f].vocab) -> dropped,
+ * KRS_FLAG_ID_OUT_OF_RANGE raised (never clamped); composite c = comp_off + id, owner = c % n_shards,
+ * stacked local row = c / n_shards; stable grouping by owner; a SEGMENT = a run of one bag inside an
+ * owner's bucket.  Outputs:
+ *   packed   [<= nnz*(1 + emit_weights) + nnz] int32: per owner d, contiguously,
+ *            [rows(lookups_d) | weights as fp32 bit patterns (lookups_d, only with emit_weights) |
+ *             segment lengths (segments_d)]; weight = user weight x combiner scale of the bag
+ *            (mean 1/sum w, sqrtn 1/sqrt(sum w^2), 0 where the divisor is 0: embed_reduce.py:255-274)
+ *   seg_bag  [nnz] bag of every segment (first n_seg valid; segments are numbered in bucket order)
+ *   seg_grow [nnz] row of the [batch*n_feats, dim] view of the output gradient the segment's partial
+ *            takes in the backward: (bag % batch)*n_feats + bag / batch
+ *   bag_seg  [n_feats*batch, n_shards] segment of (bag, owner), -1 where the bag has no lookup there
+ *   counts   [3*n_shards] int64: lookups, segments, packed words per owner
+ * emit_weights must be set when weights != NULL or any combiner is not KRS_SUM.
+ * feats is the DEVICE copy of the descriptors, feats_host the same array on the host.
+ *
+ * krs_shard_unpack (owner rank): the packed blocks received from n_sources ranks (their `lookups` /
+ * `segments` counts are HOST arrays), concatenated in source order -> rows[sum lookups],
+ * w[sum lookups] (weighted != 0), offsets[sum segments + 1] (exclusive scan of the lengths): the CSR
+ * form krs_embed_bag_fwd and the fused backward take.
+ *
+ * krs_shard_combine (home rank): out[b, f*dim + j] = sum over owners d of
+ * partials[bag_seg[(f*batch + b)*n_shards + d]][j] (skipping -1), fp32 accumulation in ascending d,
+ * one rounding to `dtype` (the dtype of partials and out).
+ *
+ * krs_publish_i64: copies src[0..n) to page-locked host memory (host_dst, device-visible) and then
+ * writes `seq` to host_dst[n]; the host polls host_dst[n] instead of synchronising the stream.
+ * ------------------------------------------------------------------------- */
+typedef struct krs_shard_feature {
+  int64_t ids_base;   /* dense bags: position of the feature's first id in `ids` */
+  int64_t comp_off;   /* stacked local row offset of the feature's table, times n_shards */
+  int32_t hot;        /* dense bags: ids per bag; ignored with CSR offsets */
+  int32_t combiner;   /* krs_combiner */
+  int32_t vocab;      /* valid ids are [0, vocab) */
+  int32_t reserved;
+} krs_shard_feature;
+
+size_t krs_shard_route_workspace_bytes(int64_t nnz, int64_t n_bags, int n_shards);
+int krs_shard_route(const krs_shard_feature* feats, const krs_shard_feature* feats_host, int n_feats,
+                    const void* ids, int id_type, const void* offsets, int offset_type,
+                    const float* weights, int64_t nnz, int batch, int n_shards, int emit_weights,
+                    int32_t* packed, int32_t* seg_bag, int32_t* seg_grow, int32_t* bag_seg,
+                    int64_t* counts, int32_t* err_flag,
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t krs_shard_unpack_workspace_bytes(int64_t total_segments);
+int krs_shard_unpack(const int32_t* packed, int n_sources, const int64_t* lookups, const int64_t* segments,
+                     int weighted, int32_t* rows, float* w, int32_t* offsets,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int krs_shard_combine(const void* partials, const int32_t* bag_seg, int batch, int n_feats, int n_shards,
+                      int dim, int dtype, void* out, int64_t out_ld, void* stream);
+int krs_publish_i64(const int64_t* src, int n, int64_t* host_dst, int64_t seq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

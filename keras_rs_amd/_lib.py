@@ -31,6 +31,10 @@ TABLE_DT = np.dtype(
 FEATURE_DT = np.dtype(
     [("ids_base", "<i8"), ("table", "<i4"), ("hot", "<i4"), ("combiner", "<i4"), ("out_col", "<i4")]
 )
+SHARD_FEATURE_DT = np.dtype(
+    [("ids_base", "<i8"), ("comp_off", "<i8"), ("hot", "<i4"), ("combiner", "<i4"), ("vocab", "<i4"),
+     ("reserved", "<i4")]
+)
 
 
 class GemmEpilogue(C.Structure):
@@ -72,6 +76,12 @@ SYMBOLS = [
     "krs_dot_interaction_bwd",
     "krs_mod_bucketize_workspace_bytes",
     "krs_mod_bucketize",
+    "krs_shard_route_workspace_bytes",
+    "krs_shard_route",
+    "krs_shard_unpack_workspace_bytes",
+    "krs_shard_unpack",
+    "krs_shard_combine",
+    "krs_publish_i64",
 ]
 
 _lib = None
@@ -93,7 +103,8 @@ def lib() -> C.CDLL:
         _lib = C.CDLL(LIB_PATH)
         _lib.krs_last_error.restype = C.c_char_p
         for name in ("krs_embed_bag_bwd_workspace_bytes", "krs_gemm_workspace_bytes",
-                     "krs_mod_bucketize_workspace_bytes"):
+                     "krs_mod_bucketize_workspace_bytes", "krs_shard_route_workspace_bytes",
+                     "krs_shard_unpack_workspace_bytes"):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
 

@@ -252,6 +252,7 @@ class DistributedEmbedding(base.Layer):
         self._groups: dict[str, list[_Group]] = {}
         self._table_params: dict[int, torch.nn.Parameter] = {}
         self._table_slots: dict[int, torch.Tensor | None] = {}
+        self._slot_buffer_names: dict[int, str] = {}
         if "sparsecore" in self._placement_to_path_to_feature_config:
             self._sparsecore_init(self._placement_to_path_to_feature_config["sparsecore"], table_stacking)
         if "default_device" in self._placement_to_path_to_feature_config:
@@ -342,7 +343,15 @@ class DistributedEmbedding(base.Layer):
                     topts.append(fo)
                     kinds.add(dataclasses.replace(fo, lr=0.0))   # everything but the learning rate is per group
                     if self._table_slots[key] is None:
-                        self._table_slots[key] = fo.new_slot(p.shape, p.device)
+                        slot = fo.new_slot(p.shape, p.device)
+                        if slot is not None:
+                            # optimizer slot variables are part of the layer's state, as in the reference
+                            # (add_weight'ed slot variables, jax/distributed_embedding.py:316-345): a persistent
+                            # buffer travels with state_dict() / load_state_dict() / .to()
+                            bname = f"{placement}_{tc.name}_slot".replace(".", "_")
+                            self.register_buffer(bname, slot, persistent=True)
+                            self._slot_buffer_names[key] = bname
+                        self._table_slots[key] = slot
                 slots.append(self._table_slots[key])
                 lrs.append(lr)
             if len(kinds) > 1:
@@ -438,6 +447,33 @@ class DistributedEmbedding(base.Layer):
     def _default_device_preprocess(self, inputs, weights, training=False):
         del training
         return self._fuse_inputs("default_device", inputs, weights)
+
+    # ---- module state: optimizer slots are buffers, update counts travel as extra state ---------------
+    def _apply(self, fn, recurse=True):
+        """.to() / .cuda() / .float(): torch replaces buffer tensors; re-point the kernel descriptors at them."""
+        out = super()._apply(fn, recurse)
+        for key, bname in getattr(self, "_slot_buffer_names", {}).items():
+            self._table_slots[key] = self._buffers[bname]
+        for groups in getattr(self, "_groups", {}).values():
+            for g in groups:
+                if g.bags is not None:
+                    g.bags.slots = [self._table_slots[id(tc)] for tc in g.table_configs]
+                    g.bags._tab_key = None
+        self._err_dev = self._err_host = self._err_event = None
+        return out
+
+    def get_extra_state(self):
+        """Fused-update counts per group (Adam bias correction, learning-rate schedules): the reference keeps
+        `_iterations` as a layer variable (jax/distributed_embedding.py:340-345)."""
+        return {"iterations": {f"{pl}/{gi}": int(g.step) for pl, groups in self._groups.items()
+                               for gi, g in enumerate(groups)}}
+
+    def set_extra_state(self, state) -> None:
+        its = (state or {}).get("iterations", {})
+        for pl, groups in self._groups.items():
+            for gi, g in enumerate(groups):
+                if f"{pl}/{gi}" in its:
+                    g.step = int(its[f"{pl}/{gi}"])
 
     # ---- out-of-range ids: flagged by the kernels, raised lazily (no per-step host sync) ---------------
     def _err_flag(self, device) -> torch.Tensor | None:

@@ -1,72 +1,90 @@
-"""Row-sharded embedding tables across the GPUs of one node (config C4 / SURVEY.md section 8e).
+"""Row-sharded embedding tables across the GPUs of one node (config C4 / C5).
 
 Layout (the reference's own convention, sharding_strategy="MOD" at
 keras_rs/src/layers/embedding/jax/embedding_utils.py:194, reassembly code at
-tensorflow/distributed_embedding.py:316-328): global row r of every table lives on rank
-r % N at local row r // N.  Each rank keeps ONE stacked buffer [sum_t ceil(V_t / N), D]; table t
-starts at row off_t = sum_{s<t} ceil(V_s / N), so a lookup anywhere in the group is `off_t + r // N`.
+tensorflow/distributed_embedding.py:316-328): global row r of every sharded table lives on rank
+r % N at local row r // N.  Tables of one embedding width and one fused optimizer form a GROUP; each
+rank keeps ONE stacked buffer [sum_t ceil(V_t / N), D] per group, table t starting at row
+off_t = sum_{s<t} ceil(V_s / N), so the composite id c = off_t * N + r gives the owner (c % N) and the
+stacked local row (c // N) of a lookup in one integer.
 
-Per step (one process per GPU, torch.distributed over RCCL/xGMI; xGMI is point-to-point, so the
-exchange is an all-to-all whose pairs each use their own link).  What crosses the links is one
-PARTIALLY POOLED vector per (bag, owner) pair that has lookups -- not one vector per lookup: with
-the ml_perf bag lengths (214 lookups per sample) that is 41 vectors per sample at N = 2 and 79 at
-N = 8.
-  fwd  1. composite id c = off_t*N + r  (c % N = owner, c // N = stacked local row)
-       2. K5 MOD-bucketise c (stable: inside a bucket the lookups stay in bag order); runs of equal
-          bag inside a bucket are the SEGMENTS; combiner scale (mean / sqrtn) and user weights are
-          folded into one weight per lookup; all-to-all of (lookup, segment) counts, all-to-all-v of
-          local rows, segment lengths and weights
-       3. owner: K1 in CSR form over the received segments -> one partial vector per segment
-       4. all-to-all-v of the partial vectors back to the sample's home rank
-       5. home: K1 again, with the partials as the "table": every bag sums its <= N partials
-  bwd  mirror image: d(partial) of a segment is its bag's output gradient (a row gather),
-       all-to-all-v to the owners, K2 fused SGD / Adagrad on the shard in CSR form.  Every row has
-       exactly one owner, so table gradients need no cross-GPU reduction.
+Small tables are not worth an exchange: with `replicate_below=V0` every table with fewer than V0 rows is
+REPLICATED -- each rank holds it whole as an ordinary trainable weight, looks it up locally (one fused
+launch, dense [V, D] gradients from K2) and its gradient joins the data-parallel all-reduce of the dense
+weights (keras_rs_amd/dp.py), exactly what the reference's model does with the tables under
+`embedding_threshold` (examples/ml_perf/main.py:135-141, model.py:128-148: plain keras Embeddings trained by
+the model optimizer).  Without it a 3-row Criteo table would send all of its 65,536 x L lookups to <= 3 ranks.
 
-The exchange logic is independent of the compute kernels: `kernels` is an object with the four
-methods of HipShardKernels.  The product default runs the HIP kernels; the CPU/gloo tests in
-tests/test_sharded_gloo.py inject an oracle-backed implementation to check the permutation and
-collective plumbing with world_size 2.
+Per step and group (one process per GPU, torch.distributed over RCCL/xGMI; xGMI is point-to-point, so the
+exchange is an all-to-all whose pairs each use their own link).  What crosses the links is one PARTIALLY
+POOLED vector per (bag, owner) pair that has lookups -- not one vector per lookup: with the ml_perf bag
+lengths (214 lookups per sample) that is 41 vectors per sample at N = 2 and 79 at N = 8.
+  fwd  1. krs_shard_route (ONE call, csrc/shard_route.hip): range check, composite id -> owner / local row,
+          stable grouping by owner, SEGMENTS (runs of one bag inside an owner's bucket), per-lookup weight =
+          user weight x combiner scale, the packed send buffer [per owner: rows | weights | segment lengths],
+          per-owner counts
+       2. the counts travel in one tiny all-to-all; both sides' counts reach the host through page-locked
+          memory behind a sequence flag (krs_publish_i64): the ONE host wait of the lookup
+       3. ONE all-to-all-v of the packed buffer; owner: krs_shard_unpack -> rows, weights, CSR segment
+          offsets; K1 in CSR form -> one partial vector per segment
+       4. ONE all-to-all-v of the partials back; home: krs_shard_combine sums the <= N partials of every bag
+          straight into the output slab
+  bwd  d(partial of a segment) = the output gradient of its bag (a row gather by the segment's gradient row),
+       ONE all-to-all-v to the owners, K2 fused optimizer on the shard in CSR form.  Every row has exactly
+       one owner, so table gradients need no cross-GPU reduction.
+Gradient convention: the backward applies to every row the SUM over all ranks of d(loss_rank)/d(row).  With a
+loss that is a mean over the LOCAL batch and dense weights averaged over ranks (dp.GradAllReduce), pass
+`grad_average=True`: the contributions are scaled by 1 / world, so tables and dense weights both see the
+gradient of the global-batch mean (the reference's SparseCore update is a global-batch update).
+
+Partials travel in `partial_dtype` (default: the compute dtype; bf16 at C3, one extra rounding of each
+partial compared with the single-GPU path -- the sums differ by <= 1 bf16 ulp per partial; "float32" keeps
+the single-GPU summation exact at twice the bytes).
+
+The exchange logic is independent of the compute kernels: `kernels` is an object with the methods of
+HipShardKernels.  The product default runs the HIP kernels; the CPU/gloo tests in
+tests/test_sharded_gloo.py inject an oracle-backed implementation to check the plumbing with world_size 2 / 3.
 """
 
 from __future__ import annotations
 
+import ctypes as C
+import dataclasses
 import math
-from typing import Any, Sequence
+import time
+from typing import Any
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
+from keras_rs_amd import _lib as L
 from keras_rs_amd.layers import base
-from keras_rs_amd.layers.distributed_embedding import resolve_fused_optimizer
-from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig
+from keras_rs_amd.layers.distributed_embedding import (DistributedEmbedding, FusedOptimizer,
+                                                       resolve_fused_optimizer)
+from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig, TableConfig
 
 
 class HipShardKernels:
-    """The compute side of the sharded path on MI355X (K1 / K2 / K5 through the C ABI)."""
+    """The compute side of the sharded path on MI355X (K1 / K2 / K6 through the C ABI)."""
 
     def __init__(self):
         self._shard_bags: dict = {}
+        self._desc_cache: dict = {}
 
     def _bags_for(self, table, slot, lr):
         """One FusedBags (device descriptors) per shard storage, re-used across steps."""
         from keras_rs_amd.embedding_ops import FusedBags
 
-        key = (table.data_ptr(), 0 if slot is None else slot.data_ptr(), float(lr))
+        key = (table.data_ptr(), 0 if slot is None else slot.data_ptr())
         fb = self._shard_bags.get(key)
         if fb is None:
             fb = self._shard_bags[key] = FusedBags([table], [(0, "sum", 0)], slots=[slot], lrs=[lr])
         return fb
 
-    def bucketize(self, ids: torch.Tensor, n_shards: int):
-        from keras_rs_amd import dense_ops as D
-
-        return D.mod_bucketize(ids, n_shards)
-
     def _transient_bags(self, table, feats):
-        """FusedBags for a per-step `table` (returned vectors, an output gradient): one object per feature
-        list is kept and re-pointed, so that only the 32-byte table descriptor is uploaded per call."""
+        """FusedBags for a per-step `table` (an output gradient): one object per feature list is kept and
+        re-pointed, so that only the 32-byte table descriptor is uploaded per call."""
         from keras_rs_amd.embedding_ops import FusedBags
 
         key = ("transient", tuple(feats), table.shape[1], table.dtype)
@@ -78,6 +96,60 @@ class HipShardKernels:
         fb.total_rows = int(table.shape[0])
         return fb
 
+    # ---- K6 -------------------------------------------------------------------------------------
+    def route(self, desc: np.ndarray, ids, offsets, weights, batch: int, n_shards: int, emit_w: bool, err_flag=None):
+        """krs_shard_route.  desc: SHARD_FEATURE_DT array.  Returns dict(packed, seg_grow, bag_seg, counts):
+        device tensors, counts = int64 [3, n_shards] (lookups, segments, packed words per owner)."""
+        dev = ids.device
+        key = (desc.tobytes(), str(dev))
+        ddev = self._desc_cache.get(key)
+        if ddev is None:
+            ddev = self._desc_cache[key] = L.struct_to_device(desc, dev)
+        nnz, n_feats = ids.numel(), len(desc)
+        n_bags = batch * n_feats
+        packed = torch.empty(max(nnz * (2 + int(emit_w)), 1), dtype=torch.int32, device=dev)
+        seg_bag = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        seg_grow = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        bag_seg = torch.empty((max(n_bags, 1), n_shards), dtype=torch.int32, device=dev)
+        counts = torch.empty((3, n_shards), dtype=torch.int64, device=dev)
+        wsb = int(L.lib().krs_shard_route_workspace_bytes(C.c_int64(nnz), C.c_int64(n_bags), C.c_int(n_shards)))
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        if weights is not None and weights.dtype != torch.float32:
+            weights = weights.float()
+        rc = L.lib().krs_shard_route(
+            L.ptr(ddev), desc.ctypes.data_as(C.c_void_p), C.c_int(n_feats), L.ptr(ids), C.c_int(L.itype(ids)),
+            L.ptr(offsets), C.c_int(L.itype(offsets) if offsets is not None else L.I32), L.ptr(weights),
+            C.c_int64(nnz), C.c_int(batch), C.c_int(n_shards), C.c_int(int(emit_w)), L.ptr(packed), L.ptr(seg_bag),
+            L.ptr(seg_grow), L.ptr(bag_seg), L.ptr(counts), L.ptr(err_flag), L.ptr(ws), C.c_size_t(ws.numel()),
+            L.stream_ptr())
+        L.check(rc, "krs_shard_route")
+        return dict(packed=packed, seg_grow=seg_grow, bag_seg=bag_seg, counts=counts)
+
+    def unpack(self, packed, lookups, segments, weighted: bool):
+        """krs_shard_unpack: (rows int32 [sum lookups], w fp32 | None, offsets int32 [sum segments + 1])."""
+        dev = packed.device
+        n = len(lookups)
+        n_cnt, n_seg = int(sum(lookups)), int(sum(segments))
+        rows = torch.empty(max(n_cnt, 1), dtype=torch.int32, device=dev)
+        w = torch.empty(max(n_cnt, 1), dtype=torch.float32, device=dev) if weighted else None
+        off = torch.empty(n_seg + 1, dtype=torch.int32, device=dev)
+        wsb = int(L.lib().krs_shard_unpack_workspace_bytes(C.c_int64(n_seg)))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        arr = lambda v: (C.c_int64 * n)(*[int(x) for x in v])  # noqa: E731
+        rc = L.lib().krs_shard_unpack(L.ptr(packed), C.c_int(n), arr(lookups), arr(segments), C.c_int(int(weighted)),
+                                      L.ptr(rows), L.ptr(w), L.ptr(off), L.ptr(ws), C.c_size_t(wsb), L.stream_ptr())
+        L.check(rc, "krs_shard_unpack")
+        return rows[:n_cnt], (None if w is None else w[:n_cnt]), off
+
+    def combine(self, partials, bag_seg, batch: int, n_feats: int, dim: int, out):
+        """krs_shard_combine into `out` (a [batch, n_feats*dim] row-major window of the slab)."""
+        rc = L.lib().krs_shard_combine(L.ptr(partials), L.ptr(bag_seg), C.c_int(batch), C.c_int(n_feats),
+                                       C.c_int(bag_seg.shape[1]), C.c_int(dim), C.c_int(L.fdtype(out)), L.ptr(out),
+                                       C.c_int64(out.stride(0)), L.stream_ptr())
+        L.check(rc, "krs_shard_combine")
+        return out
+
+    # ---- K1 / K2 on the shard ---------------------------------------------------------------------
     def gather_rows(self, table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
         """table[rows] (K1 one-hot form).  `table` is a per-step tensor here (an output gradient)."""
         n = rows.numel()
@@ -97,230 +169,357 @@ class HipShardKernels:
                                                           out_dtype=out_dtype)
         return out
 
-    def pool(self, vectors, ids, feats, batch, offsets, out_dtype, out=None):
-        """Home side: bags (feature-major CSR over `ids`) summed out of `vectors` into [batch, n_feats*dim]
-        (`out`: a row-major buffer of that shape, possibly a column window of a wider one)."""
-        fb = self._transient_bags(vectors, feats)
-        out, _ = fb.forward(ids, batch, offsets=offsets, out=out, out_dtype=out_dtype)
-        fb.tables = []
-        return out
-
-    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None):
-        """Owner side: fused optimizer step; lookup i of segment s carries weights[i] * seg_grads[s]."""
+    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None, grad_scale=1.0):
+        """Owner side: fused optimizer step; lookup i of segment s carries weights[i] * grad_scale * seg_grads[s]."""
         n_seg = offsets.numel() - 1
         if rows.numel() == 0 or n_seg == 0:
             return
         fb = self._bags_for(table, slot, 0.0)
+        fb.slots = [slot]
         fb.lrs = [float(lr)]   # scheduled rates change per step: the descriptor is re-uploaded when it does
         ws = fb.plan_backward(rows, n_seg, offsets=offsets)
-        fb.backward_fused(kind, ws, seg_grads, n_seg, rows.numel(), weights=weights, hyper=hyper)
+        scale = None
+        if grad_scale != 1.0:
+            scale = torch.full((n_seg,), float(grad_scale), dtype=torch.float32, device=rows.device)
+        fb.backward_fused(kind, ws, seg_grads, n_seg, rows.numel(), weights=weights, bag_scale=scale, hyper=hyper)
+
+
+class _HostCounts:
+    """Device counters -> host through page-locked memory and a sequence flag (krs_publish_i64): the host
+    polls the flag instead of synchronising the stream."""
+
+    def __init__(self):
+        self.buf = torch.zeros(256, dtype=torch.int64).pin_memory()
+        self.seq = 0
+
+    def read(self, dev_counts: torch.Tensor) -> list:
+        n = dev_counts.numel()
+        self.seq += 1
+        rc = L.lib().krs_publish_i64(L.ptr(dev_counts), C.c_int(n), C.c_void_p(self.buf.data_ptr()),
+                                     C.c_int64(self.seq), L.stream_ptr())
+        L.check(rc, "krs_publish_i64")
+        flag = self.buf[n:n + 1]
+        t0 = time.monotonic()
+        while int(flag.item()) != self.seq:
+            if time.monotonic() - t0 > 120.0:
+                raise L.KrsError("sharded lookup: the size exchange did not arrive within 120 s")
+        return self.buf[:n].tolist()
+
+
+@dataclasses.dataclass
+class _ShardGroup:
+    """Sharded tables of one embedding width and one fused optimizer: one stacked shard, one exchange."""
+
+    dim: int
+    fused: FusedOptimizer
+    paths: list
+    table_of_feature: list
+    table_configs: list
+    local_rows: list = dataclasses.field(default_factory=list)
+    row_off: list = dataclasses.field(default_factory=list)
+    step: int = 0
+    pname: str = ""
+    sname: str = ""
 
 
 class _ShardedLookupFn(torch.autograd.Function):
     """Outputs: the slab [B, lead + n*dim] (see DistributedEmbedding.slab_lead_cols) and its n feature views."""
 
     @staticmethod
-    def forward(ctx, layer, ids, batch, hots, offsets, weights, anchor):
+    def forward(ctx, layer, gi, ids, batch, hots, offsets, weights, lead, anchor):
         from keras_rs_amd.autograd import _split_columns
 
         ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero tensors
-        slab, saved = layer._forward_impl(ids, batch, hots, offsets, weights)
-        ctx.layer, ctx.saved = layer, saved
-        return (slab,) + _split_columns(slab, len(layer._paths), layer.dim, layer.slab_lead_cols)
+        slab, saved = layer._forward_impl(gi, ids, batch, hots, offsets, weights, lead)
+        ctx.layer, ctx.gi, ctx.saved, ctx.lead = layer, gi, saved, lead
+        g = layer._sgroups[gi]
+        return (slab,) + _split_columns(slab, len(g.paths), g.dim, lead)
 
     @staticmethod
     def backward(ctx, g_slab, *gs):
-        layer = ctx.layer
+        layer, g = ctx.layer, ctx.layer._sgroups[ctx.gi]
         from keras_rs_amd.autograd import _sum_slab_and_feature_grads
 
         out_dtype, device = ctx.saved["out_meta"]
-        g = _sum_slab_and_feature_grads(g_slab, gs, layer.slab_lead_cols, ctx.saved["batch"], len(layer._paths),
-                                        layer.dim, out_dtype, device)
-        layer._backward_impl(g, ctx.saved)
-        return (None, None, None, None, None, None, torch.zeros((), device=device))
+        grad = _sum_slab_and_feature_grads(g_slab, gs, ctx.lead, ctx.saved["batch"], len(g.paths), g.dim, out_dtype,
+                                           device)
+        layer._backward_impl(ctx.gi, grad, ctx.saved)
+        return (None, None, None, None, None, None, None, None, torch.zeros((), device=device))
 
 
 class ShardedDistributedEmbedding(base.Layer):
     """DistributedEmbedding whose tables are MOD row-sharded over the ranks of `process_group`.
 
-    feature_configs: flat dict {name: FeatureConfig}; all tables share embedding_dim; the
-    per-table optimizer (SGD / Adagrad) is fused into the backward as on the single-GPU
-    'sparsecore' placement.  call(inputs) takes raw {name: ids} or the result of preprocess()."""
+    feature_configs: flat dict {name: FeatureConfig}.  Sharded tables run their TableConfig.optimizer (SGD /
+    Adagrad / Adam / Ftrl, see resolve_fused_optimizer) inside the backward, as on the single-GPU 'sparsecore'
+    placement; tables with fewer than `replicate_below` rows (and every table whose placement is
+    'default_device') are replicated trainable weights with dense gradients.  call(inputs) takes raw
+    {name: ids} (dense [batch, hot] / [batch] arrays, embed_reduce.Ragged or numpy object arrays of rows) or
+    the result of preprocess()."""
 
     def __init__(self, feature_configs: dict[str, FeatureConfig], *, process_group=None, kernels=None,
-                 slab_lead_cols: int = 0, **kwargs: Any):
+                 slab_lead_cols: int = 0, replicate_below: int = 0, grad_average: bool = False,
+                 partial_dtype=None, **kwargs: Any):
         super().__init__(**kwargs)
         self.slab_lead_cols = int(slab_lead_cols)  # as DistributedEmbedding: room for layers.concat_features
         self._pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.kernels = kernels or HipShardKernels()
+        self.replicate_below = int(replicate_below)
+        self.grad_average = bool(grad_average)
+        self._partial_dtype = partial_dtype
         self._feature_configs = feature_configs
         self._paths = list(feature_configs.keys())
-        tcs: list = []
-        self._table_of_feature = []
-        for p in self._paths:
-            tc = feature_configs[p].table
-            idx = next((i for i, t in enumerate(tcs) if t is tc), None)
-            if idx is None:
-                idx = len(tcs)
-                tcs.append(tc)
-            self._table_of_feature.append(idx)
-        self._table_configs = tcs
-        dims = {tc.embedding_dim for tc in tcs}
-        if len(dims) != 1:
-            raise NotImplementedError("ShardedDistributedEmbedding: tables must share embedding_dim")
-        self.dim = dims.pop()
-        kinds = {resolve_fused_optimizer(tc.optimizer) for tc in tcs}
-        if None in kinds or len(kinds) != 1:
-            raise NotImplementedError("ShardedDistributedEmbedding: one fusable optimizer setting (SGD / Adagrad / "
-                                      "Adam / Ftrl, see resolve_fused_optimizer) for all tables")
-        self._fused = next(iter(kinds))
-        self._opt_kind = self._fused.kind
-        self._step = 0
-        # local rows of table t sit at [row_off[t], row_off[t] + ceil(V_t / N)) of this rank's stacked buffer
-        self._local_rows = [math.ceil(tc.vocabulary_size / self.world) for tc in tcs]
-        self._row_off = [0]
-        for n_loc in self._local_rows:
-            self._row_off.append(self._row_off[-1] + n_loc)
-        self._combiners = [feature_configs[p].table.combiner for p in self._paths]
-        self.register_parameter("shard", None)
-        self._slot = None
+        self._sgroups: list[_ShardGroup] = []
+        self._where: dict[str, tuple] = {}       # path -> ("shard", group, index) | ("rep",)
+        rep_cfgs: dict[str, FeatureConfig] = {}
+        rep_tables: dict[int, TableConfig] = {}
+        for p, fc in feature_configs.items():
+            tc = fc.table
+            if tc.placement == "default_device" or tc.vocabulary_size < self.replicate_below:
+                # a replicated twin of the table: same name / shape / initializer, ordinary trainable weight
+                if id(tc) not in rep_tables:
+                    rep_tables[id(tc)] = dataclasses.replace(tc, placement="default_device")
+                rep_cfgs[p] = dataclasses.replace(fc, table=rep_tables[id(tc)])
+                self._where[p] = ("rep",)
+                continue
+            fo = resolve_fused_optimizer(tc.optimizer)
+            if fo is None:
+                raise NotImplementedError(
+                    f"Table '{tc.name}': a sharded table runs its optimizer inside the backward (SGD / Adagrad / "
+                    f"Adam / Ftrl, the option set of the reference's SparseCore path); got {tc.optimizer!r}. "
+                    "Smaller tables can be replicated instead (replicate_below / placement='default_device').")
+            # one group = one stacked shard = one exchange: same width, same optimizer INCLUDING its learning rate
+            # (or schedule object); C3 / C5 have one group
+            g = next((g for g in self._sgroups if g.dim == tc.embedding_dim and g.fused == fo), None)
+            if g is None:
+                g = _ShardGroup(tc.embedding_dim, fo, [], [], [])
+                self._sgroups.append(g)
+            ti = next((i for i, t in enumerate(g.table_configs) if t is tc), None)
+            if ti is None:
+                ti = len(g.table_configs)
+                g.table_configs.append(tc)
+            self._where[p] = ("shard", self._sgroups.index(g), len(g.paths))
+            g.paths.append(p)
+            g.table_of_feature.append(ti)
+        for gi, g in enumerate(self._sgroups):
+            g.local_rows = [math.ceil(tc.vocabulary_size / self.world) for tc in g.table_configs]
+            g.row_off = [0]
+            for n_loc in g.local_rows:
+                g.row_off.append(g.row_off[-1] + n_loc)
+            if g.row_off[-1] >= 2 ** 31:
+                raise NotImplementedError("a rank's stacked shard must stay below 2^31 rows")
+            g.pname, g.sname = f"shard{gi}", f"shard{gi}_slot"
+            self.register_parameter(g.pname, None)
+        self._replicated = None
+        if rep_cfgs:
+            self._replicated = DistributedEmbedding(rep_cfgs, dtype=self.dtype_policy, device=self._device,
+                                                    name=f"{self.name}_replicated")
         self._anchor = None
-        self._offset_cache: dict = {}
+        self._host_counts = None
+        self._err_dev = self._err_host = self._err_event = None
+        self.last_exchange: dict = {}    # host-side counts of the last lookup (tests / load-balance diagnostics)
+
+    # single-group conveniences (the common case: one width, one optimizer) -- kept for callers / tests
+    @property
+    def dim(self) -> int:
+        return self._sgroups[0].dim
+
+    @property
+    def shard(self):
+        return getattr(self, self._sgroups[0].pname)
 
     # ---------------------------------------------------------------- tables
     def build(self, *_):
-        if self.shard is not None:
-            self.built = True
+        if self.built:
             return
-        rows = self._row_off[-1]
-        shard = torch.zeros((rows, self.dim), dtype=self.variable_dtype, device=self._device)
-        for t, tc in enumerate(self._table_configs):
-            # rank r holds global rows r, r+N, r+2N, ...: initialise the full table deterministically
-            # only when it is small; otherwise draw the local rows directly
-            n_local = len(range(self.rank, tc.vocabulary_size, self.world))
-            init = base.get_initializer(tc.initializer)
-            if tc.vocabulary_size * self.dim <= (1 << 24):
-                full = init((tc.vocabulary_size, self.dim), self.variable_dtype, self._device)
-                shard[self._row_off[t]: self._row_off[t] + n_local] = full[self.rank::self.world]
-            else:
-                shard[self._row_off[t]: self._row_off[t] + n_local] = init((n_local, self.dim), self.variable_dtype,
+        for g in self._sgroups:
+            rows = g.row_off[-1]
+            shard = torch.zeros((rows, g.dim), dtype=self.variable_dtype, device=self._device)
+            for t, tc in enumerate(g.table_configs):
+                # rank r holds global rows r, r+N, r+2N, ...: initialise the full table deterministically
+                # only when it is small; otherwise draw the local rows directly
+                n_local = len(range(self.rank, tc.vocabulary_size, self.world))
+                init = base.get_initializer(tc.initializer)
+                if tc.vocabulary_size * g.dim <= (1 << 24):
+                    full = init((tc.vocabulary_size, g.dim), self.variable_dtype, self._device)
+                    shard[g.row_off[t]: g.row_off[t] + n_local] = full[self.rank::self.world]
+                else:
+                    shard[g.row_off[t]: g.row_off[t] + n_local] = init((n_local, g.dim), self.variable_dtype,
                                                                      self._device)
-        self.shard = torch.nn.Parameter(shard, requires_grad=False)
-        self._weight_order.append(self.shard)
-        self._slot = self._fused.new_slot((rows, self.dim), self._device)
+            p = torch.nn.Parameter(shard, requires_grad=False)
+            setattr(self, g.pname, p)
+            self._weight_order.append(p)
+            slot = g.fused.new_slot((rows, g.dim), self._device)
+            if slot is not None:
+                self.register_buffer(g.sname, slot, persistent=True)   # optimizer state is module state
+        if self._replicated is not None:
+            self._replicated.build(None)
         self._anchor = torch.zeros((), device=self._device, requires_grad=True)
         self.built = True
+
+    def _slot(self, g: _ShardGroup):
+        return self._buffers.get(g.sname)
+
+    def get_extra_state(self):
+        return {"iterations": [int(g.step) for g in self._sgroups]}
+
+    def set_extra_state(self, state) -> None:
+        for g, s in zip(self._sgroups, (state or {}).get("iterations", [])):
+            g.step = int(s)
+
+    def _all_gather_rows(self, mine: torch.Tensor) -> list:
+        if self.world == 1:
+            return [mine]
+        mine = mine.contiguous()
+        staged = mine.is_cuda and dist.get_backend(self._pg) == "gloo"   # gloo gathers host tensors only
+        src = mine.cpu() if staged else mine
+        parts = [torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(parts, src, group=self._pg)
+        return [q.to(mine.device) for q in parts] if staged else parts
 
     def get_embedding_tables(self) -> dict[str, torch.Tensor]:
         """Unsharded [V, D] tables by name (all-gather + un-interleave), base:810-825 contract."""
         if not self.built:
             self.build()
-        if self.world > 1:
-            mine = self.shard.data.contiguous()
-            staged = mine.is_cuda and dist.get_backend(self._pg) == "gloo"   # gloo gathers host tensors only
-            src = mine.cpu() if staged else mine
-            parts = [torch.empty_like(src) for _ in range(self.world)]
-            dist.all_gather(parts, src, group=self._pg)
-            if staged:
-                parts = [q.to(mine.device) for q in parts]
-        else:
-            parts = [self.shard.data]
+        self.check_ids(wait=True)
         out = {}
-        for t, tc in enumerate(self._table_configs):
-            full = torch.empty((tc.vocabulary_size, self.dim), dtype=self.shard.dtype, device=self.shard.device)
-            for r in range(self.world):
-                n_local = len(range(r, tc.vocabulary_size, self.world))
-                full[r::self.world] = parts[r][self._row_off[t]: self._row_off[t] + n_local]
-            out[tc.name] = full
+        for g in self._sgroups:
+            parts = self._all_gather_rows(getattr(self, g.pname).data)
+            for t, tc in enumerate(g.table_configs):
+                full = torch.empty((tc.vocabulary_size, g.dim), dtype=parts[0].dtype, device=parts[0].device)
+                for r in range(self.world):
+                    n_local = len(range(r, tc.vocabulary_size, self.world))
+                    full[r::self.world] = parts[r][g.row_off[t]: g.row_off[t] + n_local]
+                out[tc.name] = full
+        if self._replicated is not None:
+            out.update(self._replicated.get_embedding_tables())
         return out
 
     def set_embedding_tables(self, tables: dict) -> None:
         if not self.built:
             self.build()
         with torch.no_grad():
-            for t, tc in enumerate(self._table_configs):
-                if tc.name in tables:
-                    full = torch.as_tensor(np.asarray(tables[tc.name])).to(self.shard.dtype).to(self.shard.device)
-                    mine = full[self.rank::self.world]
-                    self.shard[self._row_off[t]: self._row_off[t] + mine.shape[0]] = mine
+            for g in self._sgroups:
+                shard = getattr(self, g.pname)
+                for t, tc in enumerate(g.table_configs):
+                    if tc.name in tables:
+                        full = torch.as_tensor(np.asarray(tables[tc.name].detach().cpu() if isinstance(
+                            tables[tc.name], torch.Tensor) else tables[tc.name])).to(shard.dtype).to(shard.device)
+                        mine = full[self.rank::self.world]
+                        shard[g.row_off[t]: g.row_off[t] + mine.shape[0]] = mine
+        if self._replicated is not None:
+            self._replicated.set_embedding_tables(tables)
+
+    # ---------------------------------------------------------------- out-of-range ids (as DistributedEmbedding)
+    def _err_flag(self, device):
+        if device.type != "cuda":
+            return None
+        if self._err_dev is None:
+            self._err_dev = torch.zeros(1, dtype=torch.int32, device=device)
+            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return self._err_dev
+
+    def check_ids(self, wait: bool = False) -> None:
+        """IndexError if an earlier lookup met an id outside [0, vocabulary_size) of its table (such lookups are
+        dropped before the exchange: they reach no row of any table on any rank)."""
+        if self._replicated is not None:
+            self._replicated.check_ids(wait)
+        ev = self._err_event
+        if ev is None:
+            return
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._err_event = None
+        if int(self._err_host.item()) & L.FLAG_ID_OUT_OF_RANGE:
+            self._err_dev.zero_()
+            self._err_host.zero_()
+            raise IndexError("ShardedDistributedEmbedding: an embedding id was out of range for its table "
+                             "(ids are never clamped; the lookup was dropped)")
 
     # ---------------------------------------------------------------- inputs
     def preprocess(self, inputs: dict, weights: dict | None = None, training: bool = False):
-        """{feature: ids} -> one feature-major id buffer.  A feature is a dense [batch, hot] (or [batch])
-        array, or ragged: an embed_reduce.Ragged (values + row offsets) or a numpy object array of rows;
-        with any ragged feature the bags are described by CSR offsets instead of `hots`."""
+        """{feature: ids} -> per group one feature-major id buffer (+ CSR offsets when any feature is ragged)."""
         from keras_rs_amd.layers.distributed_embedding import _ragged_numpy_to_csr
         from keras_rs_amd.layers.embed_reduce import Ragged
 
         if not self.built:
             self.build()
-        dev = self.shard.device
-        parts, wparts, hots, lens, batch = [], [], [], [], None
-        ragged = False
-        for p in self._paths:
-            x = inputs[p]
-            w = None if weights is None else weights[p]
-            x, w = _ragged_numpy_to_csr(x, w)
-            if isinstance(x, Ragged):
-                ragged = True
-                vals = x.values if isinstance(x.values, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x.values))
-                offs = np.asarray(x.row_offsets.cpu() if isinstance(x.row_offsets, torch.Tensor) else x.row_offsets,
-                                  dtype=np.int64)
-                b = len(offs) - 1
-                t = vals.reshape(-1)
-                hots.append(None)
-                lens.append(np.diff(offs))
-                if w is not None:
-                    w = w.values if isinstance(w, Ragged) else w
-            else:
-                t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
-                if t.dim() == 1:
-                    t = t.reshape(-1, 1)
-                b = t.shape[0]
-                hots.append(int(t.shape[1]))
-                lens.append(np.full(b, t.shape[1], dtype=np.int64))
-            batch = b if batch is None else batch
-            if b != batch:
-                raise ValueError("all features must share the batch size")
-            parts.append(t.reshape(-1).to(torch.int64 if t.dtype == torch.int64 else torch.int32))
-            if weights is not None:
-                w = w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w))
-                wparts.append(w.reshape(-1).float())
-        ids = torch.cat(parts).to(dev, non_blocking=True)
-        w = torch.cat(wparts).to(dev, non_blocking=True) if weights is not None else None
-        offsets = None
-        if ragged:
-            offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.int64)).to(dev)
-        return {"preprocessed_inputs_per_placement": {"sparsecore": {
-            "inputs": {"ids": ids, "hots": None if ragged else tuple(hots), "batch": batch, "offsets": offsets},
-            "weights": w}}}
-
-    def _composite_offsets(self, batch, hots, dtype, device):
-        key = (batch, hots, dtype, str(device))
-        off = self._offset_cache.get(key)
-        if off is None:
-            per_feat = torch.tensor([self._row_off[self._table_of_feature[i]] * self.world for i in range(len(hots))],
-                                    dtype=dtype)
-            reps = torch.tensor([batch * h for h in hots])
-            off = torch.repeat_interleave(per_feat, reps).to(device)
-            self._offset_cache[key] = off
-        return off
+        pre: dict = {"groups": []}
+        for g in self._sgroups:
+            dev = getattr(self, g.pname).device
+            parts, wparts, hots, lens, batch = [], [], [], [], None
+            ragged = False
+            for p in g.paths:
+                x = inputs[p]
+                w = None if weights is None else weights[p]
+                x, w = _ragged_numpy_to_csr(x, w)
+                if isinstance(x, Ragged):
+                    ragged = True
+                    vals = x.values if isinstance(x.values, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x.values))
+                    offs = np.asarray(x.row_offsets.cpu() if isinstance(x.row_offsets, torch.Tensor) else x.row_offsets,
+                                      dtype=np.int64)
+                    b = len(offs) - 1
+                    t = vals.reshape(-1)
+                    hots.append(None)
+                    lens.append(np.diff(offs))
+                    if w is not None:
+                        w = w.values if isinstance(w, Ragged) else w
+                else:
+                    t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+                    if t.dim() == 1:
+                        t = t.reshape(-1, 1)
+                    b = t.shape[0]
+                    hots.append(int(t.shape[1]))
+                    lens.append(np.full(b, t.shape[1], dtype=np.int64))
+                batch = b if batch is None else batch
+                if b != batch:
+                    raise ValueError("all features must share the batch size")
+                parts.append(t.reshape(-1).to(torch.int64 if t.dtype == torch.int64 else torch.int32))
+                if weights is not None:
+                    w = w if isinstance(w, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(w))
+                    wparts.append(w.reshape(-1).float())
+            dt = torch.int64 if any(q.dtype == torch.int64 for q in parts) else torch.int32
+            ids = torch.cat([q.to(dt) for q in parts]).to(dev, non_blocking=True)
+            w = torch.cat(wparts).to(dev, non_blocking=True) if weights is not None else None
+            offsets = None
+            if ragged:
+                offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.int64)).to(dev)
+            pre["groups"].append({"ids": ids, "hots": None if ragged else tuple(hots), "batch": batch,
+                                  "offsets": offsets, "weights": w})
+        if self._replicated is not None:
+            rp = [p for p in self._paths if self._where[p][0] == "rep"]
+            pre["replicated"] = self._replicated.preprocess({p: inputs[p] for p in rp},
+                                                            None if weights is None else {p: weights[p] for p in rp})
+        return {"preprocessed_inputs_per_placement": {"sparsecore": pre}}
 
     # ---------------------------------------------------------------- step
     def call(self, inputs, weights=None, training: bool = False):
+        self.check_ids()
         if not (isinstance(inputs, dict) and "preprocessed_inputs_per_placement" in inputs):
             inputs = self.preprocess(inputs, weights, training)
         pre = inputs["preprocessed_inputs_per_placement"]["sparsecore"]
-        fi = pre["inputs"]
-        slab, *outs = _ShardedLookupFn.apply(self, fi["ids"], fi["batch"], fi["hots"], fi["offsets"],
-                                             pre.get("weights"), self._anchor)
-        for i, o in enumerate(outs):
-            o._krs_slab = (slab, self.slab_lead_cols + i * self.dim, len(outs), self.slab_lead_cols)
-        return {p: o for p, o in zip(self._paths, outs)}
+        out: dict = {}
+        single = len(self._sgroups) == 1 and self._replicated is None
+        for gi, (g, fi) in enumerate(zip(self._sgroups, pre["groups"])):
+            lead = self.slab_lead_cols if single else 0
+            slab, *outs = _ShardedLookupFn.apply(self, gi, fi["ids"], fi["batch"], fi["hots"], fi["offsets"],
+                                                 fi["weights"], lead, self._anchor)
+            for i, o in enumerate(outs):
+                o._krs_slab = (slab, lead + i * g.dim, len(outs), lead)
+            out.update(zip(g.paths, outs))
+        if self._replicated is not None:
+            out.update(self._replicated(pre["replicated"]))
+        if self._err_dev is not None:
+            self._err_host.copy_(self._err_dev, non_blocking=True)
+            self._err_event = torch.cuda.Event()
+            self._err_event.record()
+        return {p: out[p] for p in self._paths}
 
-    def _a2a(self, send: torch.Tensor, send_counts: list[int], recv_counts: list[int]) -> torch.Tensor:
+    def _a2a(self, send: torch.Tensor, send_counts: list, recv_counts: list) -> torch.Tensor:
         recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         if self.world == 1:
             recv.copy_(send)
@@ -336,115 +535,74 @@ class ShardedDistributedEmbedding(base.Layer):
                                    input_split_sizes=send_counts, group=self._pg)
         return recv
 
-    def _bag_tables(self, batch, hots, device):
-        """Per (batch, hots): bag of every lookup position (feature-major), combiner code of every bag."""
-        key = ("bags", batch, hots, str(device))
-        got = self._offset_cache.get(key)
-        if got is None:
-            bag = torch.cat([f * batch + torch.arange(batch, dtype=torch.int32).repeat_interleave(h)
-                             for f, h in enumerate(hots)])
-            comb = torch.tensor([{"sum": 0, "mean": 1, "sqrtn": 2}[c] for c in self._combiners],
-                                dtype=torch.int32).repeat_interleave(batch)
-            got = self._offset_cache[key] = (bag.to(device), comb.to(device))
-        return got
-
-    def _lookup_weights(self, weights, bag_of_pos, comb_of_bag, n_bags):
-        """User weight x combiner scale per lookup (mean: 1 / sum w, sqrtn: 1 / sqrt(sum w^2), both
-        divide_no_nan: embed_reduce.py:236-262), or None when every bag is a plain sum."""
-        if weights is None and all(c == "sum" for c in self._combiners):
-            return None
-        w = torch.ones(bag_of_pos.numel(), dtype=torch.float32, device=bag_of_pos.device) if weights is None \
-            else weights.float()
-        idx = bag_of_pos.long()
-        s1 = torch.zeros(n_bags, dtype=torch.float32, device=w.device).index_add_(0, idx, w)
-        s2 = torch.zeros(n_bags, dtype=torch.float32, device=w.device).index_add_(0, idx, w * w)
-        inv = lambda d: torch.where(d != 0, 1.0 / d, torch.zeros_like(d))  # noqa: E731
-        scale = torch.where(comb_of_bag == 1, inv(s1), torch.where(comb_of_bag == 2, inv(s2.sqrt()),
-                                                                   torch.ones_like(s1)))
-        return w * scale[idx]
-
-    def _forward_impl(self, ids, batch, hots, offsets, weights):
-        k, n, dev = self.kernels, self.world, ids.device
-        if ids.dtype == torch.int32 and self._row_off[-1] * self.world >= 2 ** 31:
-            ids = ids.long()   # the composite id space (all tables, interleaved over the ranks) needs 64 bits
-        n_feats = len(self._paths)
-        nnz, n_bags = ids.numel(), batch * n_feats
-        if offsets is None:
-            comp = ids + self._composite_offsets(batch, hots, ids.dtype, dev)
-            bag_of_pos, comb_of_bag = self._bag_tables(batch, hots, dev)
-        else:  # ragged bags: CSR offsets over the feature-major bags
-            lens = torch.diff(offsets)
-            bag_of_pos = torch.repeat_interleave(torch.arange(n_bags, dtype=torch.int32, device=dev), lens)
-            _, comb_of_bag = self._bag_tables(batch, (1,) * n_feats, dev)
-            feat_off = torch.tensor([self._row_off[t] * self.world for t in self._table_of_feature], dtype=ids.dtype,
-                                    device=dev)
-            comp = ids + feat_off[(bag_of_pos // batch).long()]
-        local_rows, perm, counts = k.bucketize(comp, n)
-        w_eff = self._lookup_weights(weights, bag_of_pos, comb_of_bag, n_bags)
-        # segments: runs of one bag inside a bucket (the bucketise is stable, so bags ascend in a bucket).
-        # Everything up to the size exchange has a data-independent shape (length nnz, valid in the first
-        # n_seg entries), so the host waits for the device exactly once per lookup: for the sizes.
-        order = perm.long()
-        bag_b = bag_of_pos[order]
-        ends = torch.cumsum(counts, 0)
-        starts = ends - counts
-        head = torch.ones(nnz + 1, dtype=torch.bool, device=dev)
-        if nnz > 1:
-            head[1:nnz] = bag_b[1:] != bag_b[:-1]
-        head[starts] = True          # an empty bucket's start is the next bucket's (or the spare slot nnz)
-        heads_before = torch.zeros(nnz + 1, dtype=torch.int64, device=dev)
-        heads_before[1:] = torch.cumsum(head[:nnz], 0)                               # segments in front of position p
-        seg_counts = heads_before[ends] - heads_before[starts]                       # per destination bucket
-        # slot s < n_seg: first lookup of segment s; slots n_seg..nnz keep the sentinel nnz; slot nnz + 1
-        # swallows the writes of the non-head positions
-        pos = torch.arange(nnz, dtype=torch.int64, device=dev)
-        slot = torch.where(head[:nnz], heads_before[:nnz], torch.full_like(pos, nnz + 1))
-        first = torch.full((nnz + 2,), nnz, dtype=torch.int64, device=dev)
-        first[slot] = pos
-        seg_len_all = (first[1:nnz + 1] - first[:nnz]).to(torch.int32)
-        seg_bag_all = bag_b[first[:nnz].clamp_(max=max(nnz - 1, 0))]
-        # sizes: every rank learns how many lookups / segments it receives (one tiny all-to-all + host sync)
-        mine = torch.stack([counts.to(torch.int64), seg_counts], dim=1).contiguous()   # [n, 2]
+    def _exchange_sizes(self, mine: torch.Tensor):
+        """mine: [3, N] int64 per-owner counts on the device.  Returns (mine, theirs) as host lists of lists:
+        theirs[k][s] = what rank s sends here.  One host wait (page-locked flag) on the GPU path."""
+        n = self.world
         if n > 1:
-            theirs = self._a2a(mine, [1] * n, [1] * n)
+            theirs = self._a2a(mine.t().contiguous(), [1] * n, [1] * n).t().contiguous()   # rows = per-rank triples
         else:
-            theirs = mine.clone()
-        sizes = torch.stack([mine, theirs]).cpu()   # ONE device-to-host copy / sync for all four lists
-        send_counts, send_segs = sizes[0, :, 0].tolist(), sizes[0, :, 1].tolist()
-        recv_counts, recv_segs = sizes[1, :, 0].tolist(), sizes[1, :, 1].tolist()
+            theirs = mine
+        both = torch.stack([mine, theirs]).reshape(-1)
+        if both.is_cuda and isinstance(self.kernels, HipShardKernels):
+            if self._host_counts is None:
+                self._host_counts = _HostCounts()
+            flat = self._host_counts.read(both)
+        else:
+            flat = both.cpu().tolist()
+        a = np.asarray(flat, dtype=np.int64).reshape(2, 3, n)
+        return a[0].tolist(), a[1].tolist()
+
+    def _route_desc(self, g: _ShardGroup, batch: int, hots) -> np.ndarray:
+        desc = np.zeros(len(g.paths), dtype=L.SHARD_FEATURE_DT)
+        base_pos = 0
+        for i, p in enumerate(g.paths):
+            tc = g.table_configs[g.table_of_feature[i]]
+            hot = 0 if hots is None else int(hots[i])
+            desc[i] = (base_pos, g.row_off[g.table_of_feature[i]] * self.world, hot, L.COMBINERS[tc.combiner],
+                       tc.vocabulary_size, 0)
+            base_pos += batch * hot
+        return desc
+
+    def _forward_impl(self, gi, ids, batch, hots, offsets, weights, lead):
+        k, n, g = self.kernels, self.world, self._sgroups[gi]
+        dev = ids.device
+        n_feats = len(g.paths)
+        shard = getattr(self, g.pname).data
+        emit_w = weights is not None or any(g.table_configs[t].combiner != "sum" for t in g.table_of_feature)
+        r = k.route(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, self._err_flag(dev))
+        mine, theirs = self._exchange_sizes(r["counts"])
+        send_cnt, send_segs, send_words = mine
+        recv_cnt, recv_segs, recv_words = theirs
         n_seg = sum(send_segs)
-        seg_bag, seg_len = seg_bag_all[:n_seg], seg_len_all[:n_seg]
-        # to the owners: rows, segment lengths, weights (bucket order)
-        recv_rows = self._a2a(local_rows, send_counts, recv_counts)
-        recv_len = self._a2a(seg_len, send_segs, recv_segs)
-        recv_w = None if w_eff is None else self._a2a(w_eff[order], send_counts, recv_counts)
-        recv_off = torch.zeros(recv_len.numel() + 1, dtype=torch.int32, device=dev)
-        recv_off[1:] = torch.cumsum(recv_len, 0)
-        partial = k.pool_segments(self.shard.data, recv_rows, recv_off, recv_w, self.compute_dtype)
+        self.last_exchange = dict(send_lookups=send_cnt, recv_lookups=recv_cnt, send_segments=send_segs,
+                                  recv_segments=recv_segs)
+        # to the owners: ONE packed buffer (rows | weights | segment lengths per owner)
+        recv_packed = self._a2a(r["packed"][:sum(send_words)], send_words, recv_words)
+        rows, w, off = k.unpack(recv_packed, recv_cnt, recv_segs, emit_w)
+        pdt = self._partial_dtype or self.compute_dtype
+        if isinstance(pdt, str):
+            pdt = {"float32": torch.float32, "bfloat16": torch.bfloat16}[pdt]
+        partial = k.pool_segments(shard, rows, off, w, pdt)
         back = self._a2a(partial, recv_segs, send_segs)                           # home side, segment order
-        # every bag sums its partials: segments sorted by bag -> feature-major CSR over segment ids
-        seg_sorted = torch.argsort(seg_bag, stable=True).to(torch.int32)
-        bag_off = torch.zeros(n_bags + 1, dtype=torch.int32, device=dev)
-        per_bag = torch.zeros(n_bags, dtype=torch.int32, device=dev).scatter_add_(
-            0, seg_bag.long(), torch.ones_like(seg_bag, dtype=torch.int32))
-        bag_off[1:] = torch.cumsum(per_bag, 0)
-        feats = [(0, "sum", i * self.dim) for i in range(len(self._combiners))]
-        lead = self.slab_lead_cols
-        slab = torch.empty((batch, lead + len(feats) * self.dim), dtype=back.dtype, device=dev)
-        k.pool(back, seg_sorted, feats, batch, bag_off, self.compute_dtype, out=slab[:, lead:])
-        saved = dict(batch=batch, seg_bag=seg_bag, send_segs=send_segs, recv_segs=recv_segs, recv_rows=recv_rows,
-                     recv_off=recv_off, recv_w=recv_w, out_meta=(slab.dtype, slab.device))
+        slab = torch.empty((batch, lead + n_feats * g.dim), dtype=back.dtype, device=dev)
+        k.combine(back, r["bag_seg"], batch, n_feats, g.dim, slab[:, lead:])
+        if slab.dtype != self.compute_dtype:
+            slab = slab.to(self.compute_dtype)
+        saved = dict(batch=batch, seg_grow=r["seg_grow"][:n_seg], send_segs=send_segs, recv_segs=recv_segs,
+                     rows=rows, off=off, w=w, pdt=pdt, out_meta=(slab.dtype, slab.device))
         return slab, saved
 
-    def _backward_impl(self, g, s):
-        k, n_feats, batch = self.kernels, len(self._combiners), s["batch"]
-        # d(partial of a segment) = the output gradient of its bag: rows of g viewed as [batch * n_feats, dim]
-        g = g.contiguous()
-        seg_bag = s["seg_bag"]
-        rows = ((seg_bag % batch) * n_feats + seg_bag // batch).to(torch.int32)
-        dpart = k.gather_rows(g.view(batch * n_feats, self.dim), rows)
+    def _backward_impl(self, gi, grad, s):
+        k, g = self.kernels, self._sgroups[gi]
+        n_feats, batch = len(g.paths), s["batch"]
+        # d(partial of a segment) = the output gradient of its bag: rows of grad viewed as [batch * n_feats, dim]
+        grad = grad.contiguous()
+        if grad.dtype != s["pdt"]:
+            grad = grad.to(s["pdt"])
+        dpart = k.gather_rows(grad.view(batch * n_feats, g.dim), s["seg_grow"])
         dseg = self._a2a(dpart, s["send_segs"], s["recv_segs"])                   # to the owners
-        lr = self._fused.lr_at(self._step)
-        self._step += 1
-        k.apply_segments(self.shard.data, self._slot, s["recv_rows"], s["recv_off"], s["recv_w"], dseg, lr,
-                         self._opt_kind, self._fused.hyper(self._step))
+        lr = g.fused.lr_at(g.step)
+        g.step += 1
+        k.apply_segments(getattr(self, g.pname).data, self._slot(g), s["rows"], s["off"], s["w"], dseg, lr,
+                         g.fused.kind, g.fused.hyper(g.step), 1.0 / self.world if self.grad_average else 1.0)

@@ -429,3 +429,132 @@ int krs_oracle_mod_bucketize(const void* ids, int id_type, int64_t nnz, int n_sh
   free(start);
   return KRS_OK;
 }
+
+/* ---- K6: row-sharded lookup, id side (include/krs.h: krs_shard_route / unpack / combine) --------------
+ * Sequential restatement: MOD ownership and local rows as in the reference's layout
+ * (tensorflow/distributed_embedding.py:316-328, jax/embedding_utils.py:187-197), combiner scales as
+ * embed_reduce.py:255-274, segments = runs of one bag inside an owner's bucket in lookup order. */
+int krs_oracle_shard_route(const krs_shard_feature* feats, int n_feats, const void* ids, int id_type,
+                           const void* offsets, int offset_type, const float* weights, int64_t nnz, int batch,
+                           int n_shards, int emit_weights, int32_t* packed, int32_t* seg_bag, int32_t* seg_grow,
+                           int32_t* bag_seg, int64_t* counts, int32_t* err_flag) {
+  const int64_t n_bags = (int64_t)batch * n_feats;
+  for (int64_t i = 0; i < n_bags * n_shards; ++i) bag_seg[i] = -1;
+  for (int i = 0; i < 3 * n_shards; ++i) counts[i] = 0;
+  if (nnz == 0) return 0;
+  int32_t* dest = (int32_t*)malloc((size_t)nnz * 4);
+  int32_t* row = (int32_t*)malloc((size_t)nnz * 4);
+  int32_t* bagp = (int32_t*)malloc((size_t)nnz * 4);
+  float* wl = (float*)malloc((size_t)nnz * 4);
+  /* per lookup: bag, validity, owner, local row, effective weight */
+  for (int f = 0; f < n_feats; ++f)
+    for (int b = 0; b < batch; ++b) {
+      const int64_t bag = (int64_t)f * batch + b;
+      int64_t lo, hi;
+      if (offsets) { lo = ldi(offsets, offset_type, bag); hi = ldi(offsets, offset_type, bag + 1); }
+      else { lo = feats[f].ids_base + (int64_t)b * feats[f].hot; hi = lo + feats[f].hot; }
+      float s1 = 0.0f, s2 = 0.0f;
+      for (int64_t q = lo; q < hi; ++q) {
+        const float w = weights ? weights[q] : 1.0f;
+        s1 += w;
+        s2 = fmaf(w, w, s2);
+      }
+      float scale = 1.0f;
+      if (feats[f].combiner != KRS_SUM) {
+        const float d = feats[f].combiner == KRS_MEAN ? s1 : sqrtf(s2);
+        scale = d != 0.0f ? 1.0f / d : 0.0f;
+      }
+      for (int64_t q = lo; q < hi; ++q) {
+        const int64_t id = ldi(ids, id_type, q);
+        bagp[q] = (int32_t)bag;
+        wl[q] = (weights ? weights[q] : 1.0f) * scale;
+        if (id < 0 || id >= feats[f].vocab) {
+          dest[q] = n_shards;
+          row[q] = 0;
+          if (err_flag) *err_flag |= KRS_FLAG_ID_OUT_OF_RANGE;
+        } else {
+          const int64_t c = feats[f].comp_off + id;
+          dest[q] = (int32_t)(c % n_shards);
+          row[q] = (int32_t)(c / n_shards);
+        }
+      }
+    }
+  /* counts, then the packed blocks in owner order (stable inside an owner) */
+  for (int64_t q = 0; q < nnz; ++q)
+    if (dest[q] < n_shards) counts[dest[q]]++;
+  int64_t n_seg = 0;
+  for (int d = 0; d < n_shards; ++d) {
+    int32_t prev = -1;
+    int first = 1;
+    for (int64_t q = 0; q < nnz; ++q)
+      if (dest[q] == d) {
+        if (first || bagp[q] != prev) counts[n_shards + d]++;
+        prev = bagp[q];
+        first = 0;
+      }
+  }
+  int64_t base = 0;
+  for (int d = 0; d < n_shards; ++d) {
+    const int64_t cnt = counts[d], segs = counts[n_shards + d];
+    counts[2 * n_shards + d] = cnt * (1 + (emit_weights != 0)) + segs;
+    int64_t k = 0, sk = -1;
+    int32_t prev = -1;
+    for (int64_t q = 0; q < nnz; ++q)
+      if (dest[q] == d) {
+        if (k == 0 || bagp[q] != prev) {
+          ++sk;
+          const int32_t bag = bagp[q];
+          seg_bag[n_seg] = bag;
+          seg_grow[n_seg] = (bag % batch) * n_feats + bag / batch;
+          bag_seg[(int64_t)bag * n_shards + d] = (int32_t)n_seg;
+          packed[base + cnt * (1 + (emit_weights != 0)) + sk] = 0;
+          ++n_seg;
+        }
+        prev = bagp[q];
+        packed[base + k] = row[q];
+        if (emit_weights) memcpy(&packed[base + cnt + k], &wl[q], 4);
+        packed[base + cnt * (1 + (emit_weights != 0)) + sk] += 1;
+        ++k;
+      }
+    base += counts[2 * n_shards + d];
+  }
+  free(dest); free(row); free(bagp); free(wl);
+  return 0;
+}
+
+int krs_oracle_shard_unpack(const int32_t* packed, int n_sources, const int64_t* lookups, const int64_t* segments,
+                            int weighted, int32_t* rows, float* w, int32_t* offsets) {
+  int64_t base = 0, r = 0, s = 0;
+  int32_t run = 0;
+  for (int src = 0; src < n_sources; ++src) {
+    const int64_t cnt = lookups[src], segs = segments[src];
+    for (int64_t k = 0; k < cnt; ++k) {
+      rows[r + k] = packed[base + k];
+      if (weighted) memcpy(&w[r + k], &packed[base + cnt + k], 4);
+    }
+    for (int64_t k = 0; k < segs; ++k) {
+      offsets[s + k] = run;
+      run += packed[base + cnt * (1 + (weighted != 0)) + k];
+    }
+    r += cnt;
+    s += segs;
+    base += cnt * (1 + (weighted != 0)) + segs;
+  }
+  offsets[s] = run;
+  return 0;
+}
+
+int krs_oracle_shard_combine(const void* partials, const int32_t* bag_seg, int batch, int n_feats, int n_shards,
+                             int dim, int dtype, void* out, int64_t out_ld) {
+  for (int f = 0; f < n_feats; ++f)
+    for (int b = 0; b < batch; ++b)
+      for (int j = 0; j < dim; ++j) {
+        float acc = 0.0f;
+        for (int d = 0; d < n_shards; ++d) {
+          const int32_t s = bag_seg[((int64_t)f * batch + b) * n_shards + d];
+          if (s >= 0) acc += ld(partials, dtype, (int64_t)s * dim + j);
+        }
+        st(out, dtype, (int64_t)b * out_ld + (int64_t)f * dim + j, acc);
+      }
+  return 0;
+}

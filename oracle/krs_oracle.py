@@ -351,3 +351,60 @@ def feature_cross(x0, x, kernel, bias=None, down_kernel=None, diag_scale=0.0, ac
     kk = h.shape[1]
     y, _ = gemm(h, kernel, m, d, kk, bias=bias, act=act, diag_scale=diag_scale or 0.0, x0=x02, x=x2)
     return y.reshape(*lead, d)
+
+
+# --------------------------------------------------------------------------- #
+# K6: the id side of the row-sharded lookup (include/krs.h: krs_shard_*)
+# --------------------------------------------------------------------------- #
+SHARD_FEATURE_DT = np.dtype(
+    [("ids_base", "<i8"), ("comp_off", "<i8"), ("hot", "<i4"), ("combiner", "<i4"), ("vocab", "<i4"),
+     ("reserved", "<i4")]
+)
+assert SHARD_FEATURE_DT.itemsize == 32
+
+
+def shard_route(feats, ids, offsets, weights, batch, n_shards, emit_weights):
+    """Returns dict(packed, seg_bag, seg_grow, bag_seg, counts [3, n_shards], flags); arrays sized as the device
+    call sizes them (first n_seg / sum(counts[2]) entries valid)."""
+    nnz = int(ids.shape[0])
+    n_feats = len(feats)
+    packed = np.zeros(max(nnz * (2 + int(bool(emit_weights))), 1), np.int32)
+    seg_bag = np.zeros(max(nnz, 1), np.int32)
+    seg_grow = np.zeros(max(nnz, 1), np.int32)
+    bag_seg = np.zeros((max(batch * n_feats, 1), n_shards), np.int32)
+    counts = np.zeros(3 * n_shards, np.int64)
+    flag = np.zeros(1, np.int32)
+    w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+    rc = lib().krs_oracle_shard_route(
+        _p(feats), C.c_int(n_feats), _p(ids), C.c_int(itype(ids)),
+        _p(offsets), C.c_int(itype(offsets) if offsets is not None else I32), _p(w), C.c_int64(nnz),
+        C.c_int(batch), C.c_int(n_shards), C.c_int(int(bool(emit_weights))), _p(packed), _p(seg_bag), _p(seg_grow),
+        _p(bag_seg), _p(counts), _p(flag))
+    assert rc == 0, rc
+    return dict(packed=packed, seg_bag=seg_bag, seg_grow=seg_grow, bag_seg=bag_seg,
+                counts=counts.reshape(3, n_shards), flags=int(flag[0]))
+
+
+def shard_unpack(packed, lookups, segments, weighted):
+    lookups = np.ascontiguousarray(lookups, np.int64)
+    segments = np.ascontiguousarray(segments, np.int64)
+    n_cnt, n_seg = int(lookups.sum()), int(segments.sum())
+    rows = np.zeros(max(n_cnt, 1), np.int32)
+    w = np.zeros(max(n_cnt, 1), np.float32)
+    off = np.zeros(n_seg + 1, np.int32)
+    rc = lib().krs_oracle_shard_unpack(_p(np.ascontiguousarray(packed, np.int32)), C.c_int(len(lookups)), _p(lookups),
+                                       _p(segments), C.c_int(int(bool(weighted))), _p(rows), _p(w), _p(off))
+    assert rc == 0, rc
+    return rows[:n_cnt], (w[:n_cnt] if weighted else None), off
+
+
+def shard_combine(partials, bag_seg, batch, n_feats, dim, out=None):
+    n_shards = bag_seg.shape[1]
+    if out is None:
+        out = np.zeros((batch, n_feats * dim), partials.dtype)
+    part = np.ascontiguousarray(partials) if partials.shape[0] else np.zeros((1, dim), partials.dtype)
+    rc = lib().krs_oracle_shard_combine(_p(part), _p(np.ascontiguousarray(bag_seg, np.int32)), C.c_int(batch),
+                                        C.c_int(n_feats), C.c_int(n_shards), C.c_int(dim), C.c_int(fdtype(part)),
+                                        _p(out), C.c_int64(out.strides[0] // out.itemsize))
+    assert rc == 0, rc
+    return out

@@ -13,6 +13,78 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def criteo_shaped(rank, world, kl, Sharded):
+    """The 26 Criteo-1TB vocabularies (examples/ml_perf/configs/v6e_8.py:15-172) scaled down by 2000, the ml_perf
+    bag lengths, embedding_threshold scaled alike: tables under it are REPLICATED (main.py:135-141), the rest
+    MOD-sharded.  Checks: (1) outputs equal the single-GPU layer's, (2) the lookups every rank receives are within
+    5 % of each other -- with the 3-, 4-, 10-row tables sharded they would not be --, (3) grad_average scales the
+    table update by 1 / world, (4) replicated tables hand back dense gradients."""
+    vocabs = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282, 10, 2209, 11938,
+              155, 4, 976, 14, 40000000, 40000000, 40000000, 590152, 12973, 108, 36]
+    hots = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
+    V = [max(3, v // 2000) for v in vocabs]
+    threshold, D, B, lr = 11, 16, 64, 0.05
+
+    def configs():
+        tcs = [kl.TableConfig(f"cat_{t}", V[t], D, optimizer=kl.SGD(lr), combiner="sum", placement="sparsecore")
+               for t in range(26)]
+        return {f"cat_{t:02d}_id": kl.FeatureConfig(f"cat_{t}", tcs[t], (B, hots[t]), (B, D)) for t in range(26)}
+
+    rng = np.random.default_rng(11)
+    full = {f"cat_{t}": rng.uniform(-1, 1, (V[t], D)).astype(np.float32) for t in range(26)}
+    ids = [{f"cat_{t:02d}_id": np.random.default_rng(1000 + 50 * r + t).integers(0, V[t], (B, hots[t])).astype(np.int32)
+            for t in range(26)} for r in range(world)]
+    g = [{k: np.random.default_rng(5000 + 50 * r + i).uniform(-1, 1, (B, D)).astype(np.float32)
+          for i, k in enumerate(ids[r])} for r in range(world)]
+    small = [f"cat_{t}" for t in range(26) if V[t] < threshold]
+    assert len(small) >= 8
+    results = {}
+    for avg in (False, True):
+        layer = Sharded(configs(), replicate_below=threshold, grad_average=avg)
+        layer.build(None)
+        layer.set_embedding_tables(full)
+        out = layer(ids[rank])
+        sum((o * torch.from_numpy(g[rank][k]).cuda()).sum() for k, o in out.items()).backward()
+        torch.cuda.synchronize()
+        recv = torch.tensor([float(sum(layer.last_exchange["recv_lookups"]))])
+        all_recv = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(all_recv, recv)
+        loads = np.array([float(x) for x in all_recv])
+        assert loads.max() / loads.mean() < 1.05 and loads.min() / loads.mean() > 0.95, loads
+        rep = layer._replicated
+        rep_grads = {tc.name: rep._table_params[id(tc)].grad.clone() for grp in rep._groups["default_device"]
+                     for tc in grp.table_configs}
+        assert sorted(rep_grads) == sorted(small)
+        results[avg] = (out, {k: v.cpu().numpy() for k, v in layer.get_embedding_tables().items()}, rep_grads)
+
+    ref = kl.DistributedEmbedding({k: kl.FeatureConfig(k, fc.table, (world * B, fc.input_shape[1]), (world * B, D))
+                                   for k, fc in configs().items()})
+    ref.build(None)
+    ref.set_embedding_tables(full)
+    cat = lambda xs, k: np.concatenate([x[k] for x in xs], 0)  # noqa: E731
+    rout = ref({k: cat(ids, k) for k in ids[0]})
+    sum((o * torch.from_numpy(cat(g, k)).cuda()).sum() for k, o in rout.items()).backward()
+    ref_tables = {k: v.cpu().numpy() for k, v in ref.get_embedding_tables().items()}
+    out, tables, rep_grads = results[False]
+    for k in out:
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), rout[k].detach().cpu().numpy()[rank * B:(rank + 1) * B],
+                                   rtol=1e-5, atol=1e-5)
+    for t in range(26):
+        name = f"cat_{t}"
+        if name in small:
+            # replicated: untouched by the fused update; this rank's dense gradient = scatter-add of its own batch
+            np.testing.assert_array_equal(tables[name], full[name])
+            dense = np.zeros((V[t], D), np.float64)
+            np.add.at(dense, ids[rank][f"cat_{t:02d}_id"].reshape(-1),
+                      np.repeat(g[rank][f"cat_{t:02d}_id"], hots[t], axis=0))
+            np.testing.assert_allclose(rep_grads[name].cpu().numpy(), dense, rtol=1e-5, atol=1e-5)
+        else:
+            np.testing.assert_allclose(tables[name], ref_tables[name], rtol=2e-5, atol=2e-6)
+            # grad_average: the same update scaled by 1 / world (SGD is linear in the gradient)
+            np.testing.assert_allclose(results[True][1][name] - full[name], (ref_tables[name] - full[name]) / world,
+                                       rtol=1e-4, atol=2e-6)
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -62,6 +134,8 @@ def main():
                                    rtol=1e-5, atol=1e-5)
     for k, v in ref.get_embedding_tables().items():
         np.testing.assert_allclose(got_tables[k], v.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    if kind == "adagrad":
+        criteo_shaped(rank, world, kl, ShardedDistributedEmbedding)
     dist.barrier()
     if rank == 0:
         print("SHARDED_HIP_OK", kind)

@@ -16,11 +16,24 @@ from oracle import krs_oracle as ko  # noqa: E402
 
 
 class OracleShardKernels:
-    """The five kernel calls of keras_rs_amd.sharded on the CPU oracle."""
+    """The kernel calls of keras_rs_amd.sharded on the CPU oracle (K6 route / unpack / combine, K1, K2)."""
 
-    def bucketize(self, ids, n):
-        l, p, c = ko.mod_bucketize(ids.numpy(), n)
-        return torch.from_numpy(l), torch.from_numpy(p), torch.from_numpy(c)
+    def route(self, desc, ids, offsets, weights, batch, n_shards, emit_w, err_flag=None):
+        r = ko.shard_route(desc.view(ko.SHARD_FEATURE_DT), np.ascontiguousarray(ids.numpy()),
+                           None if offsets is None else np.ascontiguousarray(offsets.numpy()),
+                           None if weights is None else weights.numpy(), batch, n_shards, emit_w)
+        self.flags = r["flags"]
+        return dict(packed=torch.from_numpy(r["packed"]), seg_grow=torch.from_numpy(r["seg_grow"]),
+                    bag_seg=torch.from_numpy(r["bag_seg"]), counts=torch.from_numpy(r["counts"].copy()))
+
+    def unpack(self, packed, lookups, segments, weighted):
+        rows, w, off = ko.shard_unpack(packed.numpy(), lookups, segments, weighted)
+        return torch.from_numpy(rows.copy()), (None if w is None else torch.from_numpy(w.copy())), torch.from_numpy(off)
+
+    def combine(self, partials, bag_seg, batch, n_feats, dim, out):
+        res = ko.shard_combine(np.ascontiguousarray(partials.numpy()), bag_seg.numpy(), batch, n_feats, dim)
+        out.copy_(torch.from_numpy(res))
+        return out
 
     def gather_rows(self, table, rows):
         t = table.detach().numpy()
@@ -32,34 +45,23 @@ class OracleShardKernels:
         out = np.zeros((max(n_seg, 1), t.shape[1]), np.float32)
         if n_seg:
             f = ko.make_features([0], ["sum"], [0])
-            ko.embed_bag_fwd_raw(ko.make_tables([t]), ko.F32, f, rows.numpy(), offsets.numpy(),
-                                 None if weights is None else weights.numpy(), n_seg, t.shape[1], out)
+            ko.embed_bag_fwd_raw(ko.make_tables([t]), ko.F32, f, np.ascontiguousarray(rows.numpy()), offsets.numpy(),
+                                 None if weights is None else np.ascontiguousarray(weights.numpy()), n_seg, t.shape[1], out)
         return torch.from_numpy(out[:n_seg])
 
-    def pool(self, vectors, ids, feats, batch, offsets, out_dtype, out=None):
-        v = np.ascontiguousarray(vectors.numpy())
-        if v.shape[0] == 0:
-            v = np.zeros((1, v.shape[1]), np.float32)
-        f = ko.make_features([0] * len(feats), [c for _, c, _ in feats], [col for _, _, col in feats])
-        res = np.zeros((batch, len(feats) * v.shape[1]), np.float32)
-        ko.embed_bag_fwd_raw(ko.make_tables([v]), ko.F32, f, ids.numpy(), offsets.numpy(), None, batch, v.shape[1], res)
-        if out is None:
-            return torch.from_numpy(res)
-        out.copy_(torch.from_numpy(res))
-        return out
-
-    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None):
+    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None, grad_scale=1.0):
         t = table.numpy()
         n_seg = offsets.numel() - 1
         if rows.numel() == 0 or n_seg == 0:
             return
         dense = np.zeros_like(t)
         f = ko.make_features([0], ["sum"], [0])
-        ko.embed_bag_bwd_dense(ko.make_tables([dense]), f, rows.numpy(), offsets.numpy(),
-                               None if weights is None else weights.numpy(), None,
-                               np.ascontiguousarray(seg_grads.numpy()), n_seg, t.shape[1])
+        r = np.ascontiguousarray(rows.numpy())
+        ko.embed_bag_bwd_dense(ko.make_tables([dense]), f, r, offsets.numpy(),
+                               None if weights is None else np.ascontiguousarray(weights.numpy()), None,
+                               np.ascontiguousarray(seg_grads.numpy() * np.float32(grad_scale)), n_seg, t.shape[1])
         touched = np.zeros(t.shape[0], np.uint8)
-        touched[rows.numpy()] = 1
+        touched[r] = 1
         ko.apply_optimizer(t, None if slot is None else slot.numpy(), dense, touched, lr, kind, hyper)
 
 

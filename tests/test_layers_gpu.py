@@ -308,6 +308,48 @@ def test_distributed_embedding_reports_out_of_range_ids_lazily(placement):
     layer.check_ids(wait=True)
 
 
+@pytest.mark.parametrize("kind", ["adagrad", "adam"])
+def test_distributed_embedding_state_dict_carries_optimizer_state(kind):
+    # the reference's slot variables and `_iterations` are layer variables (jax/distributed_embedding.py:316-345):
+    # a checkpoint taken after k steps resumes exactly -- tables, accumulators / moments, update count
+    kl = _layers()
+
+    def make():
+        opt = kl.Adagrad(0.1, 0.1) if kind == "adagrad" else kl.Adam(0.05)
+        t = kl.TableConfig("t", 40, 8, placement="sparsecore", optimizer=opt, combiner="mean")
+        layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t, (8, 3), (8, 8))})
+        layer.build(None)
+        return layer
+
+    rng = np.random.default_rng(9)
+    batches = [rng.integers(0, 40, (8, 3)).astype(np.int32) for _ in range(4)]
+    grads = [torch.from_numpy(rng.uniform(-1, 1, (8, 8)).astype(np.float32)).to(DEV) for _ in range(4)]
+
+    def step(layer, i):
+        (layer({"a": batches[i]})["a"] * grads[i]).sum().backward()
+
+    a = make()
+    for i in range(2):
+        step(a, i)
+    sd = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in a.state_dict().items()}
+    assert any(k.endswith("_slot") for k in sd) and sd["_extra_state"]["iterations"] == {"sparsecore/0": 2}
+    b = make()
+    b.load_state_dict(sd)
+    for i in range(2, 4):
+        step(a, i)
+        step(b, i)
+    torch.testing.assert_close(b.get_embedding_tables()["t"], a.get_embedding_tables()["t"], rtol=0, atol=0)
+    for k, v in a.state_dict().items():
+        if isinstance(v, torch.Tensor):
+            torch.testing.assert_close(b.state_dict()[k], v, rtol=0, atol=0)
+    # a resumed run without the state would differ (Adam's bias correction / Adagrad's accumulator restart)
+    c = make()
+    c.set_embedding_tables({"t": sd["sparsecore_t_embeddings"]})
+    for i in range(2, 4):
+        step(c, i)
+    assert not torch.equal(c.get_embedding_tables()["t"], a.get_embedding_tables()["t"])
+
+
 def _de_configs(placement, optimizer="sgd", combiner="mean"):
     kl = _layers()
     de = KAT["distributed_embedding"]
