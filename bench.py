@@ -188,44 +188,112 @@ def k1_bytes(nnz, bags, dim, es):
     return nnz * (dim * es + 4) + bags * (dim * es + 4)
 
 
+def _median_time(fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), float(np.min(ts))
+
+
 def cpu_baseline(a, hots):
-    """The oracle (C restatement, OpenMP) on a bounded sample: batch `cpu_sample_batch`, same tables
-    count/width/bag lengths, vocab capped so the tables fit comfortably in host memory."""
+    """The hot path on the host cores, on a bounded sample of the same workload (batch `cpu_sample_batch` of the
+    same 26 tables x 1M rows x 128 bf16, same bag lengths, same cross stack), two implementations
+    (BASELINE.md section 3):
+      * `port`: the C oracle (oracle/krs_oracle.c, OpenMP over all host threads) -- gather+pool, then one
+        FeatureCross layer forward + backward (6 GEMMs + the elementwise pass) x cross_layers;
+      * `torch_cpu`: how Keras-on-CPU composes the reference -- embedding_bag (ops.take + sum) with sparse
+        gradients, matmul + bias + elementwise, autograd backward -- fp32, at all threads and at one thread.
+    3 warm-ups + 10 timed runs, medians (the one-thread leg: a quarter of the sample, 1 + 3 runs).  Neither leg
+    updates the tables (the reference's dense [V, D] gradient + dense optimizer pass over all 26 M rows per step
+    would come on top)."""
     from oracle import krs_oracle as ko
 
     b = a.cpu_sample_batch
-    vocab = min(a.vocab, 200_000)
+    vocab = a.vocab
     rng = np.random.default_rng(1337)
-    tables = [ko.f32_to_bf16_bits(rng.uniform(-0.05, 0.05, (vocab, a.dim)).astype(np.float32))
-              for _ in range(a.tables)]
-    ids = np.concatenate([rng.integers(0, vocab, b * h) for h in hots]).astype(np.int32)
+    one = ko.f32_to_bf16_bits(rng.uniform(-0.05, 0.05, (vocab, a.dim)).astype(np.float32))
+    tables = [one] + [one.copy() for _ in range(a.tables - 1)]        # distinct memory, same statistics
+    ids_list = [rng.integers(0, vocab, b * h).astype(np.int32) for h in hots]
+    ids = np.concatenate(ids_list)
     tabs = ko.make_tables(tables)
     feats = ko.make_features(list(range(a.tables)), ["sum"] * a.tables, [t * a.dim for t in range(a.tables)],
                              hots=hots, batch=b)
     out = np.zeros((b, a.tables * a.dim), np.uint16)
-    ko.embed_bag_fwd_raw(tabs, ko.BF16, feats, ids, None, None, b, a.dim, out)  # warm
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 3.0 or reps < 3:
-        ko.embed_bag_fwd_raw(tabs, ko.BF16, feats, ids, None, None, b, a.dim, out)
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    # the dense part of the step on the same sample: one low-rank FeatureCross layer fwd, scaled x3 layers x3 (fwd+bwd)
-    d = (a.tables + 1) * a.dim
-    x = ko.f32_to_bf16_bits(rng.uniform(-1, 1, (256, d)).astype(np.float32))
-    u = ko.f32_to_bf16_bits(rng.uniform(-0.03, 0.03, (d, a.projection)).astype(np.float32))
-    v = ko.f32_to_bf16_bits(rng.uniform(-0.03, 0.03, (a.projection, d)).astype(np.float32))
-    t1 = time.perf_counter()
-    h, _ = ko.gemm(x, u, 256, a.projection, d)
-    ko.gemm(h, v, 256, d, a.projection, x0=x, x=x)
-    t_cross = (time.perf_counter() - t1) * (b / 256) * a.cross_layers * 3
+    t_emb, _ = _median_time(lambda: ko.embed_bag_fwd_raw(tabs, ko.BF16, feats, ids, None, None, b, a.dim, out), 3, 10)
+    d, p = (a.tables + 1) * a.dim, a.projection
+    bits = lambda lo, hi, shape: ko.f32_to_bf16_bits(rng.uniform(lo, hi, shape).astype(np.float32))  # noqa: E731
+    x0, x, g = bits(-1, 1, (b, d)), bits(-1, 1, (b, d)), bits(-1, 1, (b, d))
+    u_, v_ = bits(-0.03, 0.03, (d, p)), bits(-0.03, 0.03, (p, d))
+
+    def cross_layer():
+        h, _ = ko.gemm(x, u_, b, p, d)
+        y, uo = ko.gemm(h, v_, b, d, p, x0=x0, x=x, want_u=True)
+        dz, dx0, _, _ = ko.cross_epilogue_bwd(g, uo, x0, x)
+        ko.gemm(h, dz, p, d, b, a_is_km=True, out_dtype=ko.F32)
+        dh, _ = ko.gemm(dz, v_, b, p, d, b_is_nk=True)
+        ko.gemm(x, dh, d, p, b, a_is_km=True, out_dtype=ko.F32)
+        ko.gemm(dh, u_, b, d, p, b_is_nk=True, r=g)
+
+    t_layer, _ = _median_time(cross_layer, 1, 3)
+    t_port = t_emb + t_layer * a.cross_layers
     lookups = b * sum(hots)
+
+    # ---- torch on the CPU: the composition Keras would run (fp32) ----
+    def torch_leg(threads, bb, warm, reps):
+        torch.set_num_threads(threads)
+        tt = [torch.from_numpy(ko.bf16_bits_to_f32(tables[0]))] + [None] * (a.tables - 1)
+        for t in range(1, a.tables):
+            tt[t] = tt[0].clone()
+        tt = [t.requires_grad_() for t in tt]
+        tid = [torch.from_numpy(ids_list[t][: bb * hots[t]].astype(np.int64)) for t in range(a.tables)]
+        offs = [torch.arange(0, bb * hots[t], hots[t]) for t in range(a.tables)]
+        dense = torch.rand(bb, a.dim)
+        U = [torch.randn(d, p).mul_(0.03).requires_grad_() for _ in range(a.cross_layers)]
+        V = [torch.randn(p, d).mul_(0.03).requires_grad_() for _ in range(a.cross_layers)]
+        bias = [torch.zeros(d, requires_grad=True) for _ in range(a.cross_layers)]
+        gy = torch.rand(bb, d)
+        emb_t = [0.0]
+
+        def step():
+            t0 = time.perf_counter()
+            embs = [torch.nn.functional.embedding_bag(tid[t], tt[t], offs[t], mode="sum", sparse=True)
+                    for t in range(a.tables)]
+            emb_t[0] = time.perf_counter() - t0
+            x0_ = torch.cat([dense] + embs, dim=1)
+            xl = x0_
+            for i in range(a.cross_layers):
+                xl = x0_ * ((xl @ U[i]) @ V[i] + bias[i]) + xl
+            xl.backward(gy)
+            for w in tt + U + V + bias:
+                w.grad = None
+
+        med, _ = _median_time(step, warm, reps)
+        embs = []
+        for _ in range(max(reps, 3)):
+            step()
+            embs.append(emb_t[0])
+        return {"threads": threads, "batch": bb, "ms_per_step": med * 1e3, "value": bb * sum(hots) / med,
+                "unit": "lookups/s", "embed_fwd_lookups_per_s": bb * sum(hots) / float(np.median(embs))}
+
+    n_thr = os.cpu_count() or 1
+    torch_all = torch_leg(n_thr, b, 3, 10)
+    torch_one = torch_leg(1, max(b // 4, 64), 1, 3)
+    torch.set_num_threads(n_thr)
     return {
-        "value": lookups / (dt + t_cross), "unit": "lookups/s", "cores": os.cpu_count(), "kind": "port",
-        "embed_fwd_lookups_per_s": lookups / dt,
-        "sample": f"oracle/krs_oracle.c (OpenMP, {os.cpu_count()} threads): batch {b} of the same 26-table "
-                  f"workload (vocab capped at {vocab}); embedding gather+pool timed {reps}x, FeatureCross "
-                  "GEMMs timed on 256 rows and scaled to the sample batch x layers x fwd+bwd",
+        "value": lookups / t_port, "unit": "lookups/s", "cores": n_thr, "kind": "port",
+        "embed_fwd_lookups_per_s": lookups / t_emb,
+        "ms_per_step_on_sample": t_port * 1e3,
+        "sample": f"batch {b} of the C3 workload ({a.tables} tables x {vocab} rows x {a.dim} bf16, sum L = "
+                  f"{sum(hots)}, {a.cross_layers} x FeatureCross(d={d}, p={p})): oracle/krs_oracle.c with OpenMP on "
+                  f"{n_thr} threads -- gather+pool (3 warm-ups + 10 runs, median) + one cross layer forward+backward "
+                  f"(1 + 3 runs, median) x {a.cross_layers}; no table update",
+        "torch_cpu": {"all_threads": torch_all, "one_thread": torch_one,
+                      "note": "fp32 embedding_bag (sparse gradients) + matmul / elementwise cross stack, autograd "
+                              "backward, no table update: the op composition Keras-on-CPU runs for this path"},
     }
 
 

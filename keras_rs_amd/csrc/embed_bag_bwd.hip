@@ -25,9 +25,8 @@
 #include <cstdlib>
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
-
 #include "krs_common.h"
+#include "krs_scan.h"
 
 namespace krs {
 namespace {
@@ -68,18 +67,235 @@ struct PlanLayout {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-size_t sort_temp_bytes(int64_t nnz) {
-  size_t bytes = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                           (uint64_t*)nullptr, (uint64_t*)nullptr, (size_t)nnz, 0u, 32u,
-                                           (hipStream_t)0);
-  size_t sbytes = 0;
-  hipError_t e2 = rocprim::exclusive_scan(nullptr, sbytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u,
-                                          (size_t)nnz, rocprim::plus<uint32_t>(), (hipStream_t)0);
-  if (e != hipSuccess || bytes == 0) bytes = (size_t)nnz * 16 + (1 << 20);  // no device visible: upper bound
-  if (e2 != hipSuccess || sbytes == 0) sbytes = (size_t)nnz * 4 + (1 << 20);
-  return align_up(bytes > sbytes ? bytes : sbytes, 256);
+// ---- plan: the sort (LSD radix sort of (row key, bag << 32 | position) pairs, written for this plan) -----------
+// Digits of up to 10 bits, ceil(bits / 10) passes over ceil(log2(total_rows + 1)) key bits (C3: 25 bits = 3 passes,
+// against 4 passes of 8 bits over the same bits in a general-purpose device sort).  One pass = per-tile digit
+// histogram -> exclusive scan of the [digit][tile] counts (krs_scan.h) -> stable scatter.  A tile is 4096 consecutive
+// lookups, one workgroup; wave w owns the w-th quarter, so the (wave, round, lane) order IS the input order and
+// the ranks below keep equal keys in input order (stability = ascending position inside a row's segment = a fixed
+// summation order in the apply kernels).  Dense bags: the first pass computes keys and values from the ids on the
+// fly (no key generation kernel, no round trip of 12 bytes per lookup through HBM).
+namespace rs {
+constexpr int kTile = 4096, kMaxBits = 10, kMaxBins = 1 << kMaxBits;
+constexpr int kHistThreads = 256, kHistItems = kTile / kHistThreads;
+constexpr int kThreads = 512, kWaves = kThreads / 64, kItems = kTile / kThreads;   // scatter: 8 waves x 512 lookups
+constexpr int kGenFeats = 256;   // features whose descriptors the generating pass caches in LDS
+
+struct Gen {   // key generation for dense bags (first pass)
+  const krs_table* tables;
+  const krs_feature* feats;
+  int n_feats;
+  const void* ids;
+  int id64;
+  int batch;
+  int* err_flag;
+};
+
+struct Pass {
+  const uint32_t* keys_in;     // null in a generating pass
+  const uint64_t* vals_in;
+  uint32_t* keys_out;
+  uint64_t* vals_out;
+  int32_t* counts;             // [bins][tiles]: histogram, then exclusive offsets
+  int64_t nnz;
+  int n_tiles;
+  int shift, bits;
+  Gen gen;
+};
+
+// per-feature constants of the generating pass, in LDS
+struct GenLds {
+  uint32_t base[kGenFeats + 1];   // first lookup position of the feature (nnz < 2^31)
+  uint32_t hot[kGenFeats];
+  uint32_t row_base[kGenFeats];   // total_rows < 2^32 (checked by the plan)
+  uint32_t vocab[kGenFeats];
+};
+__device__ __forceinline__ void load_gen(const Pass& p, GenLds& g, int n_threads) {
+  for (int i = threadIdx.x; i <= p.gen.n_feats; i += n_threads) {
+    if (i < p.gen.n_feats) {
+      const krs_feature ft = p.gen.feats[i];
+      const krs_table tb = p.gen.tables[ft.table];
+      g.base[i] = (uint32_t)ft.ids_base;
+      g.hot[i] = (uint32_t)ft.hot;
+      g.row_base[i] = (uint32_t)tb.row_base;
+      g.vocab[i] = (uint32_t)tb.vocab;
+    } else {
+      g.base[i] = (uint32_t)p.nnz;
+    }
+  }
 }
+// (key, value) of lookup position q; dense bags, features laid out one after the other
+__device__ __forceinline__ void generate(const Pass& p, const GenLds& g, uint32_t q, uint32_t& key, uint64_t& val,
+                                         bool& bad) {
+  int lo = 0, hi = p.gen.n_feats;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (g.base[mid] <= q) lo = mid; else hi = mid;
+  }
+  const uint32_t bag = (uint32_t)lo * (uint32_t)p.gen.batch + (q - g.base[lo]) / g.hot[lo];
+  const int64_t id = ld_index(p.gen.ids, p.gen.id64, q);
+  key = kInvalidKey;
+  if (id >= 0 && id < (int64_t)g.vocab[lo]) key = g.row_base[lo] + (uint32_t)id;
+  else bad = true;
+  val = ((uint64_t)bag << 32) | (uint64_t)q;
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(kHistThreads) void hist_kernel(const Pass p) {
+  __shared__ int h[kMaxBins];
+  __shared__ GenLds g;
+  const int bins = 1 << p.bits;
+  for (int i = threadIdx.x; i < bins; i += kHistThreads) h[i] = 0;
+  if constexpr (GEN) load_gen(p, g, kHistThreads);
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  bool bad = false;
+  for (int it = 0; it < kHistItems; ++it) {
+    const int64_t q = base + it * kHistThreads + threadIdx.x;
+    if (q < p.nnz) {
+      uint32_t key;
+      if constexpr (GEN) {
+        uint64_t v;
+        generate(p, g, (uint32_t)q, key, v, bad);
+      } else {
+        key = p.keys_in[q];
+      }
+      atomicAdd(&h[(key >> p.shift) & (bins - 1)], 1);
+    }
+  }
+  if constexpr (GEN)
+    if (bad && p.gen.err_flag) atomicOr(p.gen.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
+  __syncthreads();
+  for (int i = threadIdx.x; i < bins; i += kHistThreads) p.counts[(int64_t)i * p.n_tiles + blockIdx.x] = h[i];
+}
+
+template <bool GEN>
+__global__ __launch_bounds__(kThreads) void scatter_kernel(const Pass p) {
+  // 74 KB of LDS: two workgroups (16 waves) per CU
+  __shared__ uint16_t cnt[kWaves][kMaxBins];   // per wave: elements of each digit seen so far -> (wave, digit) start
+  __shared__ uint16_t tile_excl[kMaxBins];     // first slot of every digit in the tile's sorted image
+  __shared__ int gbase[kMaxBins];              // first output slot of the tile's elements of every digit
+  __shared__ uint32_t skey[kTile];             // the tile, sorted by digit (stable): consecutive threads then
+  __shared__ uint64_t sval[kTile];             // write consecutive output slots inside a digit's run
+  __shared__ int wtot[kWaves];
+  __shared__ GenLds g;
+  const int bins = 1 << p.bits;
+  for (int i = threadIdx.x; i < kWaves * kMaxBins; i += kThreads) (&cnt[0][0])[i] = 0;
+  if constexpr (GEN) load_gen(p, g, kThreads);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile0 = (int64_t)blockIdx.x * kTile;
+  const int64_t base = tile0 + (int64_t)wave * (kTile / kWaves);
+  uint32_t key[kItems];
+  uint64_t val[kItems];
+  int rank[kItems];
+  bool bad = false;
+  volatile uint16_t* mine = cnt[wave];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int64_t q = base + it * 64 + lane;
+    const bool live = q < p.nnz;
+    key[it] = kInvalidKey;
+    val[it] = 0;
+    if (live) {
+      if constexpr (GEN) {
+        generate(p, g, (uint32_t)q, key[it], val[it], bad);
+      } else {
+        key[it] = p.keys_in[q];
+        val[it] = p.vals_in[q];
+      }
+    }
+    const int d = (int)((key[it] >> p.shift) & (bins - 1));
+    // lanes of this round with the same digit
+    unsigned long long peers = __ballot(live);
+    for (int b = 0; b < p.bits; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1);
+      peers &= ((d >> b) & 1) ? m : ~m;
+    }
+    int r = 0, c = 0;
+    if (live) {
+      r = __popcll(peers & ((1ULL << lane) - 1ULL));
+      const int leader = __ffsll((long long)peers) - 1;
+      if (lane == leader) {
+        c = mine[d];
+        mine[d] = (uint16_t)(c + __popcll(peers));
+      }
+      c = __shfl(c, leader, 64);
+    }
+    rank[it] = c + r;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // digit totals of the tile -> exclusive scan over the digits (bins <= 1024 = 2 per thread)
+  int tot[2], run = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = threadIdx.x * 2 + k;
+    tot[k] = 0;
+    if (i < bins)
+      for (int w = 0; w < kWaves; ++w) tot[k] += cnt[w][i];
+    run += tot[k];
+  }
+  int x = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wtot[wave] = x;
+  __syncthreads();
+  int excl = x - run;
+  for (int w = 0; w < wave; ++w) excl += wtot[w];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = threadIdx.x * 2 + k;
+    if (i < bins) {
+      tile_excl[i] = (uint16_t)excl;
+      gbase[i] = p.counts[(int64_t)i * p.n_tiles + blockIdx.x];
+      int o = excl;
+      for (int w = 0; w < kWaves; ++w) {
+        const int t = cnt[w][i];
+        cnt[w][i] = (uint16_t)o;
+        o += t;
+      }
+      excl += tot[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int64_t q = base + it * 64 + lane;
+    if (q < p.nnz) {
+      const int d = (int)((key[it] >> p.shift) & (bins - 1));
+      const int lp = cnt[wave][d] + rank[it];
+      skey[lp] = key[it];
+      sval[lp] = val[it];
+    }
+  }
+  __syncthreads();
+  const int n_here = (int)min<int64_t>(kTile, p.nnz - tile0);
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int i = it * kThreads + threadIdx.x;
+    if (i < n_here) {
+      const uint32_t k = skey[i];
+      const int d = (int)((k >> p.shift) & (bins - 1));
+      const int pos = gbase[d] + (i - (int)tile_excl[d]);
+      p.keys_out[pos] = k;
+      p.vals_out[pos] = sval[i];
+    }
+  }
+  (void)bad;   // the histogram pass of the same data reports out-of-range ids
+}
+
+inline int n_passes(unsigned bits) { return (int)((bits + kMaxBits - 1) / kMaxBits); }
+inline size_t temp_bytes(int64_t nnz) {
+  const int64_t tiles = ceil_div(nnz > 0 ? nnz : 1, kTile);
+  const size_t counts = (size_t)kMaxBins * tiles * sizeof(int32_t);
+  return align_up(counts, 256) + align_up(scan::workspace_bytes((int64_t)kMaxBins * tiles), 256) +
+         align_up(scan::workspace_bytes(nnz), 256);
+}
+}  // namespace rs
 
 PlanLayout plan_layout(void* ws, int64_t nnz, bool need_temp = false) {
   PlanLayout l;
@@ -100,7 +316,7 @@ PlanLayout plan_layout(void* ws, int64_t nnz, bool need_temp = false) {
   l.head_index = reinterpret_cast<uint32_t*>(l.vals_in);
   l.seg_start = reinterpret_cast<uint32_t*>(l.vals_in) + n;
   l.temp = p + o;
-  l.temp_bytes = need_temp ? sort_temp_bytes(nnz) : 0;
+  l.temp_bytes = need_temp ? rs::temp_bytes(nnz) : 0;
   l.total_bytes = o + l.temp_bytes;
   return l;
 }
@@ -802,8 +1018,8 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
   KRS_REQUIRE(tables && feats && (ids || nnz == 0), "embed_bag_bwd_plan: null argument");
   KRS_REQUIRE(n_feats > 0 && batch > 0 && nnz >= 0, "embed_bag_bwd_plan: bad sizes");
   KRS_REQUIRE(total_rows > 0 && total_rows < 0xffffffffLL, "embed_bag_bwd_plan: total_rows must fit 32-bit keys");
-  KRS_REQUIRE(nnz < 0xffffffffLL && (int64_t)n_feats * batch < 0xffffffffLL,
-              "embed_bag_bwd_plan: nnz / bag count must fit 32 bits");
+  KRS_REQUIRE(nnz < 0x7fffffffLL && (int64_t)n_feats * batch < 0xffffffffLL,
+              "embed_bag_bwd_plan: nnz must stay below 2^31 and the bag count below 2^32");
   if (nnz == 0) return KRS_OK;
   KRS_REQUIRE(workspace, "embed_bag_bwd_plan: null workspace");
   const PlanLayout l = plan_layout(workspace, nnz, true);
@@ -814,24 +1030,60 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
   kp.tables = tables; kp.feats = feats; kp.n_feats = n_feats; kp.ids = ids; kp.id64 = id_type == KRS_I64;
   kp.offsets = offsets; kp.off64 = off_type == KRS_I64; kp.batch = batch; kp.keys = l.keys_in; kp.vals = l.vals_in;
   kp.err_flag = err_flag;
-  // dense mode never leaves holes; CSR mode covers [offsets[0], offsets[last]) = [0, nnz)
-  const int64_t n_bags = (int64_t)n_feats * batch;
-  hipLaunchKernelGGL(bag_keys_kernel, dim3((unsigned)ceil_div(n_bags, 16)), dim3(256), 0, st, kp);
-  KRS_CHECK_LAUNCH("bag_keys_kernel");
-  // Sort only the significant key bits.  2^bits - 1 > every valid row id, so the
-  // invalid key (all ones) still sorts last.
+  // Sort only the significant key bits.  2^bits - 1 > every valid row id, so the invalid key (all ones) still
+  // sorts last.
   unsigned bits = 1;
   while (bits < 32 && (1ULL << bits) <= (uint64_t)total_rows) ++bits;
-  size_t temp = l.temp_bytes;
-  KRS_HIP(rocprim::radix_sort_pairs(l.temp, temp, l.keys_in, l.keys_sorted, l.vals_in, l.vals_sorted, (size_t)nnz,
-                                    0u, bits, st));
+  const int passes = rs::n_passes(bits);
+  const int n_tiles = (int)ceil_div(nnz, rs::kTile);
+  char* tp = reinterpret_cast<char*>(l.temp);
+  int32_t* counts = reinterpret_cast<int32_t*>(tp);
+  tp += align_up((size_t)rs::kMaxBins * n_tiles * sizeof(int32_t), 256);
+  int32_t* sums = reinterpret_cast<int32_t*>(tp);
+  tp += align_up(scan::workspace_bytes((int64_t)rs::kMaxBins * n_tiles), 256);
+  int32_t* sums2 = reinterpret_cast<int32_t*>(tp);
+  // ping-pong between (keys_in, vals_in) and (keys_sorted, vals_sorted); the LAST pass must write the sorted pair
+  // dense bags: keys are generated inside the first pass (feature constants cached in LDS)
+  const bool gen = offsets == nullptr && n_feats <= rs::kGenFeats;
+  bool to_sorted = (passes % 2) == 1;    // where the first pass writes
+  if (!gen) {
+    // CSR bags (or very many features): the key kernel walks the bags
+    kp.keys = to_sorted ? l.keys_in : l.keys_sorted;
+    kp.vals = to_sorted ? l.vals_in : l.vals_sorted;
+    const int64_t n_bags = (int64_t)n_feats * batch;
+    hipLaunchKernelGGL(bag_keys_kernel, dim3((unsigned)ceil_div(n_bags, 16)), dim3(256), 0, st, kp);
+    KRS_CHECK_LAUNCH("bag_keys_kernel");
+  }
+  unsigned done = 0;
+  for (int ps = 0; ps < passes; ++ps) {
+    rs::Pass p;
+    p.bits = (int)((bits - done + (passes - ps) - 1) / (passes - ps));
+    p.shift = (int)done;
+    p.nnz = nnz;
+    p.n_tiles = n_tiles;
+    p.counts = counts;
+    const bool generating = gen && ps == 0;
+    p.keys_in = generating ? nullptr : (to_sorted ? l.keys_in : l.keys_sorted);
+    p.vals_in = generating ? nullptr : (to_sorted ? l.vals_in : l.vals_sorted);
+    p.keys_out = to_sorted ? l.keys_sorted : l.keys_in;
+    p.vals_out = to_sorted ? l.vals_sorted : l.vals_in;
+    p.gen.tables = tables; p.gen.feats = feats; p.gen.n_feats = n_feats; p.gen.ids = ids;
+    p.gen.id64 = id_type == KRS_I64; p.gen.batch = batch; p.gen.err_flag = err_flag;
+    if (generating) hipLaunchKernelGGL(rs::hist_kernel<true>, dim3(n_tiles), dim3(rs::kHistThreads), 0, st, p);
+    else hipLaunchKernelGGL(rs::hist_kernel<false>, dim3(n_tiles), dim3(rs::kHistThreads), 0, st, p);
+    scan::exclusive(counts, counts, (int64_t)(1 << p.bits) * n_tiles, sums, nullptr, st);
+    if (generating) hipLaunchKernelGGL(rs::scatter_kernel<true>, dim3(n_tiles), dim3(rs::kThreads), 0, st, p);
+    else hipLaunchKernelGGL(rs::scatter_kernel<false>, dim3(n_tiles), dim3(rs::kThreads), 0, st, p);
+    done += (unsigned)p.bits;
+    to_sorted = !to_sorted;
+  }
+  KRS_CHECK_LAUNCH("embed_bag_bwd_plan: radix sort");
   // segment list: head flags -> exclusive scan -> scatter of the head positions
   const unsigned nb = (unsigned)ceil_div(nnz, 256);
   hipLaunchKernelGGL(head_flags_kernel, dim3(nb), dim3(256), 0, st, l.keys_sorted, nnz, l.head_flag);
   KRS_CHECK_LAUNCH("head_flags_kernel");
-  temp = l.temp_bytes;
-  KRS_HIP(rocprim::exclusive_scan(l.temp, temp, l.head_flag, l.head_index, 0u, (size_t)nnz,
-                                  rocprim::plus<uint32_t>(), st));
+  scan::exclusive(reinterpret_cast<const int32_t*>(l.head_flag), reinterpret_cast<int32_t*>(l.head_index), nnz, sums2,
+                  nullptr, st);
   hipLaunchKernelGGL(seg_scatter_kernel, dim3(nb), dim3(256), 0, st, l.head_flag, l.head_index, nnz, l.seg_start,
                      l.n_seg);
   KRS_CHECK_LAUNCH("seg_scatter_kernel");

@@ -24,6 +24,7 @@
 //                      (the host polls the flag: one wait per lookup, no stream synchronisation)
 // All integer outputs are bit-exact against oracle/krs_oracle.c (krs_oracle_shard_*).
 #include "krs_common.h"
+#include "krs_scan.h"
 
 namespace krs {
 namespace {
@@ -44,6 +45,7 @@ struct RouteWs {
   float* w_b;            // [nnz]
   int32_t* blk_heads;    // [n_blocks] segment heads per block, then exclusive offsets
   int32_t* seg_first;    // [nnz + 1]  first bucket-order position of every segment
+  int32_t* scan_sums;    // workspace of the histogram scan
   int64_t* meta;         // [64]: start[0..N] (N+1 entries: bucket starts, start[N] = valid lookups), 17: n_seg,
                          //       18..18+N: seg_start[d], 36..36+N: packed base of owner d
 };
@@ -160,34 +162,6 @@ __global__ __launch_bounds__(256) void route_classify_kernel(const RouteParams p
   if (__ballot(bad) && lane == 0 && p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
   __syncthreads();
   if ((int)threadIdx.x <= p.n_shards) p.ws.blk_cnt[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
-}
-
-// in-place exclusive scan of an int32 array by ONE workgroup (n up to a few hundred thousand); total -> *total
-__global__ __launch_bounds__(1024) void scan_block_kernel(int32_t* a, int64_t n, int64_t* total) {
-  __shared__ long long wsum[16];
-  __shared__ long long carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t base = 0; base < n; base += 1024) {
-    const int64_t i = base + threadIdx.x;
-    const int v = i < n ? a[i] : 0;
-    long long x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const long long y = __shfl_up(x, o, 64);
-      if (lane >= o) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    long long off = carry;
-    for (int w = 0; w < wave; ++w) off += wsum[w];
-    if (i < n) a[i] = (int32_t)(off + x - v);
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = off + x;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && total) *total = carry;
 }
 
 // bucket starts from the scanned [bucket][block] offsets
@@ -386,45 +360,6 @@ __global__ __launch_bounds__(256) void unpack_kernel(const UnpackParams p) {
   if (i == n_seg) p.offsets[n_seg] = 0;
 }
 
-// exclusive scan over many blocks: per-block sums -> scan_block_kernel -> per-block scan with its base
-__global__ __launch_bounds__(256) void scan_sums_kernel(const int32_t* a, int64_t n, int32_t* sums) {
-  __shared__ int total;
-  if (threadIdx.x == 0) total = 0;
-  __syncthreads();
-  const int64_t i0 = (int64_t)blockIdx.x * kRB + threadIdx.x * 4;
-  int c = 0;
-  for (int k = 0; k < 4; ++k)
-    if (i0 + k < n) c += a[i0 + k];
-  for (int o = 32; o; o >>= 1) c += __shfl_down(c, o, 64);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
-  __syncthreads();
-  if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-__global__ __launch_bounds__(256) void scan_apply_kernel(int32_t* a, int64_t n, const int32_t* sums) {
-  __shared__ int wsum[4];
-  const int64_t i0 = (int64_t)blockIdx.x * kRB + threadIdx.x * 4;
-  int v[4], c = 0;
-  for (int k = 0; k < 4; ++k) {
-    v[k] = i0 + k < n ? a[i0 + k] : 0;
-    c += v[k];
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int x = c;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(x, o, 64);
-    if (lane >= o) x += y;
-  }
-  if (lane == 63) wsum[wave] = x;
-  __syncthreads();
-  int s = sums[blockIdx.x] + x - c;
-  for (int w = 0; w < wave; ++w) s += wsum[w];
-  for (int k = 0; k < 4; ++k) {
-    if (i0 + k < n) a[i0 + k] = s;
-    s += v[k];
-  }
-}
-
 // ---- home side -------------------------------------------------------------------------------------
 // out[b, f*dim ..] = sum_d partials[bag_seg[(f*batch + b)*N + d]]; one thread per VEC columns of one bag
 template <typename T, int VEC>
@@ -510,6 +445,7 @@ RouteWs carve(void* workspace, int64_t nnz, int64_t n_bags, int n_shards, int n_
   w.w_b = reinterpret_cast<float*>(take((size_t)nnz * 4));
   w.blk_heads = reinterpret_cast<int32_t*>(take((size_t)n_blocks * 4));
   w.seg_first = reinterpret_cast<int32_t*>(take((size_t)(nnz + 1) * 4));
+  w.scan_sums = reinterpret_cast<int32_t*>(take(scan::workspace_bytes((int64_t)(n_shards + 1) * n_blocks)));
   *bytes = off;
   return w;
 }
@@ -567,12 +503,11 @@ extern "C" int krs_shard_route(const krs_shard_feature* feats, const krs_shard_f
   if (offsets) hipLaunchKernelGGL(route_expand_kernel, dim3(bag_blocks), dim3(256), 0, st, p);
   if (p.any_scale) hipLaunchKernelGGL(route_scale_kernel, dim3(bag_blocks), dim3(256), 0, st, p);
   hipLaunchKernelGGL(route_classify_kernel, dim3(p.n_blocks), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(1024), 0, st, p.ws.blk_cnt, (int64_t)(n_shards + 1) * p.n_blocks,
-                     (int64_t*)nullptr);
+  scan::exclusive(p.ws.blk_cnt, p.ws.blk_cnt, (int64_t)(n_shards + 1) * p.n_blocks, p.ws.scan_sums, nullptr, st);
   hipLaunchKernelGGL(route_starts_kernel, dim3(1), dim3(64), 0, st, p);
   hipLaunchKernelGGL(route_scatter_kernel, dim3(p.n_blocks), dim3(256), 0, st, p);
   hipLaunchKernelGGL(route_heads_kernel, dim3(p.n_blocks), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(1024), 0, st, p.ws.blk_heads, (int64_t)p.n_blocks,
+  hipLaunchKernelGGL(scan::block_kernel, dim3(1), dim3(1024), 0, st, p.ws.blk_heads, (int64_t)p.n_blocks,
                      p.ws.meta + kMetaNseg);
   hipLaunchKernelGGL(route_segments_kernel, dim3(p.n_blocks), dim3(256), 0, st, p);
   hipLaunchKernelGGL(route_finalize_kernel, dim3(1), dim3(64), 0, st, p);
@@ -582,7 +517,7 @@ extern "C" int krs_shard_route(const krs_shard_feature* feats, const krs_shard_f
 }
 
 extern "C" size_t krs_shard_unpack_workspace_bytes(int64_t total_segments) {
-  return (size_t)(ceil_div(total_segments > 0 ? total_segments : 1, kRB) + 1) * sizeof(int32_t) + 256;
+  return scan::workspace_bytes(total_segments + 1);
 }
 
 extern "C" int krs_shard_unpack(const int32_t* packed, int n_sources, const int64_t* lookups, const int64_t* segments,
@@ -608,12 +543,7 @@ extern "C" int krs_shard_unpack(const int32_t* packed, int n_sources, const int6
   const int64_t span = std::max<int64_t>(std::max(n_cnt, n_seg + 1), 1);
   hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)ceil_div(span, 256)), dim3(256), 0, st, p);
   // lengths -> exclusive offsets (offsets[n_seg] = total)
-  int32_t* sums = reinterpret_cast<int32_t*>(workspace);
-  const int64_t n = n_seg + 1;
-  const int blocks = (int)ceil_div(n, kRB);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(blocks), dim3(256), 0, st, offsets, n, sums);
-  hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(1024), 0, st, sums, (int64_t)blocks, (int64_t*)nullptr);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(blocks), dim3(256), 0, st, offsets, n, sums);
+  scan::exclusive(offsets, offsets, n_seg + 1, reinterpret_cast<int32_t*>(workspace), nullptr, st);
   KRS_CHECK_LAUNCH("krs_shard_unpack");
   return KRS_OK;
 }
