@@ -268,6 +268,13 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
 enum { KRS_GEMM_OPT_PIPELINE = 0 };
 int krs_gemm_set_option(int key, int value);
 
+/* Tuning switch of krs_embed_bag_fwd (process-wide; results never depend on it).
+ *   KRS_EMBED_OPT_HOT1: the pure row gather of one-hot bags -- bit 0: 16 instead of 8 row loads in
+ *   flight per lane; bit 1: walk the lookups sample-major, so that a wave's stores cover contiguous
+ *   bytes of the output slab (default 3, or the environment variable KRS_EMBED_HOT1 at first use). */
+enum { KRS_EMBED_OPT_HOT1 = 0 };
+int krs_embed_set_option(int key, int value);
+
 /* Elementwise halves of FeatureCross for the host-composed path (arbitrary
  * pre_activation callables) and for the backward:
  *   fwd: y = x0 * (u + diag_scale*x) + x                     feature_cross.py:191-194

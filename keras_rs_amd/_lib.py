@@ -69,6 +69,7 @@ SYMBOLS = [
     "krs_gemm",
     "krs_gemm_workspace_bytes",
     "krs_gemm_set_option",
+    "krs_embed_set_option",
     "krs_cross_epilogue_fwd",
     "krs_cross_epilogue_bwd",
     "krs_colsum",

@@ -18,8 +18,9 @@
 //   * ids / offsets are read by all lanes of a group from one address
 //     (a single broadcast transaction per group), sequentially along the bag.
 // Algorithmic bytes per lookup: D*s_t + 4 (+4 with weights); per bag D*s_o + 4.
-#include "krs_common.h"
+#include <cstdlib>
 
+#include "krs_common.h"
 
 namespace krs {
 namespace {
@@ -297,12 +298,12 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p)
 // 16-byte pieces when TT == OT.  A wave takes 64 consecutive bags of one feature: one coalesced
 // id load per lane, ids broadcast with ds_bpermute (__shfl), 8 non-temporal row loads in flight
 // per lane, non-temporal stores.  Features whose `hot` is not 1 take the slow loop at the end.
-template <typename TT, typename OT, int LPR>
+template <typename TT, typename OT, int LPR, int UREQ>
 __global__ __launch_bounds__(256) void embed_gather_hot1(const EmbedFwdParams p) {
   constexpr int G = 64 / LPR;
   constexpr int N = Vec16<TT>::N;
   constexpr int STEPS = 64 / G;  // = LPR
-  constexpr int U = 8;
+  constexpr int U = UREQ < STEPS ? UREQ : STEPS;
   typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR;
@@ -391,6 +392,79 @@ __global__ __launch_bounds__(256) void embed_gather_hot1(const EmbedFwdParams p)
   }
 }
 
+// The same pure row gather walked SAMPLE-major: unit u = sample * n_feats + feature, a wave takes 64 consecutive
+// units, so its stores cover 64 x row_bytes CONTIGUOUS bytes of the output slab whenever the features' column
+// slots are adjacent (a sample's 26 outputs are 6.6 KB of one slab row; consecutive samples follow) instead of
+// 64 pieces one slab row apart.  Reads are random either way.  Per-feature constants sit in LDS; a lane fetches
+// the id of its own unit (the ids of one feature are consecutive in memory, so the 64 strided 4-byte reads hit
+// lines that the neighbouring waves use too) and the groups take (id, feature, sample) by ds_bpermute.
+constexpr int kRowsMaxFeats = 128;
+template <typename TT, int LPR, int UREQ>
+__global__ __launch_bounds__(256) void embed_gather_hot1_rows(const EmbedFwdParams p) {
+  constexpr int G = 64 / LPR;
+  constexpr int N = Vec16<TT>::N;
+  constexpr int STEPS = 64 / G;
+  constexpr int U = UREQ < STEPS ? UREQ : STEPS;
+  typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
+  __shared__ const char* s_table[kRowsMaxFeats];
+  __shared__ int64_t s_ids_base[kRowsMaxFeats];
+  __shared__ int s_vocab[kRowsMaxFeats], s_out_col[kRowsMaxFeats];
+  for (int i = threadIdx.x; i < p.n_feats; i += 256) {
+    const krs_feature ft = p.feats[i];
+    const krs_table tb = p.tables[ft.table];
+    s_table[i] = reinterpret_cast<const char*>(tb.weights);
+    s_ids_base[i] = ft.ids_base;
+    s_vocab[i] = tb.vocab;
+    s_out_col[i] = ft.out_col;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR, sub = lane % LPR;
+  const int64_t units = (int64_t)p.batch * p.n_feats;
+  const int64_t u0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (u0 >= units) return;
+  const int64_t row_bytes = (int64_t)p.dim * sizeof(TT);
+  const bool col_live = sub < (int)(row_bytes >> 4);
+  // this lane's own unit: feature, sample, validated id
+  const int64_t mu = min(u0 + lane, units - 1);
+  const int mb = (int)(mu / p.n_feats), mf = (int)(mu - (int64_t)mb * p.n_feats);
+  const int64_t q = s_ids_base[mf] + mb;
+  const int64_t rawid = p.id64 ? reinterpret_cast<const int64_t*>(p.ids)[q] : (int64_t)reinterpret_cast<const int32_t*>(p.ids)[q];
+  const int myid = (rawid >= 0 && rawid < s_vocab[mf]) ? (int)rawid : -1;
+  const bool mine = u0 + lane < units;
+  if (mine && myid < 0 && p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
+  if (p.bag_scale && mine) p.bag_scale[(int64_t)mf * p.batch + mb] = 1.0f;
+  TT* out = reinterpret_cast<TT*>(p.out) + sub * N;
+#pragma unroll 1
+  for (int s0 = 0; s0 < STEPS; s0 += U) {
+    int id[U], f[U], b[U];
+    u32x4 raw[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int src_lane = (s0 + k) * G + g;
+      id[k] = __shfl(myid, src_lane, 64);
+      f[k] = __shfl(mf, src_lane, 64);
+      b[k] = __shfl(mb, src_lane, 64);
+      gvec_ptr src = (gvec_ptr)(s_table[f[k]] + (int64_t)(id[k] < 0 ? 0 : id[k]) * row_bytes + (col_live ? sub : 0) * 16);
+      raw[k] = __builtin_nontemporal_load(src);
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (u0 + (s0 + k) * G + g < units && col_live) {
+        if (id[k] < 0) raw[k] = u32x4{0, 0, 0, 0};
+        TT* dst = out + (int64_t)b[k] * p.out_ld + s_out_col[f[k]];
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+          __builtin_nontemporal_store(raw[k], reinterpret_cast<u32x4*>(dst));
+        } else {   // a column slot that is not 16-byte aligned: element stores
+          const TT* e = reinterpret_cast<const TT*>(&raw[k]);
+#pragma unroll
+          for (int i = 0; i < N; ++i) dst[i] = e[i];
+        }
+      }
+    }
+  }
+}
+
 // Any dim / any alignment / any dtype pair: one LPR-lane group per bag, one
 // column per lane per pass.  Used when dim*sizeof(T) is not a multiple of 16 B
 // (the reference's toy shapes: D = 6, 7, 11, 20).
@@ -440,13 +514,38 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_generic(const EmbedFwdParam
   if (oob && p.err_flag && sub == 0) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
 }
 
+// One-hot gather variant (krs_embed_set_option(KRS_EMBED_OPT_HOT1, v) / environment KRS_EMBED_HOT1, read once):
+// bit 0: 16 instead of 8 row loads in flight per lane; bit 1: sample-major walk (embed_gather_hot1_rows).
+int g_hot1 = -1;
+int hot1_variant() {
+  if (g_hot1 < 0) {
+    const char* e = getenv("KRS_EMBED_HOT1");
+    g_hot1 = e ? (atoi(e) & 3) : 3;   // measured at C3: 172.7 / 170.1 / 164.8 / 159.3 us for variants 0..3
+  }
+  return g_hot1;
+}
+
 template <typename TT, typename OT, int LPR>
 int launch_vec(const EmbedFwdParams& p, bool one_hot, bool stream, hipStream_t st) {
   constexpr int G = 64 / LPR;
   if (one_hot) {
+    const int v = hot1_variant();
+    if constexpr (sizeof(TT) == sizeof(OT)) {
+      bool rows_ok = (v & 2) && p.n_feats <= kRowsMaxFeats &&
+                     ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)(p.out_ld * sizeof(OT))) & 15) == 0;
+      if (rows_ok) {
+        const int64_t blocks = ceil_div(ceil_div((int64_t)p.batch * p.n_feats, 64), 4);
+        if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_fwd: grid too large");
+        if (v & 1) hipLaunchKernelGGL((embed_gather_hot1_rows<TT, LPR, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((embed_gather_hot1_rows<TT, LPR, 8>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        KRS_CHECK_LAUNCH("embed_gather_hot1_rows");
+        return KRS_OK;
+      }
+    }
     const int64_t blocks = ceil_div(ceil_div(p.batch, 64) * p.n_feats, 4);
     if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_fwd: grid too large");
-    hipLaunchKernelGGL((embed_gather_hot1<TT, OT, LPR>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    if (v & 1) hipLaunchKernelGGL((embed_gather_hot1<TT, OT, LPR, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((embed_gather_hot1<TT, OT, LPR, 8>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     KRS_CHECK_LAUNCH("embed_gather_hot1");
     return KRS_OK;
   }
@@ -473,6 +572,15 @@ int dispatch_lpr(const EmbedFwdParams& p, int row_pieces, bool one_hot, bool str
 
 }  // namespace
 }  // namespace krs
+
+extern "C" int krs_embed_set_option(int key, int value) {
+  if (key == KRS_EMBED_OPT_HOT1) {
+    KRS_REQUIRE(value >= 0 && value <= 3, "krs_embed_set_option: one-hot gather variant must be 0..3");
+    krs::g_hot1 = value;
+    return KRS_OK;
+  }
+  return krs::fail(KRS_ERR_INVALID, "krs_embed_set_option: unknown key %d", key);
+}
 
 extern "C" int krs_embed_bag_fwd(const krs_table* tables, const krs_feature* feats, int n_feats,
                                  const void* ids, int id_type, const void* offsets, int off_type,
