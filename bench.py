@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the MOD-sharded embedding path even at N = 1 (dry run of the multi-GPU code)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2048)
+    ap.add_argument("--rowwise-adagrad", action="store_true",
+                    help="table optimizer = layers.RowwiseAdagrad (opt-in variant with one accumulator per row; the "
+                         "default line uses the reference's exact Adagrad)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo stages through the host and lets "
                          "several ranks share one GPU: a functional rig, not a measurement)")
@@ -121,6 +124,8 @@ class Model(torch.nn.Module):
         self.a, self.hots = a, hots
         self.concat = kl.concat_features
         opt = kl.Adagrad(learning_rate=0.0034, initial_accumulator_value=0.1)  # configs/v6e_8.py lr
+        if a.rowwise_adagrad:   # opt-in variant, NOT the reference's optimizer (one accumulator per row)
+            opt = kl.RowwiseAdagrad(learning_rate=0.0034, initial_accumulator_value=0.1)
         feats = {}
         for t in range(a.tables):
             # the 40 M-row tables of C5 are drawn on the device, they never exist in host memory

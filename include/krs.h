@@ -175,6 +175,17 @@ int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_tables,
                                     int batch, int dim, int table_dtype, int64_t nnz,
                                     const void* workspace, void* stream);
 
+/* Row-wise Adagrad on the touched rows -- an OPT-IN variant, not the reference's rule (the FBGEMM / TorchRec
+ * "rowwise_adagrad" form, no epsilon): acc[row] += mean_j g[row, j]^2;  w[row, j] -= lr * g[row, j] / sqrt(acc[row]).
+ * tables[t].slot = fp32 [vocab]: ONE accumulator per row (the exact form keeps [vocab, dim], which is two
+ * thirds of K2's HBM traffic at C3: 2 x dim x 4 bytes per touched row against 8 here). */
+int krs_embed_bag_bwd_fused_adagrad_rowwise(const krs_table* tables, int n_tables,
+                                            const krs_feature* feats, int n_feats,
+                                            const float* weights, const float* bag_scale,
+                                            const void* grad, int grad_dtype, int64_t grad_ld,
+                                            int batch, int dim, int table_dtype, int64_t nnz,
+                                            const void* workspace, void* stream);
+
 /* Fused Adam on the touched rows ("lazy": a row that is not looked up keeps its moments and its
  * value).  The reference names keras.optimizers.Adam for 'sparsecore' tables and hands
  * (learning_rate, beta_1, beta_2, epsilon) to the SparseCore library

@@ -63,6 +63,7 @@ SYMBOLS = [
     "krs_embed_bag_bwd_dense",
     "krs_embed_bag_bwd_fused_sgd",
     "krs_embed_bag_bwd_fused_adagrad",
+    "krs_embed_bag_bwd_fused_adagrad_rowwise",
     "krs_embed_bag_bwd_fused_adam",
     "krs_embed_bag_bwd_fused_ftrl",
     "krs_embed_bag_bwd_sparse",

@@ -368,9 +368,21 @@ __global__ __launch_bounds__(256) void bag_keys_kernel(const KeyParams p) {
 }
 
 // ---- apply ------------------------------------------------------------------
-enum ApplyMode { kDense = 0, kSgd = 1, kAdagrad = 2, kSparse = 3, kAdam = 4, kFtrl = 5 };
-constexpr bool mode_is_fused(int m) { return m == kSgd || m == kAdagrad || m == kAdam || m == kFtrl; }
+enum ApplyMode { kDense = 0, kSgd = 1, kAdagrad = 2, kSparse = 3, kAdam = 4, kFtrl = 5, kAdagradRow = 6 };
+constexpr bool mode_is_fused(int m) { return m == kSgd || m == kAdagrad || m == kAdam || m == kFtrl || m == kAdagradRow; }
+// full-size fp32 slot planes [V, D] of a mode (row-wise Adagrad keeps ONE fp32 per row instead: slot = [V])
 constexpr int mode_slots(int m) { return m == kAdagrad ? 1 : ((m == kAdam || m == kFtrl) ? 2 : 0); }
+
+// Row-wise Adagrad (opt-in, NOT the reference's rule: the FBGEMM / TorchRec "rowwise_adagrad" form without
+// epsilon): acc[row] += mean_j g_j^2;  w_j -= lr * g_j / sqrt(acc[row]).  The exact form moves 2 x D x 4
+// accumulator bytes per touched row (two thirds of K2's traffic at C3), this one 8.  `ss` = this lane's share of
+// sum_j g_j^2; the group's lanes (LPR, a power of two, all active) add theirs by butterfly shuffles.
+template <int LPR>
+__device__ __forceinline__ float row_sumsq(float ss) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  return ss;
+}
 
 // optimizer constants shared by every table of a call (the learning rate is per table)
 struct Hyper {
@@ -599,7 +611,8 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
 #pragma unroll
   for (int k = 0; k < N; ++k) { wv[k] = 0.0f; av[k] = 0.0f; bv[k] = 0.0f; }
   // dim % N == 0, so a 16-byte aligned buffer keeps every lane's piece naturally aligned
-  const bool t_al = ((reinterpret_cast<uintptr_t>(tb.weights) | reinterpret_cast<uintptr_t>(tb.slot)) & 15) == 0;
+  const bool t_al = ((reinterpret_cast<uintptr_t>(tb.weights) |
+                      (MODE == kAdagradRow ? (uintptr_t)0 : reinterpret_cast<uintptr_t>(tb.slot))) & 15) == 0;
   const int64_t plane = tb.vocab * p.dim;  // second slot plane (Adam v / FTRL linear)
   if constexpr (mode_is_fused(MODE)) load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
   if constexpr (mode_slots(MODE) >= 1) load_elems<float, N>(tb.slot + off, av, t_al);
@@ -648,6 +661,24 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
       }
     }
   }
+  if constexpr (MODE == kAdagradRow) {
+    float ss = 0.0f;
+    if (col_live) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) ss = fmaf(acc[k], acc[k], ss);
+    }
+    ss = row_sumsq<LPR>(ss);
+    const int64_t row = (int64_t)key - tb.row_base;
+    const float a_new = tb.slot[row] + ss / (float)p.dim;
+    if (col_live) {
+      const float inv = tb.lr / sqrtf(a_new);
+#pragma unroll
+      for (int k = 0; k < N; ++k) wv[k] = wv[k] - inv * acc[k];
+      store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
+      if (sub == 0) tb.slot[row] = a_new;
+    }
+    continue;
+  }
   if (!col_live) continue;
 
   // ---- write the finished row once ----
@@ -670,11 +701,35 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
 
 // Writes one finished row (summed gradient `tot` of segment u, this lane's N columns): dense
 // gradient row, compact (unique_rows, grads) entry, or the fused optimizer update in place.
-template <typename GT, typename TT, int MODE>
+// Row-wise Adagrad: EVERY lane of the row's group calls (live = the lane holds columns of the row).
+template <typename GT, typename TT, int MODE, int LPR = 1>
 __device__ __forceinline__ void finish_row(const ApplyParams& p, uint32_t u, uint32_t key, int64_t s0, int sub,
-                                           const float (&tot)[Piece<GT>::N]) {
+                                           const float (&tot)[Piece<GT>::N], bool live = true) {
   constexpr int N = Piece<GT>::N;
-  if constexpr (MODE == kSparse) {
+  if constexpr (MODE == kAdagradRow) {
+    const uint64_t v0 = p.vals[s0];
+    const int f0 = (int)((uint32_t)(v0 >> 32) / (uint32_t)p.batch);
+    const krs_table tb = p.tables[p.feats[f0].table];
+    const int64_t row = (int64_t)key - tb.row_base;
+    float ss = 0.0f;
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) ss = fmaf(tot[k], tot[k], ss);
+    }
+    ss = row_sumsq<LPR>(ss);
+    const float a_new = tb.slot[row] + ss / (float)p.dim;
+    if (live) {
+      const int64_t off = row * p.dim + sub * N;
+      const bool t_al = (reinterpret_cast<uintptr_t>(tb.weights) & 15) == 0;
+      float wv[N];
+      load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
+      const float inv = tb.lr / sqrtf(a_new);
+#pragma unroll
+      for (int k = 0; k < N; ++k) wv[k] = wv[k] - inv * tot[k];
+      store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
+      if (sub == 0) tb.slot[row] = a_new;
+    }
+  } else if constexpr (MODE == kSparse) {
     if (sub == 0) p.unique_rows[u] = (int64_t)key;
     float* dst = p.row_grads + (int64_t)u * p.dim + sub * N;
 #pragma unroll
@@ -780,19 +835,22 @@ __global__ __launch_bounds__(256) void bag_apply_long_kernel(const ApplyParams p
       for (int k = 0; k < N; ++k) part[g * p.dim + sub * N + k] = acc[k];
     }
     __syncthreads();
-    if (g == 0 && col_live) {
+    if (g == 0 && (col_live || MODE == kAdagradRow)) {
       float tot[N];
 #pragma unroll
       for (int k = 0; k < N; ++k) tot[k] = 0.0f;
-      for (int gg = 0; gg < GPB; ++gg)
+      if (col_live)
+        for (int gg = 0; gg < GPB; ++gg)
 #pragma unroll
-        for (int k = 0; k < N; ++k) tot[k] += part[gg * p.dim + sub * N + k];
+          for (int k = 0; k < N; ++k) tot[k] += part[gg * p.dim + sub * N + k];
       if (item.partial != 0xffffffffu) {  // one of several chunks: the row is finished by bag_apply_finish_kernel
-        float* dst = p.partials + (int64_t)item.partial * (kPartialBytes / 4) + sub * N;
+        if (col_live) {
+          float* dst = p.partials + (int64_t)item.partial * (kPartialBytes / 4) + sub * N;
 #pragma unroll
-        for (int k = 0; k < N; ++k) dst[k] = tot[k];
+          for (int k = 0; k < N; ++k) dst[k] = tot[k];
+        }
       } else {
-        finish_row<GT, TT, MODE>(p, u, key, s0, sub, tot);
+        finish_row<GT, TT, MODE, LPR>(p, u, key, s0, sub, tot, col_live);
       }
     }
     __syncthreads();
@@ -808,7 +866,8 @@ __global__ __launch_bounds__(256) void bag_apply_finish_kernel(const ApplyParams
   const uint32_t n_multi = p.n_long[2];
   const int sub = threadIdx.x % LPR;
   const int row_pieces = (int)(((int64_t)p.dim * sizeof(GT)) >> 4);
-  if (sub >= row_pieces) return;
+  const bool live = sub < row_pieces;
+  if (!live && MODE != kAdagradRow) return;
   for (uint32_t mi = blockIdx.x * GPB + threadIdx.x / LPR; mi < n_multi; mi += gridDim.x * GPB) {
     const MultiSeg ms = p.multi_list[mi];
     const int64_t s0 = p.seg_start[ms.seg];
@@ -816,12 +875,13 @@ __global__ __launch_bounds__(256) void bag_apply_finish_kernel(const ApplyParams
     float tot[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) tot[k] = 0.0f;
-    for (uint32_t c = 0; c < ms.n_chunks; ++c) {
-      const float* src = p.partials + (int64_t)(ms.partial_base + c) * (kPartialBytes / 4) + sub * N;
+    if (live)
+      for (uint32_t c = 0; c < ms.n_chunks; ++c) {
+        const float* src = p.partials + (int64_t)(ms.partial_base + c) * (kPartialBytes / 4) + sub * N;
 #pragma unroll
-      for (int k = 0; k < N; ++k) tot[k] += src[k];
-    }
-    finish_row<GT, TT, MODE>(p, ms.seg, key, s0, sub, tot);
+        for (int k = 0; k < N; ++k) tot[k] += src[k];
+      }
+    finish_row<GT, TT, MODE, LPR>(p, ms.seg, key, s0, sub, tot, live);
   }
 }
 
@@ -838,7 +898,7 @@ __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, in
   const uint32_t key = p.keys[s0];
   if (key == kInvalidKey) return;
   const int t = MODE == kSparse ? 0 : find_table(p.tables, p.n_tables, (int64_t)key);
-  for (int c = sub; c < p.dim; c += lpr) {
+  auto column_grad = [&](int c) {
     float acc = 0.0f;
     for (int64_t j = s0; j < e0; ++j) {
       const uint64_t v = p.vals[j];
@@ -849,6 +909,31 @@ __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, in
       if (p.bag_scale) coef *= p.bag_scale[bag];
       acc = fmaf(coef, ld_elem(p.grad, grad_dtype, (int64_t)b * p.grad_ld + p.feats[f].out_col + c), acc);
     }
+    return acc;
+  };
+  if constexpr (MODE == kAdagradRow) {
+    // two passes over the row's columns: sum of squares (group-wide), then the update
+    const krs_table tb = p.tables[t];
+    const int64_t row = (int64_t)key - tb.row_base;
+    float ss = 0.0f;
+    for (int c = sub; c < p.dim; c += lpr) {
+      const float gc = column_grad(c);
+      ss = fmaf(gc, gc, ss);
+    }
+    for (int o = lpr / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float a_new = tb.slot[row] + ss / (float)p.dim;
+    const float inv = tb.lr / sqrtf(a_new);
+    for (int c = sub; c < p.dim; c += lpr) {
+      const int64_t off = row * p.dim + c;
+      st_elem(tb.weights, table_dtype, off, ld_elem(tb.weights, table_dtype, off) - inv * column_grad(c));
+    }
+    // every lane of the group has read the old accumulator before lane 0 overwrites it (lanes of a wave run in
+    // lock step through the shuffle above)
+    if (sub == 0) tb.slot[row] = a_new;
+    return;
+  }
+  for (int c = sub; c < p.dim; c += lpr) {
+    const float acc = column_grad(c);
     if (MODE == kSparse) {
       if (c == 0) p.unique_rows[u] = (int64_t)key;
       p.row_grads[(int64_t)u * p.dim + c] = acc;
@@ -1121,6 +1206,16 @@ extern "C" int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_ta
   if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
   ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kAdagrad>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int krs_embed_bag_bwd_fused_adagrad_rowwise(const krs_table* tables, int n_tables,
+                                                       const krs_feature* feats, int n_feats, const float* weights,
+                                                       const float* bag_scale, const void* grad, int grad_dtype,
+                                                       int64_t grad_ld, int batch, int dim, int table_dtype,
+                                                       int64_t nnz, const void* workspace, void* stream) {
+  if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
+  ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  return run_apply<kAdagradRow>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int krs_embed_bag_bwd_fused_adam(const krs_table* tables, int n_tables, const krs_feature* feats,

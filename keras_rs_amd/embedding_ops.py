@@ -168,8 +168,9 @@ class FusedBags:
                 C.c_int(L.fdtype(grad)), C.c_int64(grad.stride(0)), C.c_int(batch), C.c_int(self.dim),
                 C.c_int(L.fdtype(self.tables[0])), C.c_int64(nnz))
         tail = (L.ptr(ws), L.stream_ptr())
-        if kind in ("sgd", "adagrad"):
-            fn = {"sgd": L.lib().krs_embed_bag_bwd_fused_sgd, "adagrad": L.lib().krs_embed_bag_bwd_fused_adagrad}[kind]
+        if kind in ("sgd", "adagrad", "adagrad_rowwise"):
+            fn = {"sgd": L.lib().krs_embed_bag_bwd_fused_sgd, "adagrad": L.lib().krs_embed_bag_bwd_fused_adagrad,
+                  "adagrad_rowwise": L.lib().krs_embed_bag_bwd_fused_adagrad_rowwise}[kind]
             rc = fn(*head, *tail)
         elif kind in ("adam", "ftrl"):
             if hyper is None or len(hyper) != 4:

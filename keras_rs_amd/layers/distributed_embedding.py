@@ -66,6 +66,21 @@ class Adagrad:
 
 
 @dataclasses.dataclass
+class RowwiseAdagrad:
+    """NOT a reference optimizer: Adagrad with ONE accumulator per table row (the mean of the squared gradient
+    over the row's columns; the FBGEMM / TorchRec "rowwise_adagrad" rule, no epsilon).  Opt-in for 'sparsecore'
+    tables: the fused update then moves 8 accumulator bytes per touched row instead of 2 x dim x 4 -- at C3 K2's
+    traffic drops to a third.  Trajectories differ from exact Adagrad (equal only where a row's gradient has the
+    same magnitude in every column)."""
+
+    learning_rate: float = 0.001
+    initial_accumulator_value: float = 0.1
+
+    def get_config(self):
+        return {"learning_rate": self.learning_rate, "initial_accumulator_value": self.initial_accumulator_value}
+
+
+@dataclasses.dataclass
 class Adam:
     learning_rate: float = 0.001
     beta_1: float = 0.9
@@ -90,21 +105,22 @@ class Ftrl:
 
 
 def optimizer_from_config(cfg: dict):
-    return {"SGD": SGD, "Adagrad": Adagrad, "Adam": Adam, "Ftrl": Ftrl}[cfg["class_name"]](**cfg.get("config", {}))
+    return {"SGD": SGD, "Adagrad": Adagrad, "Adam": Adam, "Ftrl": Ftrl,
+            "RowwiseAdagrad": RowwiseAdagrad}[cfg["class_name"]](**cfg.get("config", {}))
 
 
 @dataclasses.dataclass(frozen=True)
 class FusedOptimizer:
     """What K2 needs to run a table's optimizer inside the backward."""
 
-    kind: str                 # "sgd" | "adagrad" | "adam" | "ftrl"
+    kind: str                 # "sgd" | "adagrad" | "adam" | "ftrl" | "adagrad_rowwise"
     lr: Any                   # float, or a schedule: callable(step) / callable() (jax/config_conversion.py:136-176)
     acc0: float = 0.0         # initial value of the (first) slot plane: Adagrad / FTRL accumulator
     consts: tuple = ()        # adam: (beta_1, beta_2, epsilon); ftrl: (lr_power, l1, l2, beta)
 
     @property
     def n_slot_planes(self) -> int:
-        return {"sgd": 0, "adagrad": 1, "adam": 2, "ftrl": 2}[self.kind]
+        return {"sgd": 0, "adagrad": 1, "adam": 2, "ftrl": 2, "adagrad_rowwise": 1}[self.kind]
 
     def lr_at(self, step: int) -> float:
         """Learning rate of the update with 0-based index `step` (keras `iterations`)."""
@@ -120,6 +136,8 @@ class FusedOptimizer:
         return self.consts if self.kind == "ftrl" else None
 
     def new_slot(self, shape, device):
+        if self.kind == "adagrad_rowwise":
+            return torch.full((shape[0],), self.acc0, dtype=torch.float32, device=device)
         if self.kind == "adagrad":
             return torch.full(shape, self.acc0, dtype=torch.float32, device=device)
         if self.kind in ("adam", "ftrl"):
@@ -169,6 +187,8 @@ def resolve_fused_optimizer(opt) -> FusedOptimizer | None:
         if float(getattr(opt, "epsilon", 1e-7)) != 1e-7:
             return None
         return FusedOptimizer("adagrad", lr, float(getattr(opt, "initial_accumulator_value", 0.1)))
+    if name == "rowwiseadagrad":
+        return FusedOptimizer("adagrad_rowwise", lr, float(getattr(opt, "initial_accumulator_value", 0.1)))
     if name == "adam":
         if getattr(opt, "amsgrad", False):
             return None

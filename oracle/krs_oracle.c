@@ -185,12 +185,42 @@ int krs_oracle_embed_bag_bwd_dense(const krs_table* grad_tables, int n_tables,
  * only looked-up rows; for SGD an untouched row has grad 0 so the result is
  * identical, for Adagrad acc stays and 0/sqrt(acc) = 0 as long as acc > 0;
  * Adam / FTRL are "lazy": untouched rows keep value and slots).
- * kind: 0 = SGD, 1 = Adagrad, 2 = Adam, 3 = FTRL.
+ * kind: 0 = SGD, 1 = Adagrad, 2 = Adam, 3 = FTRL, 4 = row-wise Adagrad (opt-in variant, acc = [vocab]).
  */
 int krs_oracle_apply_optimizer2(void* table, int table_dtype, float* acc, const float* grad,
                                 const uint8_t* touched, int64_t vocab, int dim, float lr,
                                 int kind, const float* hyper) {
   const int64_t plane = vocab * dim;
+  if (kind == 4) {
+    /* row-wise Adagrad (opt-in variant, include/krs.h krs_embed_bag_bwd_fused_adagrad_rowwise): acc is [vocab];
+     * the row's sum of squares is taken in the kernel's order -- 16-byte pieces of the GRADIENT dtype per lane
+     * (N = 8 columns for bf16 gradients, 4 for fp32: `hyper[0]` carries N), fmaf chain inside a piece,
+     * butterfly over the pieces -- so that the accumulator matches bit for bit. */
+    const int n = hyper && hyper[0] > 0 ? (int)hyper[0] : 4;
+    for (int64_t r = 0; r < vocab; ++r) {
+      if (touched && !touched[r]) continue;
+      int lanes = 1;
+      while (lanes * n < dim) lanes <<= 1;
+      float part[64];
+      for (int l = 0; l < lanes; ++l) {
+        float ss = 0.0f;
+        for (int k = 0; k < n && l * n + k < dim; ++k) ss = fmaf(grad[r * dim + l * n + k], grad[r * dim + l * n + k], ss);
+        part[l] = ss;
+      }
+      for (int o = lanes / 2; o > 0; o >>= 1)          /* every lane ends with the same total: lane 0's */
+        for (int l = 0; l < lanes; ++l) {
+          if ((l & o) == 0) { float a = part[l], b = part[l | o]; part[l] = a + b; part[l | o] = b + a; }
+        }
+      const float a_new = acc[r] + part[0] / (float)dim;
+      const float inv = lr / sqrtf(a_new);
+      for (int c = 0; c < dim; ++c) {
+        int64_t i = r * dim + c;
+        st(table, table_dtype, i, ld(table, table_dtype, i) - inv * grad[i]);
+      }
+      acc[r] = a_new;
+    }
+    return KRS_OK;
+  }
   for (int64_t r = 0; r < vocab; ++r) {
     if (touched && !touched[r]) continue;
     for (int c = 0; c < dim; ++c) {

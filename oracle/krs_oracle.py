@@ -159,14 +159,15 @@ def embed_bag_bwd_dense(grad_tables, feats, ids, offsets, weights, bag_scale, gr
 
 
 def apply_optimizer(table, acc, grad, touched, lr, kind, hyper=None):
-    """kind: 'sgd' | 'adagrad' | 'adam' | 'ftrl'.  In place on `table` (and `acc`: [V, D] for adagrad,
-    [2, V, D] for adam (m, v) / ftrl (accumulator, linear)).  hyper: adam (beta_1, beta_2, epsilon,
-    bias_correction); ftrl (learning_rate_power, l1, l2, beta)."""
+    """kind: 'sgd' | 'adagrad' | 'adam' | 'ftrl' | 'adagrad_rowwise'.  In place on `table` (and `acc`: [V, D] for
+    adagrad, [V] for adagrad_rowwise, [2, V, D] for adam (m, v) / ftrl (accumulator, linear)).  hyper: adam (beta_1,
+    beta_2, epsilon, bias_correction); ftrl (learning_rate_power, l1, l2, beta); adagrad_rowwise (columns per
+    16-byte piece of the gradient dtype: 8 for bf16, 4 for fp32 -- the order of its sum of squares)."""
     h = np.zeros(4, np.float32) if hyper is None else np.asarray(hyper, np.float32)
     rc = lib().krs_oracle_apply_optimizer2(
         _p(table), C.c_int(fdtype(table)), _p(acc), _p(grad), _p(touched),
         C.c_int64(table.shape[0]), C.c_int(table.shape[1]), C.c_float(lr),
-        C.c_int({"sgd": 0, "adagrad": 1, "adam": 2, "ftrl": 3}[kind]), _p(h),
+        C.c_int({"sgd": 0, "adagrad": 1, "adam": 2, "ftrl": 3, "adagrad_rowwise": 4}[kind]), _p(h),
     )
     assert rc == 0, rc
 

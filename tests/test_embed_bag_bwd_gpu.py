@@ -113,6 +113,69 @@ def test_fused_optimizers(kind, tdt, gdt, dim):
             np.testing.assert_allclose(s["slots"][t].cpu().numpy(), exp_slots[t], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("tdt,gdt,dim", [("f32", "f32", 128), ("bf16", "bf16", 128), ("f32", "f32", 7),
+                                         ("bf16", "f32", 64), ("f32", "bf16", 96)])
+@pytest.mark.parametrize("heavy", [False, True])
+def test_fused_rowwise_adagrad(tdt, gdt, dim, heavy):
+    # opt-in variant (not a reference optimizer): ONE accumulator per row = running mean over the columns of g^2.
+    # Checked against the oracle twin on the oracle's dense gradient; `heavy`: segments longer than 128 / 2048
+    # lookups take the workgroup-per-row and the chunked paths
+    kw = dict(n_tables=2, batch=700, max_hot=40, vocab_hi=6) if heavy else {}
+    s = _setup(dim, tdt, gdt, False, use_w=not heavy, combiners=["sum", "mean"], **kw)
+    dev = s["grad"].device
+    fb = s["fb"]
+    fb.slots = [torch.full((t.shape[0],), 0.1, dtype=torch.float32, device=dev) for t in s["tables"]]
+    fb._tab_key = None
+    exp_tables = [to_np(t).copy() for t in s["tables"]]
+    exp_acc = [np.full(t.shape[0], 0.1, np.float32) for t in s["tables"]]
+    for step in range(2):
+        fb.backward_fused("adagrad_rowwise", s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                          bag_scale=s["scale"])
+    torch.cuda.synchronize()
+    ids, hots = s["bags"]["ids"], s["hots"]
+    n_piece = 8 if gdt == "bf16" else 4
+    for t in range(len(exp_tables)):
+        touched = np.zeros(s["vocabs"][t], np.uint8)
+        base = 0
+        for f, (tt, _, _) in enumerate(fb.features):
+            n = s["batch"] * hots[f]
+            if tt == t:
+                touched[ids[base:base + n]] = 1
+            base += n
+        for step in range(2):
+            ko.apply_optimizer(exp_tables[t], exp_acc[t], s["de"][t], touched, fb.lrs[t], "adagrad_rowwise",
+                               (n_piece, 0, 0, 0))
+        tol = dict(rtol=2 ** -7, atol=1e-6) if tdt == "bf16" else dict(rtol=2e-5 if heavy else 1e-6, atol=1e-6)
+        np.testing.assert_allclose(to_f32(to_np(s["tables"][t])), to_f32(exp_tables[t]), **tol)
+        np.testing.assert_allclose(fb.slots[t].cpu().numpy(), exp_acc[t], rtol=1e-5 if heavy else 1e-6, atol=1e-7)
+        assert np.all(fb.slots[t].cpu().numpy()[touched == 0] == np.float32(0.1))
+
+
+def test_rowwise_adagrad_equals_exact_adagrad_when_columns_agree():
+    # relation to the exact rule: where |g| is the same in every column of a row, mean_j g_j^2 = g_j^2 and both
+    # optimizers take the same step
+    import keras_rs_amd.layers as kl
+
+    rng = np.random.default_rng(2)
+    ids = rng.integers(0, 30, (16, 3)).astype(np.int32)
+    sign = torch.from_numpy(rng.choice([-1.0, 1.0], (16, 8)).astype(np.float32)).cuda()
+    mag = torch.from_numpy(rng.uniform(0.5, 2, (16, 1)).astype(np.float32)).cuda()
+    res = []
+    for opt in (kl.Adagrad(0.1, 0.1), kl.RowwiseAdagrad(0.1, 0.1)):
+        t = kl.TableConfig("t", 30, 8, placement="sparsecore", optimizer=opt, combiner="sum",
+                           initializer=kl.distributed_embedding.base.RandomUniform(-1, 1, seed=3))
+        layer = kl.DistributedEmbedding({"a": kl.FeatureConfig("a", t, (16, 3), (16, 8))})
+        (layer({"a": ids})["a"] * sign * mag).sum().backward()
+        res.append(layer.get_embedding_tables()["t"].clone())
+        sd = layer.state_dict()
+        assert sd["sparsecore_t_slot"].shape == ((30,) if isinstance(opt, kl.RowwiseAdagrad) else (30, 8))
+    # rows hit by several samples see sums of +-mag with differing magnitudes per column: compare the others
+    counts = np.bincount(ids.reshape(-1), minlength=30)
+    once = torch.from_numpy(np.nonzero(counts == 1)[0]).cuda()
+    assert once.numel() > 3
+    torch.testing.assert_close(res[0][once], res[1][once], rtol=1e-6, atol=1e-6)
+
+
 ADAM = (0.9, 0.999, 1e-7)
 FTRL = (-0.5, 0.02, 0.01, 0.3)   # learning_rate_power, l1, l2, beta
 
