@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void embed_gather_hot1_rows(const EmbedFwdPara
   typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
   __shared__ const char* s_table[kRowsMaxFeats];
   __shared__ int64_t s_ids_base[kRowsMaxFeats];
-  __shared__ int s_vocab[kRowsMaxFeats], s_out_col[kRowsMaxFeats];
+  __shared__ int s_vocab[kRowsMaxFeats], s_out_col[kRowsMaxFeats], s_hot[kRowsMaxFeats], s_comb[kRowsMaxFeats];
   for (int i = threadIdx.x; i < p.n_feats; i += 256) {
     const krs_feature ft = p.feats[i];
     const krs_table tb = p.tables[ft.table];
@@ -416,6 +416,8 @@ __global__ __launch_bounds__(256) void embed_gather_hot1_rows(const EmbedFwdPara
     s_ids_base[i] = ft.ids_base;
     s_vocab[i] = tb.vocab;
     s_out_col[i] = ft.out_col;
+    s_hot[i] = ft.hot;
+    s_comb[i] = ft.combiner;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -428,12 +430,15 @@ __global__ __launch_bounds__(256) void embed_gather_hot1_rows(const EmbedFwdPara
   // this lane's own unit: feature, sample, validated id
   const int64_t mu = min(u0 + lane, units - 1);
   const int mb = (int)(mu / p.n_feats), mf = (int)(mu - (int64_t)mb * p.n_feats);
-  const int64_t q = s_ids_base[mf] + mb;
+  // (a call is "one lookup per bag on average" when nnz == bags; a feature may still have hot != 1 -- 2 and 0,
+  // say: those units take the slow loop below and their id is not read here)
+  const bool one = s_hot[mf] == 1;
+  const int64_t q = one ? s_ids_base[mf] + mb : 0;
   const int64_t rawid = p.id64 ? reinterpret_cast<const int64_t*>(p.ids)[q] : (int64_t)reinterpret_cast<const int32_t*>(p.ids)[q];
-  const int myid = (rawid >= 0 && rawid < s_vocab[mf]) ? (int)rawid : -1;
+  const int myid = (one && rawid >= 0 && rawid < s_vocab[mf]) ? (int)rawid : -1;
   const bool mine = u0 + lane < units;
-  if (mine && myid < 0 && p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
-  if (p.bag_scale && mine) p.bag_scale[(int64_t)mf * p.batch + mb] = 1.0f;
+  if (mine && one && myid < 0 && p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
+  if (p.bag_scale && mine && one) p.bag_scale[(int64_t)mf * p.batch + mb] = 1.0f;
   TT* out = reinterpret_cast<TT*>(p.out) + sub * N;
 #pragma unroll 1
   for (int s0 = 0; s0 < STEPS; s0 += U) {
@@ -450,6 +455,33 @@ __global__ __launch_bounds__(256) void embed_gather_hot1_rows(const EmbedFwdPara
     }
 #pragma unroll
     for (int k = 0; k < U; ++k) {
+      if (u0 + (s0 + k) * G + g < units && s_hot[f[k]] != 1) {
+        // the odd feature whose bags do not hold exactly one id: plain loop over the bag
+        const int hot = s_hot[f[k]], comb = s_comb[f[k]];
+        float acc[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = 0.0f;
+        for (int l = 0; l < hot; ++l) {
+          const int64_t r = ld_index(p.ids, p.id64, s_ids_base[f[k]] + (int64_t)b[k] * hot + l);
+          if (r < 0 || r >= s_vocab[f[k]]) {
+            if (p.err_flag) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
+            continue;
+          }
+          const u32x4 rr = *(gvec_ptr)(s_table[f[k]] + r * row_bytes + (col_live ? sub : 0) * 16);
+          float fv[N];
+          Vec16<TT>::unpack(make_uint4(rr.x, rr.y, rr.z, rr.w), fv);
+#pragma unroll
+          for (int i = 0; i < N; ++i) acc[i] += fv[i];
+        }
+        const float den = comb == KRS_MEAN ? (float)hot : (comb == KRS_SQRTN ? sqrtf((float)hot) : 1.0f);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (comb != KRS_SUM) acc[i] = den == 0.0f ? 0.0f : acc[i] / den;
+        if (col_live) store_row_piece<TT, N>(out + (int64_t)b[k] * p.out_ld + s_out_col[f[k]], acc, false);
+        if (p.bag_scale && sub == 0)
+          p.bag_scale[(int64_t)f[k] * p.batch + b[k]] = comb == KRS_SUM ? 1.0f : (den == 0.0f ? 0.0f : 1.0f / den);
+        continue;
+      }
       if (u0 + (s0 + k) * G + g < units && col_live) {
         if (id[k] < 0) raw[k] = u32x4{0, 0, 0, 0};
         TT* dst = out + (int64_t)b[k] * p.out_ld + s_out_col[f[k]];

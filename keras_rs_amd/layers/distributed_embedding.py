@@ -273,6 +273,8 @@ class DistributedEmbedding(base.Layer):
         self._table_params: dict[int, torch.nn.Parameter] = {}
         self._table_slots: dict[int, torch.Tensor | None] = {}
         self._slot_buffer_names: dict[int, str] = {}
+        self._stacks: list = []
+        self._stack_of: dict[int, tuple] = {}      # table -> (stacked parameter, first row) for named stacks
         if "sparsecore" in self._placement_to_path_to_feature_config:
             self._sparsecore_init(self._placement_to_path_to_feature_config["sparsecore"], table_stacking)
         if "default_device" in self._placement_to_path_to_feature_config:
@@ -323,8 +325,45 @@ class DistributedEmbedding(base.Layer):
             g.table_index.append(idx)
         self._groups[placement] = list(by_dim.values())
 
+    def _parse_table_stacking(self, table_stacking, feature_configs) -> list:
+        """`table_stacking` (base:455-466, jax/distributed_embedding.py:413-453): None / "auto" / a list of table
+        names / a list of such lists.  Here tables of one embedding width are ALWAYS looked up by one launch (the
+        purpose of stacking on SparseCore), so "auto" and None need no physical change; named stacks additionally
+        get ONE contiguous [sum V, D] buffer per stack (one allocation, one checkpoint entry), the per-table
+        tensors being row windows of it.  Returns the stacks as lists of TableConfig."""
+        if table_stacking is None or (isinstance(table_stacking, str) and table_stacking == "auto"):
+            return []
+        bad = ValueError(f"Unsupported table stacking {table_stacking}, must be None, 'auto', or sequences of table "
+                         "names to stack.")
+        if isinstance(table_stacking, str) or not isinstance(table_stacking, (list, tuple)) or not table_stacking:
+            raise bad
+        if isinstance(table_stacking[0], str):
+            groups = [list(table_stacking)]
+        elif all(isinstance(g, (list, tuple)) for g in table_stacking):
+            groups = [list(g) for g in table_stacking]
+        else:
+            raise bad
+        by_name = {fc.table.name: fc.table for fc in feature_configs.values()}
+        stacks, seen = [], set()
+        for names in groups:
+            if not all(isinstance(n, str) for n in names):
+                raise bad
+            tcs = []
+            for n in names:
+                if n not in by_name:
+                    raise ValueError(f"table_stacking names table '{n}', which no 'sparsecore' feature uses")
+                if n in seen:
+                    raise ValueError(f"table '{n}' appears in more than one stack")
+                seen.add(n)
+                tcs.append(by_name[n])
+            if len({tc.embedding_dim for tc in tcs}) > 1:
+                raise ValueError(f"tables {names} cannot be stacked: their embedding_dim differ")
+            if len(tcs) > 1:
+                stacks.append(tcs)
+        return stacks
+
     def _sparsecore_init(self, feature_configs, table_stacking) -> None:
-        del table_stacking  # same-width tables are always looked up together here
+        self._stacks = self._parse_table_stacking(table_stacking, feature_configs)
         if not self.has_sparsecores():
             raise self._unsupported_placement_error("sparsecore")
         for path, fc in feature_configs.items():
@@ -346,6 +385,23 @@ class DistributedEmbedding(base.Layer):
                 continue
             tables, slots, lrs, topts = [], [], [], []
             kinds: set = set()
+            if placement == "sparsecore":
+                # named stacks: ONE parameter per stack, the tables are row windows of it
+                for tcs in getattr(self, "_stacks", []):
+                    if id(tcs[0]) in self._table_params or not all(tc in g.table_configs for tc in tcs):
+                        continue
+                    rows = sum(tc.vocabulary_size for tc in tcs)
+                    stack = self.add_weight((rows, g.dim), "zeros", "sparsecore_stack_" + "_".join(tc.name for tc in tcs),
+                                            trainable=False)
+                    r0 = 0
+                    with torch.no_grad():
+                        for tc in tcs:
+                            init = base.get_initializer(tc.initializer)
+                            stack[r0:r0 + tc.vocabulary_size] = init((tc.vocabulary_size, g.dim), stack.dtype, stack.device)
+                            self._table_params[id(tc)] = stack.data[r0:r0 + tc.vocabulary_size]
+                            self._table_slots[id(tc)] = None
+                            self._stack_of[id(tc)] = (stack, r0)
+                            r0 += tc.vocabulary_size
             for tc in g.table_configs:
                 key = id(tc)
                 if key not in self._table_params:
@@ -474,10 +530,13 @@ class DistributedEmbedding(base.Layer):
         out = super()._apply(fn, recurse)
         for key, bname in getattr(self, "_slot_buffer_names", {}).items():
             self._table_slots[key] = self._buffers[bname]
+        for key, (stack, r0) in getattr(self, "_stack_of", {}).items():
+            self._table_params[key] = stack.data[r0:r0 + self._table_params[key].shape[0]]
         for groups in getattr(self, "_groups", {}).values():
             for g in groups:
                 if g.bags is not None:
                     g.bags.slots = [self._table_slots[id(tc)] for tc in g.table_configs]
+                    g.bags.tables = [self._table_params[id(tc)] for tc in g.table_configs]
                     g.bags._tab_key = None
         self._err_dev = self._err_host = self._err_event = None
         return out

@@ -350,6 +350,60 @@ def test_distributed_embedding_state_dict_carries_optimizer_state(kind):
     assert not torch.equal(c.get_embedding_tables()["t"], a.get_embedding_tables()["t"])
 
 
+def test_table_stacking_by_name_and_checkpoint_file(tmp_path):
+    # jax/distributed_embedding.py:413-453: named stacks.  Here: one contiguous [sum V, D] parameter per stack, the
+    # tables are row windows of it; results equal the unstacked layer's; a checkpoint written to a file restores
+    # tables, optimizer slots and the update count (jax/distributed_embedding_test.py:471-552 save / restore)
+    kl = _layers()
+    from keras_rs_amd.layers import base
+
+    def make(stacking):
+        opt = kl.Adagrad(0.1, 0.1)
+        tcs = [kl.TableConfig(n, v, 8, placement="sparsecore", optimizer=opt, combiner="sum",
+                              initializer=base.RandomUniform(-1, 1, seed=5 + i))
+               for i, (n, v) in enumerate([("a", 11), ("b", 7), ("c", 13)])]
+        layer = kl.DistributedEmbedding({n: kl.FeatureConfig(n, tc, (6, 2), (6, 8)) for n, tc in zip("abc", tcs)},
+                                        table_stacking=stacking)
+        layer.build(None)
+        return layer
+
+    rng = np.random.default_rng(0)
+    ids = {n: rng.integers(0, v, (6, 2)).astype(np.int32) for n, v in zip("abc", (11, 7, 13))}
+    gr = {n: torch.from_numpy(rng.uniform(-1, 1, (6, 8)).astype(np.float32)).to(DEV) for n in "abc"}
+
+    def step(layer):
+        out = layer(ids)
+        sum((out[n] * gr[n]).sum() for n in "abc").backward()
+        return out
+
+    plain, stacked = make("auto"), make([["a", "c"]])
+    assert "sparsecore_stack_a_c" in stacked.state_dict() and stacked.state_dict()["sparsecore_stack_a_c"].shape == (24, 8)
+    assert "sparsecore_b_embeddings" in stacked.state_dict() and "sparsecore_a_embeddings" not in stacked.state_dict()
+    o1, o2 = step(plain), step(stacked)
+    for n in "abc":
+        assert torch.equal(o1[n], o2[n])
+    t1, t2 = plain.get_embedding_tables(), stacked.get_embedding_tables()
+    for n in "abc":
+        assert torch.equal(t1[n], t2[n])
+    # the windows alias the stack
+    st = stacked.state_dict()["sparsecore_stack_a_c"]
+    assert torch.equal(st[:11], t2["a"]) and torch.equal(st[11:], t2["c"])
+    # checkpoint file round trip
+    path = str(tmp_path / "emb.pt")
+    torch.save(stacked.state_dict(), path)
+    resumed = make([["a", "c"]])
+    resumed.load_state_dict(torch.load(path))
+    step(stacked), step(resumed)
+    for k, v in stacked.state_dict().items():
+        if isinstance(v, torch.Tensor):
+            assert torch.equal(resumed.state_dict()[k], v), k
+    assert resumed.get_extra_state() == stacked.get_extra_state() == {"iterations": {"sparsecore/0": 2}}
+    with pytest.raises(ValueError):
+        make([["a", "nope"]])
+    with pytest.raises(ValueError):
+        make("always")
+
+
 def _de_configs(placement, optimizer="sgd", combiner="mean"):
     kl = _layers()
     de = KAT["distributed_embedding"]

@@ -227,3 +227,21 @@ def test_threaded_data_loader_delivers_every_item_and_propagates_errors():
     # items of another shape go to process_fn whole
     loader = ThreadedDataLoader(lambda item, training=False: item * 2, [1, 2, 3], num_workers=1, device="cpu")
     assert sorted(loader) == [2, 4, 6]
+
+
+def test_table_stacking_argument_is_validated_on_the_host():
+    # jax/distributed_embedding.py:413-453: None / "auto" / names / lists of names; anything else is a ValueError
+    import keras_rs_amd.layers as kl
+
+    def cfgs(dims=(8, 8)):
+        tcs = [kl.TableConfig(n, 10, d, placement="sparsecore", optimizer="sgd") for n, d in zip("ab", dims)]
+        return {n: kl.FeatureConfig(n, tc, (4, 1), (4, d)) for n, tc, d in zip("ab", tcs, dims)}
+
+    for bad in ("always", [1, 2], [["a", "zzz"]], [["a"], ["a", "b"]]):
+        with pytest.raises(ValueError):
+            kl.DistributedEmbedding(cfgs(), table_stacking=bad)
+    with pytest.raises(ValueError):                       # different widths cannot share a stack
+        kl.DistributedEmbedding(cfgs((8, 16)), table_stacking=["a", "b"])
+    if not kl.DistributedEmbedding.has_sparsecores():
+        with pytest.raises(NotImplementedError):          # a valid request then fails for the missing GPU only
+            kl.DistributedEmbedding(cfgs(), table_stacking=[["a", "b"]])
