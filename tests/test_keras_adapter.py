@@ -104,7 +104,7 @@ def test_adapter_layers_match_native_layers_on_gpu():
     if True:
         for case in di["cases"]:
             out = A.DotInteraction(self_interaction=case["self_interaction"], skip_gather=case["skip_gather"])(feats)
-            np.testing.assert_allclose(out.cpu().numpy()[0], np.array(case["expected"], np.float32), atol=1e-5, rtol=1e-5)
+            np.testing.assert_allclose(out.cpu().numpy().reshape(-1), np.array(case["expected"], np.float32).reshape(-1), atol=1e-5, rtol=1e-5)
     # DistributedEmbedding wrapper: same numbers as the native layer, tables visible as Keras weights
     t = kl.TableConfig("t", 23, 7, placement="sparsecore", optimizer="sgd", combiner="mean")
     layer = A.DistributedEmbedding({"f": kl.FeatureConfig("f", t, (4, 2), (4, 7))})
