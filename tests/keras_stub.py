@@ -74,7 +74,12 @@ class Layer:
     def __call__(self, *args, **kwargs):
         if not self.built:
             first = args[0]
-            shape = [tuple(t.shape) for t in first] if isinstance(first, (list, tuple)) else tuple(first.shape)
+            if isinstance(first, dict):        # nested inputs (DistributedEmbedding): shapes are not inspected
+                shape = None
+            elif isinstance(first, (list, tuple)):
+                shape = [tuple(t.shape) for t in first]
+            else:
+                shape = tuple(first.shape)
             self.build(shape)
             self.built = True
         return self.call(*args, **kwargs)
