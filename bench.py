@@ -410,8 +410,11 @@ def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False):
     # gather form (sharded owner side): one output vector per lookup, i.e. `bags` = nnz
     alg = k1_bytes(nnz, nnz if gather_form else b_local * a.tables, a.dim, 2)
     achieved = alg / k1_s
+    traffic = None if gather_form or a.criteo_vocab or a.id_skew > 0 else pmc_traffic(kernel)
     return {"kernel": kernel, "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK, "traffic": None if gather_form or a.criteo_vocab or a.id_skew > 0 else pmc_traffic(kernel),
+            "frac": achieved / HBM_PEAK, "traffic": traffic,
+            "traffic_source": None if traffic is None else "profiles/k1_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                              "passes of this kernel at this shape (counters cannot be read inside this run)",
             "launch_us": k1_s * 1e6,
             "algorithmic_bytes": alg}
 
@@ -526,15 +529,17 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak" if world == 1 else "strong",
+        "scaling": "strong",   # --gpus N keeps the GLOBAL batch (BASELINE.json: "batch 65 536 at 1/2/4/8 GPU")
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
             "workload": ("%s: %d tables x %s rows x %d (bf16), global batch %d, %s, %s, "
-                         "DotInteraction(F=%d) + %d x FeatureCross(d=%d, projection=%d), fused Adagrad on tables"
+                         "DotInteraction(F=%d) + %d x FeatureCross(d=%d, projection=%d), fused %s on tables"
                          % (shape_name, a.tables, rows_desc, a.dim, a.batch, describe(primary), ids_desc, a.tables + 1,
-                            a.cross_layers, (a.tables + 1) * a.dim, a.projection)),
+                            a.cross_layers, (a.tables + 1) * a.dim, a.projection,
+                            "row-wise Adagrad (opt-in variant, NOT the reference optimizer)" if a.rowwise_adagrad
+                            else "Adagrad")),
             "global_batch": a.batch,
             "parallelism": "single GPU" if world == 1 else f"tables MOD row-sharded over {world} GPUs, dense part DP",
         },

@@ -949,6 +949,10 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 //     2kb+1, which retires the two pieces of block kb+1 and leaves the 2*NSTG-5 younger pieces in flight.
 //     A wave's vmcnt covers its own DMA writes; the barrier that follows publishes them.
 // Results are bit-identical to the two-stage kernels (same MFMA chain per accumulator: k ascending).
+// Measured and not kept (profiles/r2_gemm_ab.txt): 128-byte rows with a row-wise walk of the wave's block (the
+// "half-tile" ring of the 8-phase template: 205 us against 207 for h = x U, 342 against 338 for dx); issuing the
+// phase's DMA between the MFMAs of the compute segment instead of beside the fragment reads (212 / 319 us
+// against 205 / 274 for the K-contiguous / K-strided forms); five stages instead of four (equal).
 namespace pp {
 constexpr int PIECE = 16384;
 constexpr int STAGE = 2 * PIECE;
