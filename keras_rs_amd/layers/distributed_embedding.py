@@ -872,7 +872,6 @@ def _ragged_numpy_to_csr(x, w):
         rx = Ragged.from_rows(list(x), dtype=np.asarray(x[0]).dtype if np.asarray(x[0]).dtype.kind == "i" else np.int32)
         rw = None
         if w is not None:
-            rw = Ragged(np.concatenate([np.asarray(r, np.float32) for r in w] + [np.zeros(0, np.float32)]),
-                        rx.row_offsets)
+            rw = Ragged(Ragged.from_rows(list(w), dtype=np.float32).values, rx.row_offsets)
         return rx, rw
     return x, w

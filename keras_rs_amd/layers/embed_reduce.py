@@ -28,9 +28,21 @@ class Ragged:
 
     @classmethod
     def from_rows(cls, rows, dtype=np.int32):
-        lens = [len(r) for r in rows]
-        vals = np.concatenate([np.asarray(r, dtype=dtype) for r in rows] + [np.zeros(0, dtype)])
-        return cls(vals.astype(dtype), np.concatenate([[0], np.cumsum(lens)]).astype(np.int32))
+        """Rows (arrays or lists of varying length; the ragged input form of base_distributed_embedding.py:31-92)
+        -> CSR without a Python-level loop body per row: the lengths come from one C-level map, the values from
+        one concatenate (array rows) or one chained fromiter (list rows) -- 1.7 M rows per ml_perf batch."""
+        import itertools
+
+        n = len(rows)
+        lens = np.fromiter(map(len, rows), dtype=np.int64, count=n)
+        total = int(lens.sum())
+        if n and all(isinstance(r, np.ndarray) for r in (rows[0], rows[-1])):
+            vals = np.concatenate(rows).astype(dtype, copy=False) if total else np.zeros(0, dtype)
+        else:
+            vals = np.fromiter(itertools.chain.from_iterable(rows), dtype=dtype, count=total)
+        off = np.zeros(n + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        return cls(vals, off.astype(np.int32 if total < 2 ** 31 else np.int64))
 
     @property
     def shape(self):

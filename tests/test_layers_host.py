@@ -245,3 +245,18 @@ def test_table_stacking_argument_is_validated_on_the_host():
     if not kl.DistributedEmbedding.has_sparsecores():
         with pytest.raises(NotImplementedError):          # a valid request then fails for the missing GPU only
             kl.DistributedEmbedding(cfgs(), table_stacking=[["a", "b"]])
+
+
+def test_ragged_from_rows_builds_csr_from_arrays_and_lists():
+    from keras_rs_amd.layers import Ragged
+
+    rows = [np.array([1], np.int64), np.array([], np.int64), np.array([2, 3, 4, 5], np.int64)]
+    r = Ragged.from_rows(rows)
+    assert r.values.dtype == np.int32 and r.values.tolist() == [1, 2, 3, 4, 5] and r.row_offsets.tolist() == [0, 1, 1, 5]
+    r = Ragged.from_rows([[1.5], [], [2.0, 3.0]], dtype=np.float32)
+    assert r.values.dtype == np.float32 and r.values.tolist() == [1.5, 2.0, 3.0] and r.row_offsets.tolist() == [0, 1, 1, 3]
+    r = Ragged.from_rows([])
+    assert r.values.size == 0 and r.row_offsets.tolist() == [0]
+    big = [np.arange(i % 7, dtype=np.int32) for i in range(50_000)]
+    r = Ragged.from_rows(big)
+    assert r.row_offsets[-1] == sum(i % 7 for i in range(50_000)) and r.values[:6].tolist() == [0, 0, 1, 0, 1, 2]
