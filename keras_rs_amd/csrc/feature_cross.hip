@@ -952,7 +952,10 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // Measured and not kept (profiles/r2_gemm_ab.txt): 128-byte rows with a row-wise walk of the wave's block (the
 // "half-tile" ring of the 8-phase template: 205 us against 207 for h = x U, 342 against 338 for dx); issuing the
 // phase's DMA between the MFMAs of the compute segment instead of beside the fragment reads (212 / 319 us
-// against 205 / 274 for the K-contiguous / K-strided forms); five stages instead of four (equal).
+// against 205 / 274 for the K-contiguous / K-strided forms); five stages instead of four (equal); for the short-K
+// products with heavy epilogues, 256 x 128 tiles on a three-stage ring at TWO workgroups per CU, so that one's
+// epilogue runs under the other's main loop (467 / 344 us against 450 / 323: 1.5x the operand bytes per flop cost
+// more than the overlap returns).
 namespace pp {
 constexpr int PIECE = 16384;
 constexpr int STAGE = 2 * PIECE;
