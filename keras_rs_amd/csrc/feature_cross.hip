@@ -956,6 +956,9 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // products with heavy epilogues, 256 x 128 tiles on a three-stage ring at TWO workgroups per CU, so that one's
 // epilogue runs under the other's main loop (467 / 344 us against 450 / 323: 1.5x the operand bytes per flop cost
 // more than the overlap returns).
+#ifndef KRS_PP_PROBE
+#define KRS_PP_PROBE 0  // development builds only (scripts/exp): 1 = DMA stream alone, 2 = LDS reads + MFMA alone, 3 = DMA + LDS reads
+#endif
 namespace pp {
 constexpr int PIECE = 16384;
 constexpr int STAGE = 2 * PIECE;
@@ -966,12 +969,30 @@ __device__ __forceinline__ void pp_barrier() {
   asm volatile("s_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
+// Transposing LDS read as opaque assembly: hipcc treats the intrinsic as a read of memory an LDS-DMA may have
+// written and puts `s_waitcnt vmcnt(0)` in front of every group of them -- which drained the ring's DMA queue
+// once per phase in the K-strided form.  The caller orders these reads against the DMA itself (counted vmcnt +
+// barrier) and waits for them with pp_lgkm_wait().
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2 pp_read_tr16(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// s_waitcnt lgkmcnt(N) that the fragments' consumers depend on (the registers pass through the statement)
+template <int N>
+__device__ __forceinline__ void pp_lgkm_wait(u32x4 (&fa)[4], u32x4 (&fb)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(%6)"
+               : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1])
+               : "n"(N));
+}
 template <int N>
 __device__ __forceinline__ void pp_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool TN, int NSTG, int EPI>
+template <bool TN, int NSTG, int EPI, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int mt, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TM = 256, TN_ = 256;
@@ -1040,6 +1061,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
   }
   const int dma_off = wave * 2048;  // + i*1024: where instruction q = wave*2 + i lands inside a piece
   auto issue_a = [&](int stage) {
+    if constexpr (KRS_PP_PROBE == 2) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       __builtin_amdgcn_global_load_lds((gptr)ap[i], (lptr)(smem + stage * pp::STAGE + dma_off + i * 1024), 16, 0, 0);
@@ -1047,6 +1069,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     }
   };
   auto issue_b = [&](int stage) {
+    if constexpr (KRS_PP_PROBE == 2) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       __builtin_amdgcn_global_load_lds((gptr)bp[i], (lptr)(smem + stage * pp::STAGE + pp::PIECE + dma_off + i * 1024), 16,
@@ -1070,7 +1093,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     a_lane = wm * 8192 + lane_off;
     b_lane = pp::PIECE + (wn >> 1) * 8192 + (wn & 1) * 512 + lane_off;
   }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   auto load_frags = [&](int stage, int hk, u32x4(&fa)[4], u32x4(&fb)[2]) {
+    if constexpr (KRS_PP_PROBE == 1) return;
     const char* st = smem + stage * pp::STAGE;
     if constexpr (!TN) {
       const int x = hk * 32;
@@ -1079,19 +1104,19 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + (a_lane ^ x) + i * 2048);
     } else {
-      char* sw = const_cast<char*>(st) + hk * 4096;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint2 b0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(sw + b_lane + j * 256)));
-        const uint2 b1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(sw + b_lane + j * 256 + 1024)));
-        fb[j] = u32x4{b0.x, b0.y, b1.x, b1.y};
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint2 a0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(sw + a_lane + i * 256)));
-        const uint2 a1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(sw + a_lane + i * 256 + 1024)));
-        fa[i] = u32x4{a0.x, a0.y, a1.x, a1.y};
-      }
+      const uint32_t sa = lds_base + stage * pp::STAGE + hk * 4096 + a_lane, sb = lds_base + stage * pp::STAGE + hk * 4096 + b_lane;
+#define KRS_TR2(dst, base, off)                                                            \
+  {                                                                                        \
+    const u32x2 lo_ = pp_read_tr16<(off)>(base), hi_ = pp_read_tr16<(off) + 1024>(base);   \
+    dst = u32x4{lo_.x, lo_.y, hi_.x, hi_.y};                                               \
+  }
+      KRS_TR2(fb[0], sb, 0)
+      KRS_TR2(fb[1], sb, 256)
+      KRS_TR2(fa[0], sa, 0)
+      KRS_TR2(fa[1], sa, 256)
+      KRS_TR2(fa[2], sa, 512)
+      KRS_TR2(fa[3], sa, 768)
+#undef KRS_TR2
     }
   };
 
@@ -1105,6 +1130,11 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
   auto mfma8 = [&](const u32x4(&fa)[4], const u32x4(&fb)[2]) {
+    if constexpr (KRS_PP_PROBE == 1) return;
+    if constexpr (KRS_PP_PROBE == 3) {  // keep the fragment reads alive without the matrix pipes
+      asm volatile("" ::"v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fb[0]), "v"(fb[1]));
+      return;
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1117,48 +1147,96 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     __builtin_amdgcn_s_setprio(0);
   };
 
-  // prologue (the host guarantees nkb >= NSTG): A(0), B(0), ..., A(NSTG-3), B(NSTG-3), A(NSTG-2)
+  if constexpr (SCHED == 1) {
+    // PREFETCH schedule: no group stagger, one barrier per phase; the fragments of phase p+1 are read (into the
+    // other register set) before the MFMAs of phase p are issued, so LDS latency runs under the wave's own
+    // matrix work and both waves of a SIMD keep LDS reads in flight at the same time.  Pieces: A(kb+NSTG-1) is
+    // issued in phase 2kb, B(kb+NSTG-1) in phase 2kb+1 (the slot held block kb-1, whose last fragments every
+    // wave consumed before the barrier that closed phase 2kb-1); block kb+1 is waited for at the end of phase
+    // 2kb with the same counted vmcnt.
+    static_assert(SCHED != 1 || NSTG == 4, "the tail of the prefetch schedule is written for four stages");
+    const int64_t last = nkb - 1;
 #pragma unroll
-  for (int j = 0; j < NSTG - 2; ++j) {
-    issue_a(j);
-    issue_b(j);
-  }
-  issue_a(NSTG - 2);
-  constexpr int STEADY = 4 * NSTG - 10;  // DMA instructions of the 2*NSTG-5 pieces that may stay in flight
-  pp_vmcnt<STEADY>();
-  pp_barrier();
-  if (grp == 1) pp_barrier();  // rows 128..255 run one segment behind rows 0..127
-
-  int rd = 0, wa = NSTG - 1, wb = NSTG - 2;  // stages of block kb, of the A piece issued in its odd / the B piece in its even phase
-  const int64_t last = nkb - 1;
-  for (int64_t kb = 0; kb <= last; ++kb) {
-    u32x4 fa[4], fb[2];
-    // ---- phase 2kb ----
-    load_frags(rd, 0, fa, fb);
-    if (kb + NSTG - 2 <= last) issue_b(wb);
-    pp_barrier();
-    mfma8(fa, fb);
-    pp_barrier();
-    // ---- phase 2kb+1 ----
-    load_frags(rd, 1, fa, fb);
-    if (kb + NSTG - 1 <= last) {
-      issue_a(wa);
-      pp_vmcnt<STEADY>();
-    } else {
-      // tail: the pieces of blocks kb+2 .. last are all that is still in flight behind block kb+1
-      const int64_t rem = last - kb - 1;
-      if (rem >= 2) pp_vmcnt<8>();
-      else if (rem == 1) pp_vmcnt<4>();
-      else pp_vmcnt<0>();
+    for (int j = 0; j < NSTG - 1; ++j) {
+      issue_a(j);
+      issue_b(j);
     }
+    pp_vmcnt<4 * (NSTG - 2)>();
     pp_barrier();
-    mfma8(fa, fb);
+    u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
+    load_frags(0, 0, fa0, fb0);
+    int rd = 0, wr = NSTG - 1;
+    for (int64_t kb = 0; kb <= last; ++kb) {
+      const int nx = rd + 1 == NSTG ? 0 : rd + 1;
+      // ---- phase 2kb ----
+      load_frags(rd, 1, fa1, fb1);
+      const bool more = kb + NSTG - 1 <= last;
+      if (more) issue_a(wr);
+      if constexpr (TN) pp_lgkm_wait<12>(fa0, fb0);
+      mfma8(fa0, fb0);
+      if (more) pp_vmcnt<4 * NSTG - 10>();
+      else if (last - kb - 1 == 1) pp_vmcnt<4>();
+      else pp_vmcnt<0>();
+      pp_barrier();
+      // ---- phase 2kb+1 ----
+      if (kb < last) {
+        load_frags(nx, 0, fa0, fb0);
+        if (more) issue_b(wr);
+        if constexpr (TN) pp_lgkm_wait<12>(fa1, fb1);
+      } else {
+        if constexpr (TN) pp_lgkm_wait<0>(fa1, fb1);
+      }
+      mfma8(fa1, fb1);
+      pp_barrier();
+      rd = nx;
+      wr = wr + 1 == NSTG ? 0 : wr + 1;
+    }
+  } else {
+    // prologue (the host guarantees nkb >= NSTG): A(0), B(0), ..., A(NSTG-3), B(NSTG-3), A(NSTG-2)
+  #pragma unroll
+    for (int j = 0; j < NSTG - 2; ++j) {
+      issue_a(j);
+      issue_b(j);
+    }
+    issue_a(NSTG - 2);
+    constexpr int STEADY = 4 * NSTG - 10;  // DMA instructions of the 2*NSTG-5 pieces that may stay in flight
+    pp_vmcnt<STEADY>();
     pp_barrier();
-    rd = rd + 1 == NSTG ? 0 : rd + 1;
-    wa = wa + 1 == NSTG ? 0 : wa + 1;
-    wb = wb + 1 == NSTG ? 0 : wb + 1;
+    if (grp == 1) pp_barrier();  // rows 128..255 run one segment behind rows 0..127
+
+    int rd = 0, wa = NSTG - 1, wb = NSTG - 2;  // stages of block kb, of the A piece issued in its odd / the B piece in its even phase
+    const int64_t last = nkb - 1;
+    for (int64_t kb = 0; kb <= last; ++kb) {
+      u32x4 fa[4], fb[2];
+      // ---- phase 2kb ----
+      load_frags(rd, 0, fa, fb);
+      if (kb + NSTG - 2 <= last) issue_b(wb);
+      pp_barrier();
+      if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
+      mfma8(fa, fb);
+      pp_barrier();
+      // ---- phase 2kb+1 ----
+      load_frags(rd, 1, fa, fb);
+      if (kb + NSTG - 1 <= last) {
+        issue_a(wa);
+        pp_vmcnt<STEADY>();
+      } else {
+        // tail: the pieces of blocks kb+2 .. last are all that is still in flight behind block kb+1
+        const int64_t rem = last - kb - 1;
+        if (rem >= 2) pp_vmcnt<8>();
+        else if (rem == 1) pp_vmcnt<4>();
+        else pp_vmcnt<0>();
+      }
+      pp_barrier();
+      if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
+      mfma8(fa, fb);
+      pp_barrier();
+      rd = rd + 1 == NSTG ? 0 : rd + 1;
+      wa = wa + 1 == NSTG ? 0 : wa + 1;
+      wb = wb + 1 == NSTG ? 0 : wb + 1;
+    }
+    if (grp == 0) pp_barrier();
   }
-  if (grp == 0) pp_barrier();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
 }
@@ -1251,7 +1329,7 @@ int gemm_pipe() {
   if (g_pipe < 0) {
     const char* e = getenv("KRS_GEMM_PIPE");
     g_pipe = e ? atoi(e) : 4;
-    if (g_pipe != 0 && g_pipe != 4 && g_pipe != 5) g_pipe = 4;
+    if (g_pipe != 0 && g_pipe != 4 && g_pipe != 5 && g_pipe != 6) g_pipe = 4;
   }
   return g_pipe;
 }
@@ -1342,9 +1420,9 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
       // on the two-stage loop: nothing to hide there, and the ring pays two barriers per 8 MFMA)
       if (pipe && p.k % 32 == 0 && !(epi == 2 && p.k <= 1024)) {
         const int nt_ = (int)ceil_div(p.n, 256);
-#define KRS_PP_LAUNCH(NS, EP)                                                                        \
+#define KRS_PP_LAUNCH(NS, EP, SC)                                                                    \
   {                                                                                                  \
-    auto kern = gemm_pp256_kernel<false, NS, EP>;                                                    \
+    auto kern = gemm_pp256_kernel<false, NS, EP, SC>;                                                \
     static bool attr_set = false;                                                                    \
     if (!attr_set) {                                                                                 \
       KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
@@ -1353,14 +1431,15 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     }                                                                                                \
     hipLaunchKernelGGL(kern, grid256, dim3(512), NS * pp::STAGE, st, p, 0, nt_);                     \
   }
-#define KRS_PP_CASE(NS)                                                                              \
+#define KRS_PP_CASE(NS, SC)                                                                          \
   {                                                                                                  \
-    if (epi == 1) KRS_PP_LAUNCH(NS, 1)                                                               \
-    else if (epi == 2) KRS_PP_LAUNCH(NS, 2)                                                          \
-    else KRS_PP_LAUNCH(NS, 0)                                                                        \
+    if (epi == 1) KRS_PP_LAUNCH(NS, 1, SC)                                                           \
+    else if (epi == 2) KRS_PP_LAUNCH(NS, 2, SC)                                                      \
+    else KRS_PP_LAUNCH(NS, 0, SC)                                                                    \
   }
-        if (pipe == 5) KRS_PP_CASE(5)
-        else KRS_PP_CASE(4)
+        if (pipe == 5) KRS_PP_CASE(5, 0)
+        else if (pipe == 6) KRS_PP_CASE(4, 1)
+        else KRS_PP_CASE(4, 0)
 #undef KRS_PP_CASE
 #undef KRS_PP_LAUNCH
         KRS_CHECK_LAUNCH("gemm_pp256_kernel");
@@ -1413,9 +1492,9 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
       const dim3 grid_tn((unsigned)(ceil_div((int64_t)p.splits * mt_ * nt_, 8) * 8));
       const int pipe = gemm_pipe();
       if (pipe && p.k_per_split >= 256) {
-#define KRS_PP_TN_LAUNCH(NS)                                                                         \
+#define KRS_PP_TN_LAUNCH(NS, SC)                                                                     \
   {                                                                                                  \
-    auto kern = gemm_pp256_kernel<true, NS, 0>;                                                      \
+    auto kern = gemm_pp256_kernel<true, NS, 0, SC>;                                                  \
     static bool attr_set = false;                                                                    \
     if (!attr_set) {                                                                                 \
       KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
@@ -1424,8 +1503,9 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     }                                                                                                \
     hipLaunchKernelGGL(kern, grid_tn, dim3(512), NS * pp::STAGE, st, p, mt_, nt_);                   \
   }
-        if (pipe == 5) KRS_PP_TN_LAUNCH(5)
-        else KRS_PP_TN_LAUNCH(4)
+        if (pipe == 5) KRS_PP_TN_LAUNCH(5, 0)
+        else if (pipe == 6) KRS_PP_TN_LAUNCH(4, 1)
+        else KRS_PP_TN_LAUNCH(4, 0)
 #undef KRS_PP_TN_LAUNCH
         KRS_CHECK_LAUNCH("gemm_pp256_kernel (K-strided operands)");
         return KRS_OK;
@@ -1694,7 +1774,7 @@ using namespace krs;
 
 extern "C" int krs_gemm_set_option(int key, int value) {
   if (key == KRS_GEMM_OPT_PIPELINE) {
-    KRS_REQUIRE(value == 0 || value == 4 || value == 5, "krs_gemm_set_option: pipeline must be 0, 4 or 5");
+    KRS_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6, "krs_gemm_set_option: pipeline must be 0, 4, 5 or 6");
     g_pipe = value;
     return KRS_OK;
   }

@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
   Buf bias = alloc(1, d, d, 4);
   fill(x0, 1, 1.0f); fill(x, 2, 1.0f); fill(g, 3, 1.0f);
   fill(Ut, 4, 0.05f); fill(Vt, 5, 0.05f); fill(U, 6, 0.05f); fill(V, 7, 0.05f);
-  const int pipes[] = {0, 4, 5};
+  const int pipes[] = {0, 4, 6};
   constexpr int NP = 3;
   // outputs per pipeline
   Buf h[NP], y[NP], u[NP], dz[NP], dx0[NP], dk[NP], dh[NP], du[NP], dx[NP];
