@@ -267,6 +267,16 @@ __device__ __forceinline__ void store_kstrided(char* tile, const u32x4 (&r)[4]) 
 // epi_prefetch issues a chunk's x0 / x / R loads (specialised forms EPI 1 / 2), epi_process stages
 // the chunk's accumulators and writes it; callers order them so that a chunk's loads are in
 // flight while the previous chunk is processed.
+// After a loop that waited for its LDS-DMA with opaque assembly, hipcc still believes the DMA may be in flight
+// and fences EVERY later LDS read with `s_waitcnt vmcnt(0)` -- in the epilogue that made each 16-byte store wait
+// for the acknowledgement of all earlier stores of the wave.  A counted wait it can see (free at run time: the
+// loop has retired everything but the ALLOW youngest loads) tells it that the DMA has landed.
+template <int ALLOW>
+__device__ __forceinline__ void lds_dma_retired() {
+  static_assert(ALLOW >= 0 && ALLOW < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((ALLOW & 15) | ((ALLOW >> 4) << 14) | (7 << 4) | (15 << 8));  // vmcnt only
+}
+
 struct EpiOperands {
   uint4 ex[4], ex0[4];
 };
@@ -381,6 +391,20 @@ __device__ __forceinline__ void gemm_epilogue_wave128(const GemmParams& p, f32x1
   epi_prefetch<EPI>(p, o1, wm0 + 96, wn0);
   epi_process<EPI>(p, acc[1][0], o0, stage, wm0 + 64, wn0, split);
   epi_process<EPI>(p, acc[1][1], o1, stage, wm0 + 96, wn0, split);
+}
+
+// the same with the operands of the first NPFC chunks already requested by the caller (under the tail of its
+// main loop): 4 = all of them (residual form: one operand), 2 = the first two (cross form: x0 and x)
+template <int EPI, int NPFC>
+__device__ __forceinline__ void gemm_epilogue_wave128_pre(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
+                                                          int64_t wm0, int64_t wn0, int split, EpiOperands (&o)[4]) {
+  static_assert(NPFC == 2 || NPFC == 4, "two or four chunks of operands are fetched ahead");
+  epi_process<EPI>(p, acc[0][0], o[0], stage, wm0, wn0, split);
+  if constexpr (NPFC == 2) epi_prefetch<EPI>(p, o[2], wm0 + 64, wn0);
+  epi_process<EPI>(p, acc[0][1], o[1], stage, wm0 + 32, wn0, split);
+  if constexpr (NPFC == 2) epi_prefetch<EPI>(p, o[3], wm0 + 96, wn0);
+  epi_process<EPI>(p, acc[1][0], o[2], stage, wm0 + 64, wn0, split);
+  epi_process<EPI>(p, acc[1][1], o[3], stage, wm0 + 96, wn0, split);
 }
 
 // 128x128 workgroup tile, 4 waves as 2x2
@@ -594,6 +618,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
     __syncthreads();                                   // and every wave is done with tile t
   }
+  lds_dma_retired<0>();
   gemm_epilogue<EPI>(p, acc, smem, m0, n0, 0);
 }
 
@@ -703,6 +728,7 @@ __global__ __launch_bounds__(512) void gemm_glds256_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
     __syncthreads();                                   // and every wave is done with tile t
   }
+  lds_dma_retired<0>();
   float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   gemm_epilogue_wave128<EPI>(p, acc, stage, m0 + wm * 128, n0 + wn * 64, 0);
 }
@@ -817,6 +843,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
     __syncthreads();                                   // and every wave is done with tile t
   }
+  lds_dma_retired<0>();
   gemm_epilogue<EPI>(p, acc, smem, m0, n0, split);
 }
 
@@ -925,6 +952,7 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
     __syncthreads();                                   // and every wave is done with tile t
   }
+  lds_dma_retired<0>();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
 }
@@ -957,7 +985,7 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // epilogue runs under the other's main loop (467 / 344 us against 450 / 323: 1.5x the operand bytes per flop cost
 // more than the overlap returns).
 #ifndef KRS_PP_PROBE
-#define KRS_PP_PROBE 0  // development builds only (scripts/exp): 1 = DMA stream alone, 2 = LDS reads + MFMA alone, 3 = DMA + LDS reads
+#define KRS_PP_PROBE 0  // development builds only (scripts/exp): 1 = DMA stream alone, 2 = LDS reads + MFMA alone, 3 = DMA + LDS reads, 4 = epilogue alone
 #endif
 namespace pp {
 constexpr int PIECE = 16384;
@@ -986,6 +1014,21 @@ __device__ __forceinline__ void pp_lgkm_wait(u32x4 (&fa)[4], u32x4 (&fb)[2]) {
   asm volatile("s_waitcnt lgkmcnt(%6)"
                : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1])
                : "n"(N));
+}
+// fragment Q of a phase (0, 1: the B fragments, 2..5: the A fragments) from the stage/half addresses sa / sb
+template <bool TN, int Q>
+__device__ __forceinline__ void pp_read_frag(uint32_t sa, uint32_t sb, u32x4 (&fa)[4], u32x4 (&fb)[2]) {
+  constexpr int idx = Q < 2 ? Q : Q - 2;
+  const uint32_t base = Q < 2 ? sb : sa;
+  u32x4 v;
+  if constexpr (TN) {
+    const u32x2 lo = pp_read_tr16<idx * 256>(base), hi = pp_read_tr16<idx * 256 + 1024>(base);
+    v = u32x4{lo.x, lo.y, hi.x, hi.y};
+  } else {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(idx * 2048));
+  }
+  if constexpr (Q < 2) fb[idx] = v;
+  else fa[idx] = v;
 }
 template <int N>
 __device__ __forceinline__ void pp_vmcnt() {
@@ -1129,6 +1172,10 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
+  // epilogue operands fetched under the tail of the main loop (ping-pong schedule): chunks, load instructions
+  constexpr int NPFC = SCHED != 0 ? 0 : EPI == 2 ? 4 : EPI == 1 ? 2 : 0;
+  constexpr int NPF = NPFC * (EPI == 1 ? 8 : 4);
+  EpiOperands opf[4];
   auto mfma8 = [&](const u32x4(&fa)[4], const u32x4(&fb)[2]) {
     if constexpr (KRS_PP_PROBE == 1) return;
     if constexpr (KRS_PP_PROBE == 3) {  // keep the fragment reads alive without the matrix pipes
@@ -1147,13 +1194,16 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     __builtin_amdgcn_s_setprio(0);
   };
 
-  if constexpr (SCHED == 1) {
-    // PREFETCH schedule: no group stagger, one barrier per phase; the fragments of phase p+1 are read (into the
-    // other register set) before the MFMAs of phase p are issued, so LDS latency runs under the wave's own
-    // matrix work and both waves of a SIMD keep LDS reads in flight at the same time.  Pieces: A(kb+NSTG-1) is
-    // issued in phase 2kb, B(kb+NSTG-1) in phase 2kb+1 (the slot held block kb-1, whose last fragments every
-    // wave consumed before the barrier that closed phase 2kb-1); block kb+1 is waited for at the end of phase
-    // 2kb with the same counted vmcnt.
+  if constexpr (KRS_PP_PROBE == 4) {
+    // (probe: no main loop at all)
+  } else if constexpr (SCHED == 1) {
+    // PREFETCH schedule: no group stagger, one barrier per phase.  The fragments of phase p+1 are read into a
+    // second register set WHILE the MFMAs of phase p issue -- one fragment read behind each of the first six
+    // MFMAs (all reads opaque assembly, every step pinned with sched_barrier) -- so LDS latency and the low
+    // per-wave issue rate of the 8-byte transposing reads run under matrix work, and both waves of a SIMD keep
+    // reads in flight at the same time.  Pieces: A(kb+NSTG-1) is issued at the head of phase 2kb, B(kb+NSTG-1)
+    // at the head of phase 2kb+1 (the slot held block kb-1, whose last fragments every wave consumed before the
+    // barrier that closed phase 2kb-1); block kb+1 is waited for at the end of phase 2kb (counted vmcnt).
     static_assert(SCHED != 1 || NSTG == 4, "the tail of the prefetch schedule is written for four stages");
     const int64_t last = nkb - 1;
 #pragma unroll
@@ -1163,34 +1213,64 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     }
     pp_vmcnt<4 * (NSTG - 2)>();
     pp_barrier();
+    auto frag_addr = [&](int stage, int hk, uint32_t& sa, uint32_t& sb) {
+      if constexpr (!TN) {
+        sa = lds_base + stage * pp::STAGE + (a_lane ^ (hk * 32));
+        sb = lds_base + stage * pp::STAGE + (b_lane ^ (hk * 32));
+      } else {
+        sa = lds_base + stage * pp::STAGE + hk * 4096 + a_lane;
+        sb = lds_base + stage * pp::STAGE + hk * 4096 + b_lane;
+      }
+    };
+    auto mfma1 = [&](int i, int j, const u32x4(&fa)[4], const u32x4(&fb)[2]) {
+      f32x16& d = acc[i >> 1][i & 1][j];
+      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), d, 0, 0, 0);
+    };
+#define KRS_PF_STEP(I, J, CA, CB, READ) \
+  mfma1(I, J, CA, CB);                 \
+  READ;                                \
+  __builtin_amdgcn_sched_barrier(0);
+#define KRS_PF_PHASE(CA, CB, NA, NB)                                   \
+  pp_lgkm_wait<0>(CA, CB);                                             \
+  KRS_PF_STEP(0, 0, CA, CB, (pp_read_frag<TN, 0>(sa, sb, NA, NB)))     \
+  KRS_PF_STEP(0, 1, CA, CB, (pp_read_frag<TN, 1>(sa, sb, NA, NB)))     \
+  KRS_PF_STEP(1, 0, CA, CB, (pp_read_frag<TN, 2>(sa, sb, NA, NB)))     \
+  KRS_PF_STEP(1, 1, CA, CB, (pp_read_frag<TN, 3>(sa, sb, NA, NB)))     \
+  KRS_PF_STEP(2, 0, CA, CB, (pp_read_frag<TN, 4>(sa, sb, NA, NB)))     \
+  KRS_PF_STEP(2, 1, CA, CB, (pp_read_frag<TN, 5>(sa, sb, NA, NB)))     \
+  KRS_PF_STEP(3, 0, CA, CB, (void)0)                                   \
+  KRS_PF_STEP(3, 1, CA, CB, (void)0)
     u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
-    load_frags(0, 0, fa0, fb0);
+    uint32_t sa, sb;
+    frag_addr(0, 0, sa, sb);
+    pp_read_frag<TN, 0>(sa, sb, fa0, fb0);
+    pp_read_frag<TN, 1>(sa, sb, fa0, fb0);
+    pp_read_frag<TN, 2>(sa, sb, fa0, fb0);
+    pp_read_frag<TN, 3>(sa, sb, fa0, fb0);
+    pp_read_frag<TN, 4>(sa, sb, fa0, fb0);
+    pp_read_frag<TN, 5>(sa, sb, fa0, fb0);
     int rd = 0, wr = NSTG - 1;
     for (int64_t kb = 0; kb <= last; ++kb) {
       const int nx = rd + 1 == NSTG ? 0 : rd + 1;
-      // ---- phase 2kb ----
-      load_frags(rd, 1, fa1, fb1);
       const bool more = kb + NSTG - 1 <= last;
+      // ---- phase 2kb ----
       if (more) issue_a(wr);
-      if constexpr (TN) pp_lgkm_wait<12>(fa0, fb0);
-      mfma8(fa0, fb0);
+      frag_addr(rd, 1, sa, sb);
+      KRS_PF_PHASE(fa0, fb0, fa1, fb1)
       if (more) pp_vmcnt<4 * NSTG - 10>();
       else if (last - kb - 1 == 1) pp_vmcnt<4>();
       else pp_vmcnt<0>();
       pp_barrier();
       // ---- phase 2kb+1 ----
-      if (kb < last) {
-        load_frags(nx, 0, fa0, fb0);
-        if (more) issue_b(wr);
-        if constexpr (TN) pp_lgkm_wait<12>(fa1, fb1);
-      } else {
-        if constexpr (TN) pp_lgkm_wait<0>(fa1, fb1);
-      }
-      mfma8(fa1, fb1);
+      if (more) issue_b(wr);
+      frag_addr(nx, 0, sa, sb);   // (behind the last block: a stale slot, read into registers nobody uses)
+      KRS_PF_PHASE(fa1, fb1, fa0, fb0)
       pp_barrier();
       rd = nx;
       wr = wr + 1 == NSTG ? 0 : wr + 1;
     }
+#undef KRS_PF_PHASE
+#undef KRS_PF_STEP
   } else {
     // prologue (the host guarantees nkb >= NSTG): A(0), B(0), ..., A(NSTG-3), B(NSTG-3), A(NSTG-2)
   #pragma unroll
@@ -1206,39 +1286,70 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
 
     int rd = 0, wa = NSTG - 1, wb = NSTG - 2;  // stages of block kb, of the A piece issued in its odd / the B piece in its even phase
     const int64_t last = nkb - 1;
-    for (int64_t kb = 0; kb <= last; ++kb) {
+    auto advance = [&]() {
+      rd = rd + 1 == NSTG ? 0 : rd + 1;
+      wa = wa + 1 == NSTG ? 0 : wa + 1;
+      wb = wb + 1 == NSTG ? 0 : wb + 1;
+    };
+    int64_t kb = 0;
+    for (; kb + NSTG - 1 <= last; ++kb) {  // steady state: one piece issued per phase
       u32x4 fa[4], fb[2];
       // ---- phase 2kb ----
       load_frags(rd, 0, fa, fb);
-      if (kb + NSTG - 2 <= last) issue_b(wb);
+      issue_b(wb);
       pp_barrier();
       if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
       mfma8(fa, fb);
       pp_barrier();
       // ---- phase 2kb+1 ----
       load_frags(rd, 1, fa, fb);
-      if (kb + NSTG - 1 <= last) {
-        issue_a(wa);
-        pp_vmcnt<STEADY>();
-      } else {
-        // tail: the pieces of blocks kb+2 .. last are all that is still in flight behind block kb+1
-        const int64_t rem = last - kb - 1;
-        if (rem >= 2) pp_vmcnt<8>();
-        else if (rem == 1) pp_vmcnt<4>();
-        else pp_vmcnt<0>();
-      }
+      issue_a(wa);
+      pp_vmcnt<STEADY>();
       pp_barrier();
       if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
       mfma8(fa, fb);
       pp_barrier();
-      rd = rd + 1 == NSTG ? 0 : rd + 1;
-      wa = wa + 1 == NSTG ? 0 : wa + 1;
-      wb = wb + 1 == NSTG ? 0 : wb + 1;
+      advance();
+    }
+    // tail: the last NSTG-1 blocks; only B(last) is still to be issued.  The epilogue's operands (residual form:
+    // all four 32-row chunks of R; cross form: x0 and x of the first two) are requested here, behind the last
+    // piece, so that their HBM latency runs under the remaining 2*(NSTG-1) phases instead of in front of the
+    // epilogue; they are younger than every piece, so the counted waits simply allow NPF more loads in flight.
+#pragma unroll
+    for (int t = 0; t < NSTG - 1; ++t) {
+      u32x4 fa[4], fb[2];
+      load_frags(rd, 0, fa, fb);
+      if (t == 0) issue_b(wb);
+      pp_barrier();
+      if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
+      mfma8(fa, fb);
+      pp_barrier();
+      load_frags(rd, 1, fa, fb);
+      if constexpr (NPFC > 0) {
+        if (t == 0) {
+#pragma unroll
+          for (int c = 0; c < NPFC; ++c) epi_prefetch<EPI>(p, opf[c], m0 + wm * 128 + c * 32, n0 + wn * 64);
+        }
+      }
+      // block kb+1 must have landed; behind it only the pieces of blocks kb+2 .. last (rem = NSTG-3-t of them)
+      // and the epilogue operands are still in flight
+      if (NSTG - 3 - t >= 2) pp_vmcnt<8 + NPF>();
+      else if (NSTG - 3 - t == 1) pp_vmcnt<4 + NPF>();
+      else if (NSTG - 3 - t == 0) pp_vmcnt<NPF>();
+      pp_barrier();
+      if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
+      mfma8(fa, fb);
+      pp_barrier();
+      advance();
     }
     if (grp == 0) pp_barrier();
   }
+  lds_dma_retired<NPF>();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
+  if constexpr (NPFC > 0 && SCHED == 0 && KRS_PP_PROBE != 4)
+    gemm_epilogue_wave128_pre<EPI, NPFC>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split, opf);
+  else
+    gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
 }
 
 // Weight gradients with one tiny dimension (C = A^T B, both operands K-strided, min(M, N) <= 16, long K):
@@ -1418,7 +1529,7 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
       const int pipe = gemm_pipe();
       // (the residual-add form with a short K -- dx = dh U^T + g, cache-resident operands -- measured 4 % faster
       // on the two-stage loop: nothing to hide there, and the ring pays two barriers per 8 MFMA)
-      if (pipe && p.k % 32 == 0 && !(epi == 2 && p.k <= 1024)) {
+      if (pipe && p.k % 32 == 0) {
         const int nt_ = (int)ceil_div(p.n, 256);
 #define KRS_PP_LAUNCH(NS, EP, SC)                                                                    \
   {                                                                                                  \
