@@ -333,6 +333,16 @@ int krs_dot_interaction_bwd(const void* const* feats, const int64_t* ld, int n_f
                             const void* grad_out, int64_t grad_ld,
                             void* const* grad_feats, const int64_t* grad_feat_ld,
                             void* stream);
+/* The same with gradients that are already there: feature f with bit f of accumulate_mask set receives
+ * grad_feats[f] + dX[f] (fp32 sum of the stored value and the new term, one rounding); the others are
+ * overwritten.  Lets the gradient of the interaction join a gradient buffer the features' other consumer has
+ * already written (the concat of the same features: examples/ml_perf/model.py:204-207) without a separate add. */
+int krs_dot_interaction_bwd_accumulate(const void* const* feats, const int64_t* ld, int n_feats,
+                                       int64_t batch, int dim, int dtype,
+                                       int self_interaction, int skip_gather,
+                                       const void* grad_out, int64_t grad_ld,
+                                       void* const* grad_feats, const int64_t* grad_feat_ld,
+                                       uint64_t accumulate_mask, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * K5  MOD bucketise for row-sharded tables

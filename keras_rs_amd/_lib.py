@@ -76,6 +76,7 @@ SYMBOLS = [
     "krs_colsum",
     "krs_dot_interaction_fwd",
     "krs_dot_interaction_bwd",
+    "krs_dot_interaction_bwd_accumulate",
     "krs_mod_bucketize_workspace_bytes",
     "krs_mod_bucketize",
     "krs_shard_route_workspace_bytes",

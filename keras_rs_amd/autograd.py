@@ -78,6 +78,24 @@ class Dx0Relay:
                 and a.dtype == x0.dtype and a._version == x0._version)
 
 
+class SlabGradRelay:
+    """Lets the gradient of DotInteraction join the gradient of the concat of the same features inside the
+    DotInteraction backward kernel instead of in a separate 1.4 GB add.  `layers.concat_features([dense,
+    *embeddings])` returns the lookup slab itself, so the gradient of the concat IS the gradient of the slab: its
+    backward (SlabFillFn) leaves that matrix here; when DotInteraction's backward runs later in the same pass --
+    it does whenever the interaction was called before the concat, as in a DLRM forward -- and its trailing
+    inputs are exactly the slab's feature views, it adds their gradients into the matrix
+    (krs_dot_interaction_bwd_accumulate) and returns no gradient for them.  The leading inputs (the bottom-MLP
+    output) keep their ordinary gradient tensors, so whatever else consumes them is unaffected.  Not used when
+    the concat result retains its gradient or has hooks (its .grad would show the joined value)."""
+
+    __slots__ = ("buf", "task", "out_ref")
+    joined = 0   # times the in-kernel path was taken (read by the tests)
+
+    def __init__(self):
+        self.buf, self.task, self.out_ref = None, -1, None
+
+
 class CrossLayerFn(torch.autograd.Function):
     """y = x0 * (act(h @ K + b) + diag * x) + x,  h = x (full rank) or x @ U (low rank).
 
@@ -220,20 +238,33 @@ class CrossEpilogueFn(torch.autograd.Function):
 
 
 class DotInteractionFn(torch.autograd.Function):
-    """DotInteraction.call (dot_interaction.py:170-203) and its gradient."""
+    """DotInteraction.call (dot_interaction.py:170-203) and its gradient.
+    relay / n_heads: see SlabGradRelay -- feats[n_heads:] are the feature views of the relay's slab, in order."""
 
     @staticmethod
-    def forward(ctx, self_interaction, skip_gather, *feats):
+    def forward(ctx, self_interaction, skip_gather, relay, n_heads, *feats):
         ctx.save_for_backward(*feats)
         ctx.flags = (self_interaction, skip_gather)
+        ctx.relay, ctx.n_heads = relay, n_heads
         return D.dot_interaction_fwd(feats, self_interaction, skip_gather)
 
     @staticmethod
     def backward(ctx, g):
         feats = ctx.saved_tensors
         si, sg = ctx.flags
+        relay = ctx.relay
+        if relay is not None and relay.buf is not None:
+            buf, task = relay.buf, torch._C._current_graph_task_id()
+            n, (batch, dim) = len(feats), feats[0].shape
+            if (relay.task == task and task != -1 and tuple(buf.shape) == (batch, n * dim) and buf.is_contiguous()
+                    and buf.dtype == feats[0].dtype and g.dtype == buf.dtype):
+                relay.buf = None
+                SlabGradRelay.joined += 1
+                mask = ((1 << n) - 1) & ~((1 << ctx.n_heads) - 1)
+                grads = D.dot_interaction_bwd(feats, g, si, sg, into=buf, accumulate_mask=mask)
+                return (None, None, None, None, *grads)
         grads = D.dot_interaction_bwd(feats, g, si, sg)
-        return (None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class EmbedBagFn(torch.autograd.Function):
@@ -334,9 +365,10 @@ class SlabFillFn(torch.autograd.Function):
     The write goes through `.data`, so tensors that saved views of the slab keep their version."""
 
     @staticmethod
-    def forward(ctx, slab, *heads):
+    def forward(ctx, slab, relay, *heads):
         col = 0
         ctx.cols = []
+        ctx.relay = relay
         with torch.no_grad():
             for h in heads:
                 w = h.shape[1]
@@ -347,4 +379,10 @@ class SlabFillFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (g,) + tuple(g[:, a:b] for a, b in ctx.cols)
+        relay = ctx.relay
+        if relay is not None:
+            out = relay.out_ref() if relay.out_ref is not None else None
+            plain = out is not None and not out.retains_grad and not out._backward_hooks
+            task = torch._C._current_graph_task_id()
+            relay.buf, relay.task = (g, task) if (plain and task != -1 and g.is_contiguous()) else (None, -1)
+        return (g, None) + tuple(g[:, a:b] for a, b in ctx.cols)

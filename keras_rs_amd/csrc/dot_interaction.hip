@@ -39,6 +39,7 @@ struct DotParams {
   int skip_gather;
   void* out;          // forward output / backward grad_out
   int64_t out_ld;
+  uint32_t acc_mask;  // backward: bit f set = gfeat[f] already holds a gradient, add to it
 };
 
 __device__ __forceinline__ bool pair_kept(int i, int j, int self_inter) { return self_inter ? j <= i : j < i; }
@@ -126,7 +127,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __host__ __device__ constexpr int tri_cols(int rows, bool self) { return self ? rows * (rows + 1) / 2 : rows * (rows - 1) / 2; }
 
-template <int ES, int FR, bool SELF, bool MULTI>  // MULTI: several samples per wave (D < 128)
+// ACC: features whose bit is set in p.acc_mask receive `existing + dX` (fp32 sum, one rounding): the existing
+// values are requested together with the sample's rows (same clamped addresses), one iteration ahead.
+template <int ES, int FR, bool SELF, bool MULTI, bool ACC>  // MULTI: several samples per wave (D < 128)
 __global__ __launch_bounds__(64) void dot_bwd_valu_kernel(const DotParams p, int lps_log2, int spw) {
   constexpr int GSTRIDE = tri_cols(FR, SELF) + 1;                    // LDS floats per sample
   constexpr int NG = MULTI ? 16 : (tri_cols(FR, SELF) + 63) / 64;    // gradient elements per lane in flight
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(64) void dot_bwd_valu_kernel(const DotParams p, int
   }
 
   raw_t xr[FR];
+  raw_t ar[ACC ? FR : 1];
   gelem_t gr[NG];
   auto issue = [&](int64_t it) {
     const int64_t k = it / chunks;
@@ -191,6 +195,11 @@ __global__ __launch_bounds__(64) void dot_bwd_valu_kernel(const DotParams p, int
       const u32x4 e = tab[j];
       const uint64_t addr = (((uint64_t)e[1] << 32) | e[0]) + (uint64_t)bc * e[2] + dc * ES;
       xr[j] = *reinterpret_cast<const raw_t __attribute__((address_space(1)))*>(addr);
+      if constexpr (ACC) {
+        const u32x4 ge = tab[32 + j];
+        const uint64_t gaddr = (((uint64_t)ge[1] << 32) | ge[0]) + (uint64_t)bc * ge[2] + dc * ES;
+        ar[j] = *reinterpret_cast<const raw_t __attribute__((address_space(1)))*>(gaddr);
+      }
     }
   };
 
@@ -223,8 +232,13 @@ __global__ __launch_bounds__(64) void dot_bwd_valu_kernel(const DotParams p, int
       }
     }
     f32x2 x[FR], acc[FR];
+    raw_t ac[ACC ? FR : 1];  // this iteration's existing gradients (ar is re-filled below)
 #pragma unroll
     for (int j = 0; j < FR; ++j) {
+      if constexpr (ACC) {
+        ac[j] = ar[j];
+        asm volatile("" : "+v"(ac[j]));
+      }
       if constexpr (ES == 2) x[j] = f32x2{__uint_as_float(xr[j] << 16), __uint_as_float(xr[j] & 0xffff0000u)};
       else x[j] = xr[j];
       // pin the unpacked value here: left alone, the compiler sinks the unpack into the FMA section
@@ -259,6 +273,12 @@ __global__ __launch_bounds__(64) void dot_bwd_valu_kernel(const DotParams p, int
 #pragma unroll
     for (int i = 0; i < FR; ++i) {
       if (i < F && act) {
+        if constexpr (ACC) {
+          if ((p.acc_mask >> i) & 1u) {  // wave-uniform
+            if constexpr (ES == 2) acc[i] += f32x2{__uint_as_float(ac[i] << 16), __uint_as_float(ac[i] & 0xffff0000u)};
+            else acc[i] += ac[i];
+          }
+        }
         const u32x4 e = tab[32 + i];
         const uint64_t dst = (((uint64_t)e[1] << 32) | e[0]) + (uint64_t)(uint32_t)b * e[2] + d * ES;
         if constexpr (ES == 2)
@@ -273,7 +293,10 @@ __global__ __launch_bounds__(64) void dot_bwd_valu_kernel(const DotParams p, int
 template <int ES, int FR, bool SELF, bool MULTI>
 void launch_dot_bwd(const DotParams& p, int lps_log2, int spw, unsigned blocks, hipStream_t st) {
   const size_t lds = 64 * 16 + (size_t)2 * spw * (tri_cols(FR, SELF) + 1) * sizeof(float);  // table + double buffer
-  hipLaunchKernelGGL((dot_bwd_valu_kernel<ES, FR, SELF, MULTI>), dim3(blocks), dim3(64), lds, st, p, lps_log2, spw);
+  if (p.acc_mask)
+    hipLaunchKernelGGL((dot_bwd_valu_kernel<ES, FR, SELF, MULTI, true>), dim3(blocks), dim3(64), lds, st, p, lps_log2, spw);
+  else
+    hipLaunchKernelGGL((dot_bwd_valu_kernel<ES, FR, SELF, MULTI, false>), dim3(blocks), dim3(64), lds, st, p, lps_log2, spw);
 }
 
 // ---- plain kernels (any D / alignment, F <= 64); the pointer tables travel as kernel arguments ----
@@ -291,6 +314,7 @@ struct DotGenericParams {
   void* out;
   int64_t out_ld;
   int dtype;
+  uint64_t acc_mask;
 };
 
 __global__ __launch_bounds__(256) void dot_fwd_generic_kernel(const DotGenericParams p) {
@@ -326,6 +350,7 @@ __global__ __launch_bounds__(256) void dot_bwd_generic_kernel(const DotGenericPa
         gs += ld_elem(p.out, p.dtype, b * p.out_ld + pair_col(j, i, F, p.self_inter, p.skip_gather));
       acc = fmaf(gs, ld_elem(p.feat[j], p.dtype, b * p.ld[j] + c), acc);
     }
+    if ((p.acc_mask >> i) & 1ull) acc += ld_elem(p.gfeat[i], p.dtype, b * p.gld[i] + c);
     st_elem(p.gfeat[i], p.dtype, b * p.gld[i] + c, acc);
   }
 }
@@ -389,7 +414,17 @@ extern "C" int krs_dot_interaction_bwd(const void* const* feats, const int64_t* 
                                        int dim, int dtype, int self_interaction, int skip_gather,
                                        const void* grad_out, int64_t grad_ld, void* const* grad_feats,
                                        const int64_t* grad_feat_ld, void* stream) {
+  return krs_dot_interaction_bwd_accumulate(feats, ld, n_feats, batch, dim, dtype, self_interaction, skip_gather,
+                                            grad_out, grad_ld, grad_feats, grad_feat_ld, 0, stream);
+}
+
+extern "C" int krs_dot_interaction_bwd_accumulate(const void* const* feats, const int64_t* ld, int n_feats,
+                                                  int64_t batch, int dim, int dtype, int self_interaction,
+                                                  int skip_gather, const void* grad_out, int64_t grad_ld,
+                                                  void* const* grad_feats, const int64_t* grad_feat_ld,
+                                                  uint64_t accumulate_mask, void* stream) {
   if (int rc = check_args(feats, ld, n_feats, batch, dim, dtype, grad_out)) return rc;
+  if (n_feats < 64) accumulate_mask &= (uint64_t(1) << n_feats) - 1;
   KRS_REQUIRE(grad_feats && grad_feat_ld, "dot_interaction_bwd: null gradient outputs");
   if (batch == 0) return KRS_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -408,6 +443,7 @@ extern "C" int krs_dot_interaction_bwd(const void* const* feats, const int64_t* 
     }
     p.n_feats = n_feats; p.batch = batch; p.dim = dim; p.self_inter = self_interaction != 0;
     p.skip_gather = skip_gather != 0; p.out = const_cast<void*>(grad_out); p.out_ld = grad_ld;
+    p.acc_mask = (uint32_t)accumulate_mask;
     const int ncols = skip_gather ? n_feats * n_feats : tri_cols(n_feats, self_interaction != 0);
     int lps_log2 = 0;
     while ((2 << lps_log2) < dim && lps_log2 < 6) ++lps_log2;     // lanes per sample: dim/2 up to 64
@@ -438,6 +474,7 @@ extern "C" int krs_dot_interaction_bwd(const void* const* feats, const int64_t* 
   }
   g.n_feats = n_feats; g.batch = batch; g.dim = dim; g.self_inter = self_interaction != 0;
   g.skip_gather = skip_gather != 0; g.out = const_cast<void*>(grad_out); g.out_ld = grad_ld; g.dtype = dtype;
+  g.acc_mask = accumulate_mask;
   const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(batch * n_feats * dim, 256), 65536);
   hipLaunchKernelGGL(dot_bwd_generic_kernel, dim3(blocks), dim3(256), 0, st, g);
   KRS_CHECK_LAUNCH("dot_bwd_generic_kernel");

@@ -1751,7 +1751,7 @@ __global__ __launch_bounds__(256) void cross_fwd_scalar_kernel(const CrossParams
 // waves of a workgroup add theirs in LDS and issue one lane-contiguous atomic per column (with one
 // atomic per thread and chunk, ~600 chunks queued on the same cache lines of dbias and the kernel took
 // 156 us for 8192 rows where the rows themselves need 60).
-template <typename T, int V>
+template <typename T, int V, bool ACC>  // ACC: dx0 already holds the terms of the layers above (dx0_accumulate)
 __global__ __launch_bounds__(256) void cross_bwd_vec_kernel(const CrossParams p, int rows_per_block) {
   __shared__ float red[4][64 * V];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1768,14 +1768,18 @@ __global__ __launch_bounds__(256) void cross_bwd_vec_kernel(const CrossParams p,
   // the loads are unconditional)
   typedef typename RowVec<T, V>::raw_t raw_t;
   constexpr int AHEAD = 2;
-  raw_t rg[AHEAD], rx0[AHEAD], ru[AHEAD];
+  raw_t rg[AHEAD], rx0[AHEAD], ru[AHEAD], racc[AHEAD];
   const void* usrc = p.u ? p.u : p.g;  // without u the value is ignored below
+  // the running dL/dx0 of the layers above is read ahead like the other streams (a template parameter, not a
+  // branch: a load behind a run-time condition makes hipcc drain the load queue, 454 -> 550 us)
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a) {
     const int64_t oa = min(r0 + a, r1 - 1) * p.ld + col;
     rg[a] = RowVec<T, V>::load_raw(p.g, oa);
     rx0[a] = RowVec<T, V>::load_raw(p.x0, oa);
     ru[a] = RowVec<T, V>::load_raw(usrc, oa);
+    if constexpr (ACC) racc[a] = RowVec<T, V>::load_raw(p.dx0, oa);
+    else racc[a] = rg[a];
   }
   for (int64_t i = r0; i < rend; ++i) {
     const int64_t o = i * p.ld + col;
@@ -1783,17 +1787,20 @@ __global__ __launch_bounds__(256) void cross_bwd_vec_kernel(const CrossParams p,
     RowVec<T, V>::unpack(rg[0], g);
     RowVec<T, V>::unpack(rx0[0], x0);
     RowVec<T, V>::unpack(ru[0], u);
+    RowVec<T, V>::unpack(racc[0], t);
     if (!p.u) {
 #pragma unroll
       for (int k = 0; k < V; ++k) u[k] = 0.0f;
     }
 #pragma unroll
-    for (int a = 0; a + 1 < AHEAD; ++a) { rg[a] = rg[a + 1]; rx0[a] = rx0[a + 1]; ru[a] = ru[a + 1]; }
+    for (int a = 0; a + 1 < AHEAD; ++a) { rg[a] = rg[a + 1]; rx0[a] = rx0[a + 1]; ru[a] = ru[a + 1]; racc[a] = racc[a + 1]; }
     {
       const int64_t on = min(i + AHEAD, r1 - 1) * p.ld + col;
       rg[AHEAD - 1] = RowVec<T, V>::load_raw(p.g, on);
       rx0[AHEAD - 1] = RowVec<T, V>::load_raw(p.x0, on);
       ru[AHEAD - 1] = RowVec<T, V>::load_raw(usrc, on);
+      if constexpr (ACC) racc[AHEAD - 1] = RowVec<T, V>::load_raw(p.dx0, on);
+      else racc[AHEAD - 1] = rg[AHEAD - 1];
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -1809,10 +1816,9 @@ __global__ __launch_bounds__(256) void cross_bwd_vec_kernel(const CrossParams p,
 #pragma unroll
         for (int k = 0; k < V; ++k) x[k] = 0.0f;
       }
-      if (p.dx0_acc) RowVec<T, V>::load(p.dx0, o, t);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        t[k] = (p.dx0_acc ? t[k] : 0.0f) + g[k] * (u[k] + p.diag * x[k]);
+        t[k] = (ACC ? t[k] : 0.0f) + g[k] * (u[k] + p.diag * x[k]);
         if (fold) t[k] += g[k] + p.diag * gx0[k];
       }
       RowVec<T, V>::store(p.dx0, o, t);
@@ -2022,10 +2028,14 @@ extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* 
   const dim3 grid((unsigned)strips, (unsigned)ceil_div(m, rows_per_block));
   if (vec) {
     const dim3 grid4((unsigned)strips, (unsigned)ceil_div(ceil_div(m, rows_per_block), 4));  // four chunks per workgroup
-    if (dtype == KRS_BF16)
-      hipLaunchKernelGGL((cross_bwd_vec_kernel<uint16_t, 8>), grid4, dim3(256), 0, st, p, rows_per_block);
-    else
-      hipLaunchKernelGGL((cross_bwd_vec_kernel<float, 4>), grid4, dim3(256), 0, st, p, rows_per_block);
+    const bool acc = p.dx0 && p.dx0_acc;
+    if (dtype == KRS_BF16) {
+      if (acc) hipLaunchKernelGGL((cross_bwd_vec_kernel<uint16_t, 8, true>), grid4, dim3(256), 0, st, p, rows_per_block);
+      else hipLaunchKernelGGL((cross_bwd_vec_kernel<uint16_t, 8, false>), grid4, dim3(256), 0, st, p, rows_per_block);
+    } else {
+      if (acc) hipLaunchKernelGGL((cross_bwd_vec_kernel<float, 4, true>), grid4, dim3(256), 0, st, p, rows_per_block);
+      else hipLaunchKernelGGL((cross_bwd_vec_kernel<float, 4, false>), grid4, dim3(256), 0, st, p, rows_per_block);
+    }
   } else {
     hipLaunchKernelGGL(cross_bwd_scalar_kernel, grid, dim3(64), 0, st, p, rows_per_block);
   }

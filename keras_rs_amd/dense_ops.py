@@ -149,21 +149,40 @@ def dot_interaction_fwd(feats: Sequence[torch.Tensor], self_interaction=False, s
 
 
 def dot_interaction_bwd(feats: Sequence[torch.Tensor], grad_out: torch.Tensor, self_interaction=False,
-                        skip_gather=False):
+                        skip_gather=False, into: torch.Tensor | None = None, accumulate_mask: int = 0):
+    """Gradients of the features, as column views of one [B, F*dim] buffer.
+
+    into / accumulate_mask (krs_dot_interaction_bwd_accumulate): `into` is a [B, F*dim] row-major matrix that
+    already holds gradients of the features; feature f with bit f of the mask set is ADDED there (its returned
+    gradient is None: the caller hands `into` on), the others are written to a fresh buffer as usual."""
     feats = [_rowmajor(f, "dot_interaction feature") for f in feats]
     grad_out = _rowmajor(grad_out, "dot_interaction grad")
     batch, dim = feats[0].shape
+    n = len(feats)
     # one buffer, per-feature column views: a consumer that wants the gradients side by side
     # (the embedding backward) can take the buffer as it is
-    gbuf = torch.empty((batch, len(feats) * dim), dtype=feats[0].dtype, device=feats[0].device)
-    grads = [gbuf[:, i * dim:(i + 1) * dim] for i in range(len(feats))]
+    if into is None or not accumulate_mask:
+        accumulate_mask = 0
+        gbuf = torch.empty((batch, n * dim), dtype=feats[0].dtype, device=feats[0].device)
+        grads = [gbuf[:, i * dim:(i + 1) * dim] for i in range(n)]
+        outs = grads
+    else:
+        if tuple(into.shape) != (batch, n * dim) or into.dtype != feats[0].dtype or into.stride(1) != 1:
+            raise L.KrsError("dot_interaction_bwd: `into` must be a row-major [batch, F*dim] matrix of the features' dtype")
+        fresh = [i for i in range(n) if not (accumulate_mask >> i) & 1]
+        gbuf = torch.empty((batch, max(len(fresh), 1) * dim), dtype=feats[0].dtype, device=feats[0].device)
+        slot = {f: k for k, f in enumerate(fresh)}
+        outs = [into[:, i * dim:(i + 1) * dim] if i not in slot else gbuf[:, slot[i] * dim:(slot[i] + 1) * dim]
+                for i in range(n)]
+        grads = [None if i not in slot else outs[i] for i in range(n)]
     ptrs, lds = _ptr_table(feats)
-    gptrs, glds = _ptr_table(grads)
-    rc = L.lib().krs_dot_interaction_bwd(ptrs, lds, C.c_int(len(feats)), C.c_int64(batch), C.c_int(dim),
-                                         C.c_int(L.fdtype(feats[0])), C.c_int(int(self_interaction)),
-                                         C.c_int(int(skip_gather)), L.ptr(grad_out),
-                                         C.c_int64(grad_out.stride(0)), gptrs, glds, L.stream_ptr())
-    L.check(rc, "krs_dot_interaction_bwd")
+    gptrs, glds = _ptr_table(outs)
+    rc = L.lib().krs_dot_interaction_bwd_accumulate(ptrs, lds, C.c_int(n), C.c_int64(batch), C.c_int(dim),
+                                                    C.c_int(L.fdtype(feats[0])), C.c_int(int(self_interaction)),
+                                                    C.c_int(int(skip_gather)), L.ptr(grad_out),
+                                                    C.c_int64(grad_out.stride(0)), gptrs, glds,
+                                                    C.c_uint64(int(accumulate_mask)), L.stream_ptr())
+    L.check(rc, "krs_dot_interaction_bwd_accumulate")
     return grads
 
 

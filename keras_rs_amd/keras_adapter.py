@@ -145,7 +145,7 @@ def make_layers(keras) -> types.SimpleNamespace:
                     raise ValueError("All feature tensors in `inputs` should have the same shape. Found at least one "
                                      f"conflict: shape = {shape} at index 0 and shape = {tuple(t.shape)} at index {idx}.")
             cd = compute_dtype(self)
-            return DotInteractionFn.apply(self.self_interaction, self.skip_gather,
+            return DotInteractionFn.apply(self.self_interaction, self.skip_gather, None, 0,
                                           *[t if t.dtype == cd else t.to(cd) for t in inputs])
 
         def compute_output_shape(self, input_shape):

@@ -27,6 +27,7 @@ from __future__ import annotations
 import dataclasses
 import math
 import threading
+import weakref
 from typing import Any, Sequence
 
 import numpy as np
@@ -799,6 +800,38 @@ class DistributedEmbedding(base.Layer):
 
 
 # ---------------------------------------------------------------------- helpers
+def slab_grad_relay(slab: torch.Tensor):
+    """The SlabGradRelay of a lookup slab (created on first use; see autograd.SlabGradRelay)."""
+    from keras_rs_amd.autograd import SlabGradRelay
+
+    relay = getattr(slab, "_krs_grad_relay", None)
+    if relay is None:
+        relay = slab._krs_grad_relay = SlabGradRelay()
+    return relay
+
+
+def slab_views_run(tensors: Sequence[torch.Tensor]):
+    """(slab, n_heads) when the trailing tensors are ALL the feature views of one DistributedEmbedding slab, in
+    order, and the leading ones have exactly the total width of its reserved columns; else (None, 0)."""
+    tensors = list(tensors)
+    info = [getattr(t, "_krs_slab", None) for t in tensors]
+    if not tensors or info[-1] is None:
+        return None, 0
+    start = len(tensors)
+    while start > 0 and info[start - 1] is not None and info[start - 1][0] is info[-1][0]:
+        start -= 1
+    run = info[start:]
+    slab, _, n_views, lead = run[0]
+    dim = (slab.shape[1] - lead) // n_views
+    ordered = len(run) == n_views and all(r[1] == lead + i * dim for i, r in enumerate(run))
+    heads = tensors[:start]
+    if not ordered or any(h.dim() != 2 or h.shape[0] != slab.shape[0] for h in heads):
+        return None, 0
+    if sum(h.shape[1] for h in heads) != lead:
+        return None, 0
+    return slab, start
+
+
 def concat_features(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
     """torch.cat(tensors, dim=-1) for the interaction input of a DLRM / DCN model
     (examples/ml_perf/model.py:204-207 concatenates the bottom-MLP output and every embedding).
@@ -827,7 +860,10 @@ def concat_features(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
                 if not heads:
                     return slab
                 slab._krs_lead_taken = True
-                return SlabFillFn.apply(slab, *heads)
+                relay = slab_grad_relay(slab)
+                out = SlabFillFn.apply(slab, relay, *heads)
+                relay.out_ref = weakref.ref(out)
+                return out
             return torch.cat(heads + [slab[:, lead:]], dim=-1)
     return torch.cat(tensors, dim=-1)
 

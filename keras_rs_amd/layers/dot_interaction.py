@@ -41,7 +41,16 @@ class DotInteraction(base.Layer):
             L.require_device(t, "DotInteraction input")
         cd = self.compute_dtype
         feats = [t if t.dtype == cd else t.to(cd) for t in inputs]
-        return DotInteractionFn.apply(self.self_interaction, self.skip_gather, *feats)
+        # the features of one lookup slab behind a head of its reserved width (the DLRM input list
+        # [bottom_mlp_output, *embeddings] with equal widths): their gradient can join the slab's in the kernel
+        relay, n_heads = None, 0
+        if all(f is t for f, t in zip(feats, inputs)):
+            from keras_rs_amd.layers.distributed_embedding import slab_grad_relay, slab_views_run
+
+            slab, k = slab_views_run(inputs)
+            if slab is not None and slab.dtype == cd and all(tuple(h.shape) == shape for h in inputs[:k]):
+                relay, n_heads = slab_grad_relay(slab), k
+        return DotInteractionFn.apply(self.self_interaction, self.skip_gather, relay, n_heads, *feats)
 
     def compute_output_shape(self, input_shape):
         n = len(input_shape)

@@ -406,10 +406,28 @@ int krs_oracle_dot_interaction_fwd(const void* const* feats, const int64_t* ldf,
 }
 
 /* Autodiff of K4: dX[b,i,:] = sum_j (G[b,i,j] + G[b,j,i]) X[b,j,:]. */
+int krs_oracle_dot_interaction_bwd_accumulate(const void* const* feats, const int64_t* ldf, int n_feats,
+                                              int64_t batch, int dim, int dtype, int self_interaction,
+                                              int skip_gather, const void* grad_out, int64_t grad_ld,
+                                              void* const* grad_feats, const int64_t* gld,
+                                              uint64_t accumulate_mask);
+
 int krs_oracle_dot_interaction_bwd(const void* const* feats, const int64_t* ldf, int n_feats,
                                    int64_t batch, int dim, int dtype, int self_interaction,
                                    int skip_gather, const void* grad_out, int64_t grad_ld,
                                    void* const* grad_feats, const int64_t* gld) {
+  return krs_oracle_dot_interaction_bwd_accumulate(feats, ldf, n_feats, batch, dim, dtype, self_interaction,
+                                                   skip_gather, grad_out, grad_ld, grad_feats, gld, 0);
+}
+
+/* include/krs.h krs_dot_interaction_bwd_accumulate: features whose mask bit is set receive
+ * stored + dX (the stored value widened to fp32, one rounding of the sum); the gradient meeting the one of the
+ * concat of the same features, which autodiff would add (examples/ml_perf/model.py:204-207). */
+int krs_oracle_dot_interaction_bwd_accumulate(const void* const* feats, const int64_t* ldf, int n_feats,
+                                              int64_t batch, int dim, int dtype, int self_interaction,
+                                              int skip_gather, const void* grad_out, int64_t grad_ld,
+                                              void* const* grad_feats, const int64_t* gld,
+                                              uint64_t accumulate_mask) {
   int F = n_feats;
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < batch; ++b)
@@ -424,6 +442,7 @@ int krs_oracle_dot_interaction_bwd(const void* const* feats, const int64_t* ldf,
           if (cji >= 0) gs += ld(grad_out, dtype, b * grad_ld + cji);
           acc = fmaf(gs, ld(feats[j], dtype, b * ldf[j] + c), acc);
         }
+        if (i < 64 && ((accumulate_mask >> i) & 1)) acc += ld(grad_feats[i], dtype, b * gld[i] + c);
         st(grad_feats[i], dtype, b * gld[i] + c, acc);
       }
   return KRS_OK;

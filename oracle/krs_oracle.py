@@ -260,14 +260,16 @@ def dot_interaction_fwd(feats, self_interaction=False, skip_gather=False):
     return out
 
 
-def dot_interaction_bwd(feats, grad_out, self_interaction=False, skip_gather=False):
+def dot_interaction_bwd(feats, grad_out, self_interaction=False, skip_gather=False, existing=None, accumulate_mask=0):
+    """existing / accumulate_mask: krs_dot_interaction_bwd_accumulate -- `existing[f]` (copied) is the stored
+    gradient of feature f, added to when bit f of the mask is set and overwritten otherwise."""
     batch, dim = feats[0].shape
-    grads = [np.zeros_like(f) for f in feats]
-    rc = lib().krs_oracle_dot_interaction_bwd(
+    grads = [np.zeros_like(f) for f in feats] if existing is None else [np.array(e, copy=True, order="C") for e in existing]
+    rc = lib().krs_oracle_dot_interaction_bwd_accumulate(
         _ptr_array(feats), _ld_array(feats), C.c_int(len(feats)), C.c_int64(batch), C.c_int(dim),
         C.c_int(fdtype(feats[0])), C.c_int(int(self_interaction)), C.c_int(int(skip_gather)),
         _p(grad_out), C.c_int64(grad_out.strides[0] // grad_out.itemsize),
-        _ptr_array(grads), _ld_array(grads))
+        _ptr_array(grads), _ld_array(grads), C.c_uint64(int(accumulate_mask)))
     assert rc == 0, rc
     return grads
 

@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
         KK(krs_gemm(h[i].p, h[i].ld, 0, Vt.p, Vt.ld, 1, y[i].p, y[i].ld, B, d, pj, KRS_BF16, KRS_BF16, &ep, nullptr, 0, st));
         break;
       case 2:
-        KK(krs_cross_epilogue_bwd(g.p, u[i].p, x0.p, x.p, dz[i].p, dx0[i].p, 0, nullptr, dbias, B, d, x.ld, 0.0f,
+        KK(krs_cross_epilogue_bwd(g.p, u[i].p, x0.p, x.p, dz[i].p, dx0[i].p, getenv("KRS_EW_ACC") ? 1 : 0, nullptr, dbias, B, d, x.ld, 0.0f,
                                   KRS_ACT_NONE, KRS_BF16, st));
         break;
       case 3:

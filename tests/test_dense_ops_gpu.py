@@ -174,6 +174,36 @@ def test_dot_interaction_fwd_bwd(dt, F, D_, B, si, sg):
         np.testing.assert_allclose(to_f32(to_np(a)), to_f32(e), **tol)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("F,D_,B,mask", [(27, 128, 70, 0x7FFFFFE), (27, 128, 5, 0x7FFFFFF), (8, 64, 33, 0b10110100),
+                                         (5, 6, 9, 0b11110), (40, 8, 5, (1 << 40) - 2), (3, 256, 4, 0b100)])
+def test_dot_interaction_bwd_accumulate(dt, F, D_, B, mask):
+    # krs_dot_interaction_bwd_accumulate: masked features are added to what `into` holds (fp32 sum, one
+    # rounding), the others come back as fresh tensors; fast (F <= 32, even D) and generic kernels
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(F * 7 + D_)
+    buf = _t(rng.uniform(-1, 1, (B, F * D_)), dt)
+    feats = [buf[:, f * D_:(f + 1) * D_] for f in range(F)]
+    g = _t(rng.uniform(-1, 1, (B, F * (F - 1) // 2)), dt)
+    into = _t(rng.uniform(-2, 2, (B, F * D_)), dt)
+    before = to_np(into).copy()
+    fn = [np.ascontiguousarray(to_np(buf)[:, f * D_:(f + 1) * D_]) for f in range(F)]
+    existing = [np.ascontiguousarray(before[:, f * D_:(f + 1) * D_]) for f in range(F)]
+    exp = ko.dot_interaction_bwd(fn, to_np(g), False, False, existing=existing, accumulate_mask=mask)
+    grads = D.dot_interaction_bwd(feats, g, False, False, into=into, accumulate_mask=mask)
+    after = to_np(into)
+    tol = dict(rtol=2 ** -6, atol=6e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=2e-5)
+    for f in range(F):
+        sl = slice(f * D_, (f + 1) * D_)
+        if (mask >> f) & 1:
+            assert grads[f] is None
+            np.testing.assert_allclose(to_f32(after[:, sl]), to_f32(exp[f]), **tol)
+        else:
+            np.testing.assert_allclose(to_f32(to_np(grads[f])), to_f32(exp[f]), **tol)
+            assert np.array_equal(after[:, sl], before[:, sl])      # untouched
+
+
 def test_dot_interaction_feature_limit_is_loud():
     from keras_rs_amd import dense_ops as D
     from keras_rs_amd._lib import KrsError

@@ -766,3 +766,55 @@ def test_sharded_layer_world1_on_hip_matches_unsharded_layer(optimizer):
     for k in results[0][1]:
         np.testing.assert_allclose(results[1][1][k], results[0][1][k], rtol=1e-5, atol=1e-6)
         assert not np.allclose(results[0][1][k], full[k])
+
+
+@pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
+def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
+    # autograd.SlabGradRelay: with [dense, *embeddings] going to DotInteraction first and to concat_features
+    # second (the DLRM order), the interaction's gradient of the embeddings is added into the concat's gradient
+    # inside krs_dot_interaction_bwd_accumulate.  Same numbers as the separate add (which runs when the concat
+    # result retains its gradient, or when the interaction is called after the concat).
+    from keras_rs_amd.autograd import SlabGradRelay
+    from keras_rs_amd.layers import base as kl_base
+
+    kl = _layers()
+    rng = np.random.default_rng(11)
+    B, D_ = 24, 16
+    ids = {k: rng.integers(0, 50, (B, h)).astype(np.int32) for k, h in (("a", 2), ("b", 1), ("c", 4))}
+    w_dot = torch.rand(B, 6, device=DEV)
+    dt = torch.bfloat16 if policy == "mixed_bfloat16" else torch.float32
+
+    def run(mode):
+        tabs = [kl.TableConfig(f"t{k}", 50, D_, placement="sparsecore", optimizer=kl.SGD(0.25), combiner="sum",
+                               initializer=kl_base.RandomUniform(-1, 1, seed=7 + i)) for i, k in enumerate("abc")]
+        layer = kl.DistributedEmbedding({k: kl.FeatureConfig(k, t, ids[k].shape, (B, D_)) for k, t in zip("abc", tabs)},
+                                        slab_lead_cols=D_, dtype=policy)
+        dense = torch.linspace(-1, 1, B * D_, device=DEV).reshape(B, D_).to(dt).requires_grad_(True)
+        emb = layer(ids)
+        feats = [dense] + [emb[k] for k in "abc"]
+        if mode == "dot_last":
+            x0 = kl.concat_features(feats)
+            inter = kl.DotInteraction(dtype=policy)(feats)
+        else:
+            inter = kl.DotInteraction(dtype=policy)(feats)
+            x0 = kl.concat_features(feats)
+        if mode == "retain":
+            x0.retain_grad()
+        y = kl.FeatureCross(kernel_initializer=kl_base.GlorotUniform(seed=1), dtype=policy)(x0, x0)
+        before = SlabGradRelay.joined
+        ((y.float() ** 2).sum() + (inter.float() * w_dot).sum()).backward()
+        took = SlabGradRelay.joined - before
+        gx0 = x0.grad.clone() if mode == "retain" else None
+        return took, dense.grad.float().clone(), {k: v.float().clone() for k, v in layer.get_embedding_tables().items()}, gx0
+
+    took, gd, tabs, _ = run("joined")
+    assert took == 1
+    tol = dict(rtol=2 ** -6, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    for mode in ("retain", "dot_last"):
+        took_m, gd_m, tabs_m, gx0 = run(mode)
+        assert took_m == 0
+        torch.testing.assert_close(gd, gd_m, **tol)
+        for k in tabs:
+            torch.testing.assert_close(tabs[k], tabs_m[k], **tol)
+        if gx0 is not None:   # the retained gradient of the concat is the cross layer's alone
+            assert gx0.shape == (B, 4 * D_) and torch.isfinite(gx0.float()).all()
