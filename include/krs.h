@@ -306,6 +306,14 @@ int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const v
                            int64_t m, int64_t n, int64_t ld, float diag_scale, int act,
                            int dtype, void* stream);
 
+/* Weight preparation for the two GEMM layouts of a Dense / FeatureCross step: dst [rows, cols] = cast(src) and
+ * dst_t [cols, rows] = cast(src)^T, either may be NULL.  What `ops.cast(kernel, compute_dtype)` +
+ * a transposed copy do on the host side of feature_cross.py:182-194 under a mixed-precision policy, in one
+ * launch (bf16 rounding: round-to-nearest-even, as everywhere in this library). */
+int krs_cast_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, int src_dtype,
+                       void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int dst_dtype,
+                       void* stream);
+
 /* Column sum: out[n] = sum_m a[m,n] (fp32 out).  Dense bias gradient. */
 int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
                float* out, void* stream);

@@ -74,6 +74,7 @@ SYMBOLS = [
     "krs_cross_epilogue_fwd",
     "krs_cross_epilogue_bwd",
     "krs_colsum",
+    "krs_cast_transpose",
     "krs_dot_interaction_fwd",
     "krs_dot_interaction_bwd",
     "krs_dot_interaction_bwd_accumulate",

@@ -115,13 +115,14 @@ class CrossLayerFn(torch.autograd.Function):
         # The forward contracts over the kernels' leading axis: hand the (small) weights to the MFMA
         # kernel K-contiguous (one transposed copy per step, a few microseconds) so that both GEMM
         # operands stream into LDS with row-wise 16-byte stores.
-        kc = kernel.to(cd)
+        # (cast + transposed copy of a weight = one launch, krs_cast_transpose)
+        kc, kct = D.cast_transpose(kernel, cd)
         h = xc
         dc = None
         if down is not None:
-            dc = down.to(cd)
-            h, _ = D.gemm(xc, dc.t().contiguous(), b_is_nk=True)
-        y, u = D.gemm(h, kc.t().contiguous(), b_is_nk=True, bias=bias, act=act, diag_scale=diag_scale,
+            dc, dct = D.cast_transpose(down, cd)
+            h, _ = D.gemm(xc, dct, b_is_nk=True)
+        y, u = D.gemm(h, kct, b_is_nk=True, bias=bias, act=act, diag_scale=diag_scale,
                       x0=x0c, x=xc, want_u=True)
         ctx.save_for_backward(x0c, xc, h if down is not None else None, u, dc, kc)
         ctx.meta = (diag_scale, act, same, down is not None, bias is not None,
@@ -189,8 +190,8 @@ class DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, bias, act, compute_dtype):
         xc = x.to(compute_dtype).contiguous()
-        kc = kernel.to(compute_dtype)
-        y, _ = D.gemm(xc, kc.t().contiguous(), b_is_nk=True, bias=bias, act=act)
+        kc, kct = D.cast_transpose(kernel, compute_dtype)
+        y, _ = D.gemm(xc, kct, b_is_nk=True, bias=bias, act=act)
         ctx.save_for_backward(xc, kc, y if act != L.ACT_NONE else None)
         ctx.meta = (act, bias is not None, x.dtype, kernel.dtype)
         return y

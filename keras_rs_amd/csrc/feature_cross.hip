@@ -2043,6 +2043,49 @@ extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* 
   return KRS_OK;
 }
 
+// Weight preparation of a Dense / FeatureCross step: dst = cast(src) and dst_t = cast(src)^T in one pass over
+// a 64 x 64 tile staged in LDS (padded rows: conflict-free in both directions).  The weights are a few MB, so
+// the separate cast + transposed copy of every step were launch-bound (four ~16 us launches per cross layer).
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const void* src, int64_t rows, int64_t cols, int64_t lds_,
+                                                             int src_dtype, void* dst, int64_t ldd, void* dst_t,
+                                                             int64_t ldt, int dst_dtype) {
+  __shared__ float tile[64][65];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t r = r0 + ty * 16 + k, c = c0 + tx;
+    if (r < rows && c < cols) {
+      const float v = ld_elem(src, src_dtype, r * lds_ + c);
+      tile[ty * 16 + k][tx] = v;
+      if (dst) st_elem(dst, dst_dtype, r * ldd + c, v);
+    }
+  }
+  if (!dst_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t c = c0 + ty * 16 + k, r = r0 + tx;   // dst_t[c][r] = src[r][c]
+    if (r < rows && c < cols) st_elem(dst_t, dst_dtype, c * ldt + r, tile[tx][ty * 16 + k]);
+  }
+}
+
+extern "C" int krs_cast_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, int src_dtype,
+                                  void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int dst_dtype,
+                                  void* stream) {
+  KRS_REQUIRE(src && (dst || dst_t), "cast_transpose: null operand");
+  KRS_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols, "cast_transpose: bad sizes");
+  KRS_REQUIRE((src_dtype == KRS_F32 || src_dtype == KRS_BF16) && (dst_dtype == KRS_F32 || dst_dtype == KRS_BF16),
+              "cast_transpose: dtype must be f32 or bf16");
+  KRS_REQUIRE((!dst || ld_dst >= cols) && (!dst_t || ld_dst_t >= rows), "cast_transpose: bad output strides");
+  if (rows == 0 || cols == 0) return KRS_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64)), dim3(256),
+                     0, st, src, rows, cols, ld_src, src_dtype, dst, ld_dst, dst_t, ld_dst_t, dst_dtype);
+  KRS_CHECK_LAUNCH("cast_transpose_kernel");
+  return KRS_OK;
+}
+
 extern "C" int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype, float* out,
                           void* stream) {
   KRS_REQUIRE(a && out, "colsum: null operand");

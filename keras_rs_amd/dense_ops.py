@@ -124,6 +124,25 @@ def colsum(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def cast_transpose(w: torch.Tensor, dtype: torch.dtype, want_plain: bool = True, want_t: bool = True):
+    """(w.to(dtype), w.to(dtype).t().contiguous()) of a 2-D weight in ONE launch (krs_cast_transpose); an output
+    that is not wanted is None; the plain one is `w` itself when it already has the dtype and is row-major."""
+    w = _rowmajor(w, "cast_transpose")
+    rows, cols = w.shape
+    plain = None
+    if want_plain:
+        plain = w if w.dtype == dtype else torch.empty((rows, cols), dtype=dtype, device=w.device)
+    wt = torch.empty((cols, rows), dtype=dtype, device=w.device) if want_t else None
+    write_plain = plain is not None and plain is not w
+    if write_plain or want_t:
+        rc = L.lib().krs_cast_transpose(L.ptr(w), C.c_int64(rows), C.c_int64(cols), C.c_int64(w.stride(0)),
+                                        C.c_int(L.fdtype(w)), L.ptr(plain) if write_plain else None,
+                                        C.c_int64(cols), L.ptr(wt), C.c_int64(rows),
+                                        C.c_int(L.fdtype(plain if plain is not None else wt)), L.stream_ptr())
+        L.check(rc, "krs_cast_transpose")
+    return plain, wt
+
+
 def _ptr_table(ts: Sequence[torch.Tensor]):
     return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), (C.c_int64 * len(ts))(*[t.stride(0) for t in ts])
 

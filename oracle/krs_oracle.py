@@ -274,6 +274,14 @@ def dot_interaction_bwd(feats, grad_out, self_interaction=False, skip_gather=Fal
     return grads
 
 
+def cast_transpose(w, to_bf16):
+    """include/krs.h krs_cast_transpose: (cast(w), cast(w)^T); w fp32 array or bf16 bit pattern (uint16); the
+    cast is ops.cast under a mixed-precision policy (feature_cross.py:182-194): round-to-nearest-even."""
+    wf = bf16_bits_to_f32(w) if w.dtype == np.uint16 else np.asarray(w, np.float32)
+    out = f32_to_bf16_bits(wf) if to_bf16 else wf
+    return np.ascontiguousarray(out), np.ascontiguousarray(out.T)
+
+
 def mod_bucketize(ids, n_shards):
     nnz = ids.shape[0]
     local = np.zeros_like(ids)

@@ -204,6 +204,25 @@ def test_dot_interaction_bwd_accumulate(dt, F, D_, B, mask):
             assert np.array_equal(after[:, sl], before[:, sl])      # untouched
 
 
+@pytest.mark.parametrize("src,dst", [(torch.float32, torch.bfloat16), (torch.float32, torch.float32),
+                                     (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("rows,cols", [(3456, 512), (512, 3456), (13, 7), (1, 129), (64, 64), (200, 1)])
+def test_cast_transpose_is_bit_exact(src, dst, rows, cols):
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(rows * 31 + cols)
+    w = _t(rng.uniform(-3, 3, (rows, cols)), src)
+    plain, wt = D.cast_transpose(w, dst)
+    e_plain, e_t = ko.cast_transpose(to_np(w), dst == torch.bfloat16)
+    assert np.array_equal(to_np(plain), e_plain) and np.array_equal(to_np(wt), e_t)
+    if src == dst:
+        assert plain is w                      # nothing copied
+    # a strided source (a column window of a wider matrix) and a single output
+    wide = _t(rng.uniform(-3, 3, (rows, cols + 5)), src)
+    _, wt2 = D.cast_transpose(wide[:, 2:2 + cols], dst, want_plain=False)
+    assert np.array_equal(to_np(wt2), ko.cast_transpose(np.ascontiguousarray(to_np(wide)[:, 2:2 + cols]), dst == torch.bfloat16)[1])
+
+
 def test_dot_interaction_feature_limit_is_loud():
     from keras_rs_amd import dense_ops as D
     from keras_rs_amd._lib import KrsError
