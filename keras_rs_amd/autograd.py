@@ -87,7 +87,8 @@ class SlabGradRelay:
     inputs are exactly the slab's feature views, it adds their gradients into the matrix
     (krs_dot_interaction_bwd_accumulate) and returns no gradient for them.  The leading inputs (the bottom-MLP
     output) keep their ordinary gradient tensors, so whatever else consumes them is unaffected.  Not used when
-    the concat result retains its gradient or has hooks (its .grad would show the joined value)."""
+    the concat result is still referenced and retains its gradient or has hooks (its .grad would show the joined
+    value)."""
 
     __slots__ = ("buf", "task", "out_ref")
     joined = 0   # times the in-kernel path was taken (read by the tests)
@@ -382,8 +383,9 @@ class SlabFillFn(torch.autograd.Function):
     def backward(ctx, g):
         relay = ctx.relay
         if relay is not None:
+            # (a concat result nobody holds any more cannot show its .grad to anyone)
             out = relay.out_ref() if relay.out_ref is not None else None
-            plain = out is not None and not out.retains_grad and not out._backward_hooks
+            plain = out is None or (not out.retains_grad and not out._backward_hooks)
             task = torch._C._current_graph_task_id()
             relay.buf, relay.task = (g, task) if (plain and task != -1 and g.is_contiguous()) else (None, -1)
         return (g, None) + tuple(g[:, a:b] for a, b in ctx.cols)

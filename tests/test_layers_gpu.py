@@ -801,6 +801,8 @@ def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
         if mode == "retain":
             x0.retain_grad()
         y = kl.FeatureCross(kernel_initializer=kl_base.GlorotUniform(seed=1), dtype=policy)(x0, x0)
+        if mode == "dropped":     # a model's forward returns and the concat result is referenced by the graph only
+            del x0, feats, emb
         before = SlabGradRelay.joined
         ((y.float() ** 2).sum() + (inter.float() * w_dot).sum()).backward()
         took = SlabGradRelay.joined - before
@@ -809,6 +811,8 @@ def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
 
     took, gd, tabs, _ = run("joined")
     assert took == 1
+    took_d, gd_d, tabs_d, _ = run("dropped")
+    assert took_d == 1 and torch.equal(gd, gd_d) and all(torch.equal(tabs[k], tabs_d[k]) for k in tabs)
     tol = dict(rtol=2 ** -6, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
     for mode in ("retain", "dot_last"):
         took_m, gd_m, tabs_m, gx0 = run(mode)
