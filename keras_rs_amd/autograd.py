@@ -317,15 +317,10 @@ class EmbedBagFusedFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)  # unused outputs (slab or views) arrive as None, not as zero tensors
         n = len(bags.features)
         slab = torch.empty((batch, lead + n * bags.dim), dtype=out_dtype or bags.dtype, device=ids.device)
-        # err_flag: device int32[1] the kernel ORs KRS_FLAG_* into (out-of-range ids contribute nothing and are
-        # never clamped); read later by the layer, so the step keeps running without a host sync
-        out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
-                                  out=slab[:, lead:], want_scale=True, err_flag=err_flag)
-        ctx.bags, ctx.batch, ctx.hots, ctx.optimizer, ctx.lead = bags, batch, hots, optimizer, lead
-        ctx.save_for_backward(ids, offsets, weights, scale)
-        ctx.out_meta = (out.dtype, out.device)
-        # The backward's plan (sort of the lookups by row) depends only on the ids: start it now on
-        # a side stream so that it runs under the dense part of the step instead of in front of K2.
+        # The backward's plan (sort of the lookups by row) depends only on the ids: start it now on a side
+        # stream, BEFORE the gather is enqueued, so that the two run side by side -- the gather is bound by
+        # HBM, the sort's scatter passes by LDS ranking work -- and the plan is done when the dense part starts
+        # (queued behind the gather it ran under the first FeatureCross GEMMs and slowed them by 0.4 ms).
         ctx.plan = None
         if ctx.needs_input_grad[8]:  # a backward will follow (not under torch.no_grad())
             main = torch.cuda.current_stream()
@@ -339,6 +334,13 @@ class EmbedBagFusedFn(torch.autograd.Function):
                 if t is not None:
                     t.record_stream(side)
             ctx.plan = (ws, done)
+        # err_flag: device int32[1] the kernel ORs KRS_FLAG_* into (out-of-range ids contribute nothing and are
+        # never clamped); read later by the layer, so the step keeps running without a host sync
+        out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
+                                  out=slab[:, lead:], want_scale=True, err_flag=err_flag)
+        ctx.bags, ctx.batch, ctx.hots, ctx.optimizer, ctx.lead = bags, batch, hots, optimizer, lead
+        ctx.save_for_backward(ids, offsets, weights, scale)
+        ctx.out_meta = (out.dtype, out.device)
         return (slab,) + _split_columns(slab, n, bags.dim, lead)
 
     @staticmethod

@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
       u32x4 fa[4], fb[2];
       // ---- phase 2kb ----
       load_frags(rd, 0, fa, fb);
-      issue_b(wb);
+      issue_b(wb);   // (the piece in FRONT of the fragment reads: 227 / 241 us against 204 / 210, K-contiguous / K-strided)
       pp_barrier();
       if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
       mfma8(fa, fb);
