@@ -559,7 +559,9 @@ def main():
                             "row-wise Adagrad (opt-in variant, NOT the reference optimizer)" if a.rowwise_adagrad
                             else "Adagrad")),
             "global_batch": a.batch,
-            "parallelism": "single GPU" if world == 1 else f"tables MOD row-sharded over {world} GPUs, dense part DP",
+            "parallelism": ("single GPU" if world == 1 and not a.force_sharded else
+                            "sharded code path on ONE GPU (dry run: device copies stand in for the links)" if world == 1
+                            else f"tables MOD row-sharded over {world} GPUs, dense part DP"),
         },
     }
     second = {"workload": "same tables / model, " + describe(secondary),

@@ -42,6 +42,7 @@ struct DotParams {
   uint32_t acc_mask;  // backward: bit f set = gfeat[f] already holds a gradient, add to it
 };
 
+__host__ __device__ constexpr int tri_cols(int rows, bool self) { return self ? rows * (rows + 1) / 2 : rows * (rows - 1) / 2; }
 __device__ __forceinline__ bool pair_kept(int i, int j, int self_inter) { return self_inter ? j <= i : j < i; }
 // column of pair (i,j) in the gathered output (row-major lower triangle, dot_interaction.py:118-132)
 __device__ __forceinline__ int64_t pair_col(int i, int j, int F, int self_inter, int skip_gather) {
@@ -61,8 +62,15 @@ __device__ __forceinline__ void pick_feature(const DotParams& p, int f, const ch
     }
 }
 
-template <int ES>
+// KS > 0: the number of k steps is known at compile time (8 = D 128 in bf16): the sample's loads are issued as
+// one batch and the NEXT sample's loads are in flight while this one is multiplied and written (a run-time loop
+// of load -> MFMA pairs was one HBM latency per k step).  The pooled dots leave through a wave-private LDS row in
+// output order, so a sample is written by ceil(cols / 64) stores of 128 contiguous bytes instead of one 2-byte
+// scattered store per (row, lane) -- 27 partial-line stores per sample at F = 27.
+template <int ES, int KS>
 __global__ __launch_bounds__(256) void dot_fwd_mfma_kernel(const DotParams p) {
+  typedef typename std::conditional<ES == 2, uint16_t, float>::type elem_t;
+  __shared__ elem_t stage_all[4][kMaxFast * kMaxFast];
   const int lane = threadIdx.x & 63;
   const int f = lane & 31;
   const int half = lane >> 5;
@@ -71,42 +79,80 @@ __global__ __launch_bounds__(256) void dot_fwd_mfma_kernel(const DotParams p) {
   int64_t ld;
   pick_feature(p, f < F ? f : 0, base, ld);
   constexpr int VE = 16 / ES;  // elements per 16-byte piece
-  const int ksteps = (p.dim + 2 * VE - 1) / (2 * VE);
+  constexpr int NV = KS > 0 ? KS : 1;
+  const int ksteps = KS > 0 ? KS : (p.dim + 2 * VE - 1) / (2 * VE);
   const int64_t waves = (int64_t)gridDim.x * 4;
-  for (int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < p.batch; b += waves) {
+  const int ncols = p.skip_gather ? F * F : tri_cols(F, p.self_inter != 0);
+  elem_t* stage = stage_all[threadIdx.x >> 6];
+  elem_t* outp = reinterpret_cast<elem_t*>(p.out);
+  const u32x4 zero = {0, 0, 0, 0};
+  auto load_all = [&](int64_t b, u32x4(&v)[NV]) {   // KS > 0 only: every address is valid (f clamped, k < dim)
+    const char* row = base + b * ld * ES + half * 16;
+#pragma unroll
+    for (int ks = 0; ks < NV; ++ks) v[ks] = *reinterpret_cast<const u32x4*>(row + ks * 32);
+  };
+  u32x4 cur[NV], nxt[NV];
+  int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if constexpr (KS > 0)
+    if (b < p.batch) load_all(b, cur);
+  for (; b < p.batch; b += waves) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    const char* row = base + b * ld * ES;
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int k = ks * 2 * VE + half * VE;
-      u32x4 v = {0, 0, 0, 0};
-      if (f < F && k < p.dim) v = *reinterpret_cast<const u32x4*>(row + (int64_t)k * ES);
-      if constexpr (ES == 2) {
-        const bf16x8 x = __builtin_bit_cast(bf16x8, v);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, x, acc, 0, 0, 0);
-      } else {
+    if constexpr (KS > 0) {
+      load_all(b + waves < p.batch ? b + waves : b, nxt);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float x = __uint_as_float(v[q]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, acc, 0, 0, 0);
+      for (int ks = 0; ks < NV; ++ks) {
+        const u32x4 v = f < F ? cur[ks] : zero;
+        if constexpr (ES == 2) {
+          const bf16x8 x = __builtin_bit_cast(bf16x8, v);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, x, acc, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float x = __uint_as_float(v[q]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, acc, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < NV; ++ks) cur[ks] = nxt[ks];
+    } else {
+      const char* row = base + b * ld * ES;
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int k = ks * 2 * VE + half * VE;
+        u32x4 v = zero;
+        if (f < F && k < p.dim) v = *reinterpret_cast<const u32x4*>(row + (int64_t)k * ES);
+        if constexpr (ES == 2) {
+          const bf16x8 x = __builtin_bit_cast(bf16x8, v);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, x, acc, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float x = __uint_as_float(v[q]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, acc, 0, 0, 0);
+          }
         }
       }
     }
-    // accumulator: P[i][j], j = lane & 31, i = (r & 3) + 8*(r >> 2) + 4*half
+    // accumulator: P[i][j], j = lane & 31, i = (r & 3) + 8*(r >> 2) + 4*half  ->  the sample's output row in LDS
     const int j = f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
       if (i < F && j < F) {
         const bool keep = pair_kept(i, j, p.self_inter);
-        if (p.skip_gather)
-          st_elem(p.out, ES == 2 ? KRS_BF16 : KRS_F32, b * p.out_ld + (int64_t)i * F + j, keep ? acc[r] : 0.0f);
-        else if (keep)
-          st_elem(p.out, ES == 2 ? KRS_BF16 : KRS_F32,
-                  b * p.out_ld + pair_col(i, j, F, p.self_inter, 0), acc[r]);
+        const float v = keep ? acc[r] : 0.0f;
+        if (p.skip_gather || keep) {
+          const int c = (int)pair_col(i, j, F, p.self_inter, p.skip_gather);
+          if constexpr (ES == 2) stage[c] = f32_to_bf16(v); else stage[c] = v;
+        }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // wave-private row: LDS operations of a wave are in order
+    elem_t* orow = outp + b * p.out_ld;
+    for (int e = lane; e < ncols; e += 64) orow[e] = stage[e];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 }
 
@@ -125,7 +171,6 @@ __global__ __launch_bounds__(256) void dot_fwd_mfma_kernel(const DotParams p) {
 // before the FMAs of iteration n, so HBM latency hides under the arithmetic.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__host__ __device__ constexpr int tri_cols(int rows, bool self) { return self ? rows * (rows + 1) / 2 : rows * (rows - 1) / 2; }
 
 // ACC: features whose bit is set in p.acc_mask receive `existing + dX` (fp32 sum, one rounding): the existing
 // values are requested together with the sample's rows (same clamped addresses), one iteration ahead.
@@ -393,8 +438,10 @@ extern "C" int krs_dot_interaction_fwd(const void* const* feats, const int64_t* 
     p.n_feats = n_feats; p.batch = batch; p.dim = dim; p.self_inter = self_interaction != 0;
     p.skip_gather = skip_gather != 0; p.out = out; p.out_ld = out_ld;
     const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(batch, 4), 256 * 8);
-    if (es == 2) hipLaunchKernelGGL(dot_fwd_mfma_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(dot_fwd_mfma_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
+    if (es == 2 && dim == 128) hipLaunchKernelGGL((dot_fwd_mfma_kernel<2, 8>), dim3(blocks), dim3(256), 0, st, p);
+    else if (es == 2 && dim == 64) hipLaunchKernelGGL((dot_fwd_mfma_kernel<2, 4>), dim3(blocks), dim3(256), 0, st, p);
+    else if (es == 2) hipLaunchKernelGGL((dot_fwd_mfma_kernel<2, 0>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dot_fwd_mfma_kernel<4, 0>), dim3(blocks), dim3(256), 0, st, p);
     KRS_CHECK_LAUNCH("dot_fwd_mfma_kernel");
     return KRS_OK;
   }
