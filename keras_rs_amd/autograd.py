@@ -304,6 +304,10 @@ class EmbedBagFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None, None, *grads)
 
 
+# development switch (A/B of the two orders, see EmbedBagFusedFn.forward)
+_PLAN_AFTER_GATHER = bool(int(__import__("os").environ.get("KRS_PLAN_AFTER_GATHER", "0")))
+
+
 class EmbedBagFusedFn(torch.autograd.Function):
     """Fused gather+pool whose backward applies the per-table optimizer to the touched rows
     in place (the SparseCore-style path: jax/embedding_lookup.py:174-273 returns updated
@@ -322,6 +326,10 @@ class EmbedBagFusedFn(torch.autograd.Function):
         # HBM, the sort's scatter passes by LDS ranking work -- and the plan is done when the dense part starts
         # (queued behind the gather it ran under the first FeatureCross GEMMs and slowed them by 0.4 ms).
         ctx.plan = None
+        plan_first = not _PLAN_AFTER_GATHER
+        if not plan_first:
+            out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
+                                      out=slab[:, lead:], want_scale=True, err_flag=err_flag)
         if ctx.needs_input_grad[8]:  # a backward will follow (not under torch.no_grad())
             main = torch.cuda.current_stream()
             side = _side_stream(ids.device)
@@ -336,8 +344,9 @@ class EmbedBagFusedFn(torch.autograd.Function):
             ctx.plan = (ws, done)
         # err_flag: device int32[1] the kernel ORs KRS_FLAG_* into (out-of-range ids contribute nothing and are
         # never clamped); read later by the layer, so the step keeps running without a host sync
-        out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
-                                  out=slab[:, lead:], want_scale=True, err_flag=err_flag)
+        if plan_first:
+            out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
+                                      out=slab[:, lead:], want_scale=True, err_flag=err_flag)
         ctx.bags, ctx.batch, ctx.hots, ctx.optimizer, ctx.lead = bags, batch, hots, optimizer, lead
         ctx.save_for_backward(ids, offsets, weights, scale)
         ctx.out_meta = (out.dtype, out.device)
