@@ -338,7 +338,9 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         torch.autograd.backward([xl, inter], [g_xl, g_inter])
         if opt_box[0] is None:  # the first step has built the cross layers
             params = [p for layer in model.cross for p in layer.parameters()]
-            opt_box[0] = torch.optim.Adagrad(params, lr=0.0034, initial_accumulator_value=0.1, foreach=True)
+            from keras_rs_amd.optim import Adagrad   # torch.optim.Adagrad's arithmetic, one launch (krs_dense_adagrad)
+
+            opt_box[0] = Adagrad(params, lr=0.0034, initial_accumulator_value=0.1)
             if world > 1:
                 # dense weights are data-parallel: from the next backward on, each gradient's all-reduce starts
                 # the moment autograd has produced it and overlaps the rest of the backward pass

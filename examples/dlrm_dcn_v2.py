@@ -125,7 +125,9 @@ def train_step(model, opt_box, inputs, labels):
     loss.backward()
     if opt_box[0] is None:  # the first step has built the layers
         dense_params = [p for p in model.parameters() if p.requires_grad]
-        opt_box[0] = torch.optim.Adagrad(dense_params, lr=0.0034, initial_accumulator_value=0.1, foreach=True)
+        from keras_rs_amd.optim import Adagrad
+
+        opt_box[0] = Adagrad(dense_params, lr=0.0034, initial_accumulator_value=0.1)
     opt_box[0].step()
     opt_box[0].zero_grad(set_to_none=True)
     return loss.detach()

@@ -314,6 +314,14 @@ int krs_cast_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_s
                        void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int dst_dtype,
                        void* stream);
 
+/* Adagrad step on a list of dense fp32 weights (the FeatureCross / Dense kernels and biases of one training step) in
+ * one launch: acc += g*g; p -= lr * g / (sqrt(acc) + eps).  params / grads / accs / sizes: HOST arrays of `count`
+ * device pointers and element counts.  The optimizer the ml_perf example attaches to the dense part
+ * (examples/ml_perf/main.py: keras.optimizers.Adagrad, learning rate of configs/v6e_8.py); the fused table
+ * optimizers are K2's. */
+int krs_dense_adagrad(float* const* params, const float* const* grads, float* const* accs,
+                      const int64_t* sizes, int count, float lr, float eps, void* stream);
+
 /* Column sum: out[n] = sum_m a[m,n] (fp32 out).  Dense bias gradient. */
 int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
                float* out, void* stream);

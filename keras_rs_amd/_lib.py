@@ -75,6 +75,7 @@ SYMBOLS = [
     "krs_cross_epilogue_bwd",
     "krs_colsum",
     "krs_cast_transpose",
+    "krs_dense_adagrad",
     "krs_dot_interaction_fwd",
     "krs_dot_interaction_bwd",
     "krs_dot_interaction_bwd_accumulate",

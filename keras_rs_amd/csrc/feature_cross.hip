@@ -2086,6 +2086,73 @@ extern "C" int krs_cast_transpose(const void* src, int64_t rows, int64_t cols, i
   return KRS_OK;
 }
 
+// Dense Adagrad over a LIST of fp32 tensors in one launch (the FeatureCross / Dense weights of a step):
+//   acc += g*g;  p -= lr * g / (sqrt(acc) + eps)      -- torch.optim.Adagrad / keras Adagrad with eps outside the root
+// One workgroup per 4096-element chunk of one tensor; the (tensor, chunk) of a workgroup comes from the
+// cumulative chunk counts in the argument block (<= 32 tensors per launch).
+constexpr int kOptMax = 32, kOptChunk = 4096;
+struct DenseOptArgs {
+  float* p[kOptMax];
+  const float* g[kOptMax];
+  float* acc[kOptMax];
+  int64_t n[kOptMax];
+  int32_t chunk_end[kOptMax];   // inclusive prefix of the tensors' chunk counts
+  int count;
+  float lr, eps;
+};
+__global__ __launch_bounds__(256) void dense_adagrad_kernel(const DenseOptArgs a) {
+  int t = 0;
+  while (t + 1 < a.count && (int)blockIdx.x >= a.chunk_end[t]) ++t;
+  float* p = nullptr; const float* g = nullptr; float* acc = nullptr; int64_t n = 0; int first = 0;
+#pragma unroll
+  for (int i = 0; i < kOptMax; ++i)   // static kernarg indices
+    if (i == t) { p = a.p[i]; g = a.g[i]; acc = a.acc[i]; n = a.n[i]; first = i ? a.chunk_end[i - 1] : 0; }
+  const int64_t base = (int64_t)(blockIdx.x - first) * kOptChunk;
+  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(acc)) & 15) == 0;
+#pragma unroll
+  for (int k = 0; k < kOptChunk / 1024; ++k) {
+    const int64_t i0 = base + k * 1024 + threadIdx.x * 4;
+    if (vec && i0 + 4 <= n) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + i0);
+      float4 av = *reinterpret_cast<const float4*>(acc + i0), pv = *reinterpret_cast<const float4*>(p + i0);
+      av.x = fmaf(gv.x, gv.x, av.x); av.y = fmaf(gv.y, gv.y, av.y); av.z = fmaf(gv.z, gv.z, av.z); av.w = fmaf(gv.w, gv.w, av.w);
+      pv.x -= a.lr * gv.x / (sqrtf(av.x) + a.eps); pv.y -= a.lr * gv.y / (sqrtf(av.y) + a.eps);
+      pv.z -= a.lr * gv.z / (sqrtf(av.z) + a.eps); pv.w -= a.lr * gv.w / (sqrtf(av.w) + a.eps);
+      *reinterpret_cast<float4*>(acc + i0) = av;
+      *reinterpret_cast<float4*>(p + i0) = pv;
+    } else {
+      for (int q = 0; q < 4 && i0 + q < n; ++q) {
+        const float gq = g[i0 + q], aq = fmaf(gq, gq, acc[i0 + q]);
+        acc[i0 + q] = aq;
+        p[i0 + q] -= a.lr * gq / (sqrtf(aq) + a.eps);
+      }
+    }
+  }
+}
+
+extern "C" int krs_dense_adagrad(float* const* params, const float* const* grads, float* const* accs,
+                                 const int64_t* sizes, int count, float lr, float eps, void* stream) {
+  KRS_REQUIRE(count >= 0 && (count == 0 || (params && grads && accs && sizes)), "dense_adagrad: null tensor list");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int lo = 0; lo < count; lo += kOptMax) {
+    DenseOptArgs a{};
+    a.count = std::min(kOptMax, count - lo);
+    a.lr = lr; a.eps = eps;
+    int chunks = 0;
+    for (int i = 0; i < a.count; ++i) {
+      KRS_REQUIRE(sizes[lo + i] >= 0 && (sizes[lo + i] == 0 || (params[lo + i] && grads[lo + i] && accs[lo + i])),
+                  "dense_adagrad: null tensor");
+      a.p[i] = params[lo + i]; a.g[i] = grads[lo + i]; a.acc[i] = accs[lo + i]; a.n[i] = sizes[lo + i];
+      chunks += (int)ceil_div(sizes[lo + i], kOptChunk);
+      a.chunk_end[i] = chunks;
+    }
+    if (chunks == 0) continue;
+    hipLaunchKernelGGL(dense_adagrad_kernel, dim3((unsigned)chunks), dim3(256), 0, st, a);
+    KRS_CHECK_LAUNCH("dense_adagrad_kernel");
+  }
+  return KRS_OK;
+}
+
 extern "C" int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype, float* out,
                           void* stream) {
   KRS_REQUIRE(a && out, "colsum: null operand");

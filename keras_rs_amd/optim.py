@@ -1,0 +1,53 @@
+"""Dense-weight optimizer of the DLRM / DCN step on the C ABI (krs_dense_adagrad): every parameter of the list is
+updated by ONE launch instead of four multi-tensor passes.  Same arithmetic and state layout as
+torch.optim.Adagrad(lr_decay=0, weight_decay=0): state["sum"] starts at initial_accumulator_value."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from keras_rs_amd import _lib as L
+
+
+class Adagrad(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 0.01, initial_accumulator_value: float = 0.0, eps: float = 1e-10):
+        if lr < 0 or eps < 0 or initial_accumulator_value < 0:
+            raise ValueError("Adagrad: lr, eps and initial_accumulator_value must be non-negative")
+        super().__init__(params, dict(lr=lr, initial_accumulator_value=initial_accumulator_value, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps, gs, accs = [], [], []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                    raise L.KrsError("keras_rs_amd.optim.Adagrad: dense fp32 parameters and gradients only")
+                L.require_device(p, "Adagrad parameter")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["sum"] = torch.full_like(p, group["initial_accumulator_value"], memory_format=torch.contiguous_format)
+                st["step"] += 1
+                if not p.is_contiguous():
+                    raise L.KrsError("keras_rs_amd.optim.Adagrad: parameters must be contiguous")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                ps.append(p)
+                gs.append(g)
+                accs.append(st["sum"])
+            n = len(ps)
+            if not n:
+                continue
+            arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+            sizes = (C.c_int64 * n)(*[t.numel() for t in ps])
+            rc = L.lib().krs_dense_adagrad(arr(ps), arr(gs), arr(accs), sizes, C.c_int(n), C.c_float(group["lr"]),
+                                           C.c_float(group["eps"]), L.stream_ptr())
+            L.check(rc, "krs_dense_adagrad")
+        return loss

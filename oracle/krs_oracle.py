@@ -274,6 +274,16 @@ def dot_interaction_bwd(feats, grad_out, self_interaction=False, skip_gather=Fal
     return grads
 
 
+def dense_adagrad(p, g, acc, lr, eps):
+    """include/krs.h krs_dense_adagrad (keras / torch Adagrad on a dense fp32 weight, epsilon outside the root):
+    returns (new p, new acc); fp32 arithmetic with the fused multiply-add of acc + g*g done in float64 and
+    rounded once, as fmaf does."""
+    p, g, acc = (np.asarray(t, np.float32) for t in (p, g, acc))
+    acc2 = (acc.astype(np.float64) + g.astype(np.float64) * g.astype(np.float64)).astype(np.float32)
+    upd = (np.float32(lr) * g) / (np.sqrt(acc2) + np.float32(eps))
+    return (p - upd.astype(np.float32)).astype(np.float32), acc2
+
+
 def cast_transpose(w, to_bf16):
     """include/krs.h krs_cast_transpose: (cast(w), cast(w)^T); w fp32 array or bf16 bit pattern (uint16); the
     cast is ops.cast under a mixed-precision policy (feature_cross.py:182-194): round-to-nearest-even."""

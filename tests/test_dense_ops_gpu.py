@@ -223,6 +223,39 @@ def test_cast_transpose_is_bit_exact(src, dst, rows, cols):
     assert np.array_equal(to_np(wt2), ko.cast_transpose(np.ascontiguousarray(to_np(wide)[:, 2:2 + cols]), dst == torch.bfloat16)[1])
 
 
+def test_dense_adagrad_one_launch_matches_torch_and_the_oracle():
+    # keras_rs_amd.optim.Adagrad (krs_dense_adagrad): a list of weights of odd sizes (vector path, scalar tails, an
+    # unaligned view, > 32 tensors = two launches) against torch.optim.Adagrad and the numpy restatement, 3 steps
+    from keras_rs_amd.optim import Adagrad
+
+    rng = np.random.default_rng(3)
+    shapes = [(3456, 512), (512, 3456), (3456,), (7, 5), (1,), (4099,)] + [(17, 3)] * 30
+    base = [torch.tensor(rng.uniform(-1, 1, s).astype(np.float32), device=DEV) for s in shapes]
+    big = torch.zeros(1000 + 3, device=DEV)
+    mine = [b.clone().requires_grad_(True) for b in base] + [big[3:].detach().requires_grad_(True)]   # 12-byte offset
+    ref = [b.clone().requires_grad_(True) for b in base] + [torch.zeros(1000, device=DEV, requires_grad=True)]
+    o1 = Adagrad(mine, lr=0.0034, initial_accumulator_value=0.1)
+    o2 = torch.optim.Adagrad(ref, lr=0.0034, initial_accumulator_value=0.1, foreach=True)
+    pn = [to_np(b) for b in base] + [np.zeros(1000, np.float32)]
+    an = [np.full_like(x, 0.1) for x in pn]
+    for step in range(3):
+        gs = [torch.tensor(rng.uniform(-1, 1, tuple(p.shape)).astype(np.float32) * 10.0 ** -step, device=DEV) for p in mine]
+        for p, q, g in zip(mine, ref, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        o1.step()
+        o2.step()
+        for i, g in enumerate(gs):
+            pn[i], an[i] = ko.dense_adagrad(pn[i], to_np(g), an[i], 0.0034, 1e-10)
+    for p, q, e, ea in zip(mine, ref, pn, an):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(to_np(p.detach()), e, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(to_np(o1.state[p]["sum"]), ea, rtol=1e-6, atol=0)
+    with pytest.raises(Exception):
+        bad = torch.zeros(4, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+        bad.grad = torch.zeros_like(bad)
+        Adagrad([bad]).step()
+
+
 def test_dot_interaction_feature_limit_is_loud():
     from keras_rs_amd import dense_ops as D
     from keras_rs_amd._lib import KrsError
