@@ -344,6 +344,195 @@ void launch_dot_bwd(const DotParams& p, int lps_log2, int spw, unsigned blocks, 
     hipLaunchKernelGGL((dot_bwd_valu_kernel<ES, FR, SELF, MULTI, false>), dim3(blocks), dim3(64), lds, st, p, lps_log2, spw);
 }
 
+// ---- backward on the matrix cores (bf16, F <= 32, D a multiple of 32 up to 128, 16-byte aligned rows) ----
+// dX = Gs X per sample is C = A^T B with A[j][i] = Gs[j][i] (32 x 32, symmetric; every entry is ONE element of the
+// incoming gradient, or twice one on the diagonal: exactly representable in bf16) and B[j][d] = X[j][d].  Both
+// operands are strided in the contraction index j (the feature), which is what gfx950's transposing LDS read
+// serves: the sample's rows go to LDS as they lie in memory (the K-strided image of gemm_tn_glds_kernel) and
+// every MFMA operand is two ds_read_b64_tr_b16.  8 MFMA per sample at D = 128 replace ~750 packed FMAs and ~340
+// LDS broadcast reads per lane (that kernel issued ~5000 instructions per sample and ran at 3 TB/s).  The result
+// leaves through a wave-private fp32 LDS block per 32 columns so that lanes hold 8 consecutive columns of one
+// feature row: 16-byte loads of the stored gradient (ACC) and 16-byte stores.  The loads of sample n+1 are issued
+// before the MFMAs of sample n.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 dot_read_tr16(uint32_t addr) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* trptr;
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(uintptr_t)addr));
+}
+
+template <bool SELF, bool ACC, int NG, int NB>   // NG: gradient elements per lane; NB: 32-column blocks provided for (D <= 32 NB)
+__global__ __launch_bounds__(128) void dot_bwd_mfma_kernel(const DotParams p, int x_bytes) {
+  constexpr int kWavesPerWg = 2, GB = 2048, SST = 36;   // Gs image bytes; staging row stride (floats)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int F = p.n_feats, nblk = p.dim / 32;
+  // LDS: [64] {pointer, row stride in bytes} of the F inputs and F outputs (shared), then per wave
+  // X image | Gs image | staging block [32][SST] floats
+  u32x4* tab = reinterpret_cast<u32x4*>(smem);
+  char* mine = smem + 64 * sizeof(u32x4) + (size_t)wave * (x_bytes + GB + 32 * SST * 4);
+  char* ximg = mine;
+  char* gimg = mine + x_bytes;
+  float* stage = reinterpret_cast<float*>(mine + x_bytes + GB);
+  if (threadIdx.x < 64) {
+    const int f = threadIdx.x & 31;
+    uint64_t ptr = 0;
+    int64_t stride = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxFast; ++q)  // static kernarg indices
+      if (q == f) {
+        ptr = reinterpret_cast<uint64_t>(threadIdx.x < 32 ? p.feat[q] : p.gfeat[q]);
+        stride = threadIdx.x < 32 ? p.ld[q] : p.gld[q];
+      }
+    tab[threadIdx.x] = u32x4{(uint32_t)ptr, (uint32_t)(ptr >> 32), (uint32_t)stride * 2u, 0u};
+  }
+  for (int i = lane * 16; i < x_bytes + GB; i += 64 * 16) *reinterpret_cast<u32x4*>(mine + i) = u32x4{0, 0, 0, 0};
+  __syncthreads();
+  const int ncols = p.skip_gather ? F * F : tri_cols(F, SELF);
+  const int xrounds = (F + 3) / 4;                 // 4 feature rows per load instruction, 16 lanes x 16 B per row
+  const int cpr = p.dim / 8;                       // 16-byte chunks per feature row
+  const int items = F * 4;                         // output items of a 32-column block: (feature, chunk of 8)
+  const int64_t waves = (int64_t)gridDim.x * kWavesPerWg;
+  u32x4 xr[8];                                     // up to 32 rows
+  uint16_t gr[NG];
+  u32x4 ar[ACC ? NB * 2 : 1];                      // stored gradients: [block][round]
+  const uint16_t* gout = reinterpret_cast<const uint16_t*>(p.out);
+  auto issue = [&](int64_t b) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int f = t * 4 + (lane >> 4);
+      if (t < xrounds) {
+        const u32x4 e = tab[f < F ? f : F - 1];
+        const int c = lane & 15;
+        const uint64_t addr = (((uint64_t)e[1] << 32) | e[0]) + (uint64_t)b * e[2] + (uint32_t)(c < cpr ? c : 0) * 16u;
+        xr[t] = *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(addr);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) gr[q] = gout[b * p.out_ld + min(q * 64 + lane, ncols - 1)];
+    if constexpr (ACC) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (nb < nblk) {
+            const int it = min(t * 64 + lane, items - 1);
+            const u32x4 e = tab[32 + (it >> 2)];
+            const uint64_t addr = (((uint64_t)e[1] << 32) | e[0]) + (uint64_t)b * e[2] + (uint32_t)(nb * 32 + (it & 3) * 8) * 2u;
+            ar[nb * 2 + t] = *reinterpret_cast<const u32x4 __attribute__((address_space(1)))*>(addr);
+          }
+    }
+  };
+  const uint32_t xbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ximg;
+  const uint32_t gbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)gimg;
+  const int g4 = lane >> 4, ii = lane & 15;
+  const uint32_t frag_x = (uint32_t)((ii >> 2) * 64 + (g4 & 1) * 32 + (ii & 3) * 8 + (g4 >> 1) * 2048);
+  const uint32_t frag_g = (uint32_t)((ii >> 2) * 64 + (g4 & 1) * 32 + (ii & 3) * 8 + (g4 >> 1) * 512);
+  int64_t b = (int64_t)blockIdx.x * kWavesPerWg + wave;
+  if (b < p.batch) issue(b);
+  for (; b < p.batch; b += waves) {
+    // ---- this sample's rows and gradient matrix into LDS ----
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int f = t * 4 + (lane >> 4), c = lane & 15;
+      if (t < xrounds && f < F && c < cpr) {
+        const int col = c * 8;
+        *reinterpret_cast<u32x4*>(ximg + (col >> 7) * 8192 + (f >> 2) * 1024 + (((col & 127) >> 5) * 4 + (f & 3)) * 64 +
+                                  (col & 31) * 2) = xr[t];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const int c = q * 64 + lane;
+      if (c < ncols) {
+        int i, j;
+        if (p.skip_gather) {
+          i = c / F;
+          j = c - i * F;
+        } else if (SELF) {
+          i = (int)((sqrtf(8.0f * c + 1.0f) - 1.0f) * 0.5f);
+          while (i * (i + 1) / 2 > c) --i;
+          while ((i + 1) * (i + 2) / 2 <= c) ++i;
+          j = c - i * (i + 1) / 2;
+        } else {
+          i = (int)((sqrtf(8.0f * c + 1.0f) + 1.0f) * 0.5f);
+          while (i * (i - 1) / 2 > c) --i;
+          while ((i + 1) * i / 2 <= c) ++i;
+          j = c - i * (i - 1) / 2;
+        }
+        if (SELF ? j <= i : j < i) {
+          uint16_t* gi = reinterpret_cast<uint16_t*>(gimg);
+          if (i == j) {
+            gi[(i >> 2) * 128 + (i & 3) * 32 + i] = f32_to_bf16(2.0f * bf16_to_f32(gr[q]));
+          } else {
+            gi[(j >> 2) * 128 + (j & 3) * 32 + i] = gr[q];   // image[k = j][column i]
+            gi[(i >> 2) * 128 + (i & 3) * 32 + j] = gr[q];   // image[k = i][column j]
+          }
+        }
+      }
+    }
+    u32x4 ac[ACC ? NB * 2 : 1];
+    if constexpr (ACC) {
+#pragma unroll
+      for (int q = 0; q < NB * 2; ++q) ac[q] = ar[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // wave-private LDS: operations of a wave are in order
+    if (b + waves < p.batch) issue(b + waves);
+    // ---- C[i][d] = sum_j Gs[j][i] X[j][d] ----
+    u32x4 fg[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const u32x2 lo = dot_read_tr16(gbase + ks * 1024 + frag_g), hi = dot_read_tr16(gbase + ks * 1024 + frag_g + 256);
+      fg[ks] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (nb < nblk) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint32_t a = xbase + (nb >> 2) * 8192 + (nb & 3) * 256 + ks * 4096 + frag_x;
+          const u32x2 lo = dot_read_tr16(a), hi = dot_read_tr16(a + 1024);
+          const u32x4 fx = u32x4{lo.x, lo.y, hi.x, hi.y};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fg[ks]), __builtin_bit_cast(bf16x8, fx),
+                                                       acc, 0, 0, 0);
+        }
+        // accumulator: C[i][d], d = lane & 31, i = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * SST + (lane & 31)] = acc[r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int it = t * 64 + lane;
+          if (it < items) {
+            const int i = it >> 2, c8 = (it & 3) * 8;
+            const float4 v0 = *reinterpret_cast<const float4*>(stage + i * SST + c8);
+            const float4 v1 = *reinterpret_cast<const float4*>(stage + i * SST + c8 + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if constexpr (ACC) {
+              if ((p.acc_mask >> i) & 1u) {
+                const u32x4 e = ac[nb * 2 + t];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  v[2 * q] += __uint_as_float(e[q] << 16);
+                  v[2 * q + 1] += __uint_as_float(e[q] & 0xffff0000u);
+                }
+              }
+            }
+            const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            const u32x4 e = tab[32 + i];
+            const uint64_t dst = (((uint64_t)e[1] << 32) | e[0]) + (uint64_t)b * e[2] + (uint32_t)(nb * 32 + c8) * 2u;
+            *reinterpret_cast<u32x4 __attribute__((address_space(1)))*>(dst) = o;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
+    }
+  }
+}
+
 // ---- plain kernels (any D / alignment, F <= 64); the pointer tables travel as kernel arguments ----
 constexpr int kMaxGeneric = 64;
 struct DotGenericParams {
@@ -482,6 +671,40 @@ extern "C" int krs_dot_interaction_bwd_accumulate(const void* const* feats, cons
     fast = !(reinterpret_cast<uintptr_t>(feats[f]) % (2 * es)) && !(reinterpret_cast<uintptr_t>(grad_feats[f]) % (2 * es)) &&
            ld[f] % 2 == 0 && grad_feat_ld[f] % 2 == 0 && ld[f] > 0 && grad_feat_ld[f] > 0 &&
            (batch * ld[f] + dim) * es < (int64_t(1) << 31) && (batch * grad_feat_ld[f] + dim) * es < (int64_t(1) << 31);
+  // matrix-core path: bf16, rows of whole 32-column blocks (one 16-lane group loads a row: D <= 128), 16-byte aligned rows
+  bool mfma_ok = es == 2 && n_feats <= kMaxFast && dim % 32 == 0 && dim <= 128 && !getenv("KRS_DOT_BWD_VALU") &&
+                 (skip_gather || tri_cols(n_feats, self_interaction != 0) > 0);
+  for (int f = 0; mfma_ok && f < n_feats; ++f)
+    mfma_ok = !(reinterpret_cast<uintptr_t>(feats[f]) % 16) && !(reinterpret_cast<uintptr_t>(grad_feats[f]) % 16) &&
+              ld[f] % 8 == 0 && grad_feat_ld[f] % 8 == 0 && ld[f] > 0 && grad_feat_ld[f] > 0 &&
+              ld[f] * 2 < (int64_t(1) << 32) && grad_feat_ld[f] * 2 < (int64_t(1) << 32);
+  if (mfma_ok) {
+    DotParams p{};
+    for (int f = 0; f < kMaxFast; ++f) {
+      const int q = std::min(f, n_feats - 1);
+      p.feat[f] = feats[q]; p.ld[f] = ld[q]; p.gfeat[f] = grad_feats[q]; p.gld[f] = grad_feat_ld[q];
+    }
+    p.n_feats = n_feats; p.batch = batch; p.dim = dim; p.self_inter = self_interaction != 0;
+    p.skip_gather = skip_gather != 0; p.out = const_cast<void*>(grad_out); p.out_ld = grad_ld;
+    p.acc_mask = (uint32_t)accumulate_mask;
+    const int x_bytes = (dim + 127) / 128 * 8192;
+    const size_t lds = 64 * 16 + (size_t)2 * (x_bytes + 2048 + 32 * 36 * 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(batch, 2), 256 * 8);
+    const bool self = self_interaction != 0, acc = accumulate_mask != 0;
+#define KRS_DOT_MFMA(SELF, ACC, NG, NB) \
+  hipLaunchKernelGGL((dot_bwd_mfma_kernel<SELF, ACC, NG, NB>), dim3(blocks), dim3(128), lds, st, p, x_bytes)
+#define KRS_DOT_MFMA_NB(SELF, ACC, NG) \
+  { KRS_DOT_MFMA(SELF, ACC, NG, 4); }
+#define KRS_DOT_MFMA_NG(SELF, ACC) \
+  { if (skip_gather) KRS_DOT_MFMA_NB(SELF, ACC, 16) else KRS_DOT_MFMA_NB(SELF, ACC, 9) }
+    if (self) { if (acc) KRS_DOT_MFMA_NG(true, true) else KRS_DOT_MFMA_NG(true, false) }
+    else { if (acc) KRS_DOT_MFMA_NG(false, true) else KRS_DOT_MFMA_NG(false, false) }
+#undef KRS_DOT_MFMA_NG
+#undef KRS_DOT_MFMA_NB
+#undef KRS_DOT_MFMA
+    KRS_CHECK_LAUNCH("dot_bwd_mfma_kernel");
+    return KRS_OK;
+  }
   if (fast) {
     DotParams p{};
     for (int f = 0; f < kMaxFast; ++f) {

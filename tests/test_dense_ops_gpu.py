@@ -152,7 +152,8 @@ def test_dot_interaction_kat_through_hip(case):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("F,D_,B", [(3, 5, 4), (27, 128, 70), (8, 64, 33), (32, 16, 9), (40, 8, 5), (4, 256, 6)])
+@pytest.mark.parametrize("F,D_,B", [(3, 5, 4), (27, 128, 70), (8, 64, 33), (32, 16, 9), (40, 8, 5), (4, 256, 6), (32, 128, 7),
+                                    (2, 32, 300), (17, 96, 2)])
 @pytest.mark.parametrize("si,sg", [(False, False), (True, False), (False, True), (True, True)])
 def test_dot_interaction_fwd_bwd(dt, F, D_, B, si, sg):
     from keras_rs_amd import dense_ops as D
