@@ -1518,11 +1518,12 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   // (K = 512: eight tiles, then a heavy epilogue) run better on the register-staged kernel, whose
   // 36 KB of LDS lets three workgroups share a CU and hide each other's epilogues.
   const bool dma_ok = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0;
-  const bool use_glds = dma_ok && p.k >= 1024;
+  static const bool force128 = getenv("KRS_GEMM_FORCE128") != nullptr;   // development: 128 x 128 tiles, 2 workgroups per CU
+  const bool use_glds = dma_ok && (p.k >= 1024 || force128);
   // ... provided its 4x larger tiles still cover most of the 256 CUs (a per-rank batch of 8192 rows against
   // N = 512 is 64 such tiles: the 128x128 kernels below launch 256 workgroups instead)
   const bool fills256 = ceil_div(p.m, 256) * ceil_div(p.n, 256) >= 192;
-  if (dma_ok && p.k >= 256 && p.m >= 256 && p.n >= 256 && fills256) {
+  if (dma_ok && p.k >= 256 && p.m >= 256 && p.n >= 256 && fills256 && !force128) {
     const size_t lds256 = 2 * 512 * ROW_BYTES;  // 2 stages x (256 A rows + 256 B rows) x 128 B
     const dim3 grid256((unsigned)(ceil_div(ceil_div(p.m, 256), 8) * 8 * ceil_div(p.n, 256)));
     if constexpr (ES == 2) {
