@@ -1296,7 +1296,8 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
       u32x4 fa[4], fb[2];
       // ---- phase 2kb ----
       load_frags(rd, 0, fa, fb);
-      issue_b(wb);   // (the piece in FRONT of the fragment reads: 227 / 241 us against 204 / 210, K-contiguous / K-strided)
+      issue_b(wb);   // (the piece in FRONT of the fragment reads: 227 / 241 us against 204 / 210, K-contiguous / K-strided;
+                     //  its second instruction moved behind the second MFMA of the compute segment: equal)
       pp_barrier();
       if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
       mfma8(fa, fb);
@@ -1518,7 +1519,8 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   // (K = 512: eight tiles, then a heavy epilogue) run better on the register-staged kernel, whose
   // 36 KB of LDS lets three workgroups share a CU and hide each other's epilogues.
   const bool dma_ok = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0;
-  static const bool force128 = getenv("KRS_GEMM_FORCE128") != nullptr;   // development: 128 x 128 tiles, 2 workgroups per CU
+  // development switch: 128 x 128 tiles at two workgroups per CU for every LDS-DMA shape (y = cross(h V): 474 us against 429)
+  static const bool force128 = getenv("KRS_GEMM_FORCE128") != nullptr;
   const bool use_glds = dma_ok && (p.k >= 1024 || force128);
   // ... provided its 4x larger tiles still cover most of the 256 CUs (a per-rank batch of 8192 rows against
   // N = 512 is 64 such tiles: the 128x128 kernels below launch 256 workgroups instead)
