@@ -314,6 +314,13 @@ int krs_cast_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_s
                        void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int dst_dtype,
                        void* stream);
 
+/* Backward of the bias + activation epilogue of a Dense layer (keras.layers.Dense inside the DLRM MLP blocks,
+ * examples/ml_perf/model.py:214-262): dz [m,n] = g * act'(y) with the derivative taken from the saved output y
+ * (relu: y > 0; sigmoid: y(1-y); tanh: 1-y^2; none: 1, y may be NULL) and dbias [n] = column sums of dz (fp32).
+ * dz or dbias may be NULL. */
+int krs_dense_act_bwd(const void* g, int64_t ld_g, const void* y, int64_t ld_y, void* dz, int64_t ld_dz,
+                      float* dbias, int64_t m, int64_t n, int act, int dtype, void* stream);
+
 /* Adagrad step on a list of dense fp32 weights (the FeatureCross / Dense kernels and biases of one training step) in
  * one launch: acc += g*g; p -= lr * g / (sqrt(acc) + eps).  params / grads / accs / sizes: HOST arrays of `count`
  * device pointers and element counts.  The optimizer the ml_perf example attaches to the dense part

@@ -76,6 +76,7 @@ SYMBOLS = [
     "krs_colsum",
     "krs_cast_transpose",
     "krs_dense_adagrad",
+    "krs_dense_act_bwd",
     "krs_dot_interaction_fwd",
     "krs_dot_interaction_bwd",
     "krs_dot_interaction_bwd_accumulate",

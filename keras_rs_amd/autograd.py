@@ -202,19 +202,10 @@ class DenseFn(torch.autograd.Function):
         xc, kc, y = ctx.saved_tensors
         act, has_bias, x_dt, k_dt = ctx.meta
         g = g.to(xc.dtype)
-        if act == L.ACT_RELU:
-            dz = g * (y > 0).to(g.dtype)
-        elif act == L.ACT_SIGMOID:
-            yf = y.float()
-            dz = (g.float() * yf * (1.0 - yf)).to(g.dtype)
-        elif act == L.ACT_TANH:
-            yf = y.float()
-            dz = (g.float() * (1.0 - yf * yf)).to(g.dtype)
-        else:
-            dz = g
+        # dz = g * act'(y) and the bias gradient in one pass (krs_dense_act_bwd)
+        dz, db = D.dense_act_bwd(g, y, act, want_dbias=has_bias)
         dz = dz.contiguous()
         dk, _ = D.gemm(xc, dz, a_is_km=True, out_dtype=torch.float32)            # [in, units]
-        db = D.colsum(dz) if has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx, _ = D.gemm(dz, kc, b_is_nk=True)                                   # [B, in]

@@ -2046,6 +2046,115 @@ extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* 
   return KRS_OK;
 }
 
+// Backward of a Dense layer's bias + activation epilogue: dz = g * act'(y) from the saved OUTPUT y, and
+// dbias = column sums of dz (fp32, of the unrounded products), in one pass (it was a compare, a cast, a multiply
+// and a separate column-sum launch per layer).  Same walk as cross_bwd_vec_kernel: a thread owns V columns and
+// walks the rows of its wave's chunk with two rows of loads in flight.
+struct DenseBwdParams {
+  const void* g;
+  const void* y;
+  void* dz;
+  float* dbias;
+  int64_t m, n, ldg, ldy, ldz;
+  int act, dtype;
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dense_act_bwd_vec_kernel(const DenseBwdParams p, int rows_per_block) {
+  __shared__ float red[4][64 * V];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = ((int64_t)blockIdx.x * 64 + lane) * V < p.n;
+  const int64_t col = live ? ((int64_t)blockIdx.x * 64 + lane) * V : 0;
+  const int64_t r0 = ((int64_t)blockIdx.y * 4 + wave) * rows_per_block;
+  const int64_t r1 = min(p.m, r0 + rows_per_block);
+  const int64_t rend = live ? r1 : r0;
+  float db[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) db[k] = 0.0f;
+  typedef typename RowVec<T, V>::raw_t raw_t;
+  constexpr int AHEAD = 2;
+  raw_t rg[AHEAD], ry[AHEAD];
+  const void* ysrc = p.y ? p.y : p.g;   // no activation: the value is ignored
+  const int64_t ldy = p.y ? p.ldy : p.ldg;
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a) {
+    const int64_t ra = max(min(r0 + a, r1 - 1), (int64_t)0);
+    rg[a] = RowVec<T, V>::load_raw(p.g, ra * p.ldg + col);
+    ry[a] = RowVec<T, V>::load_raw(ysrc, ra * ldy + col);
+  }
+  for (int64_t i = r0; i < rend; ++i) {
+    float g[V], y[V], dz[V];
+    RowVec<T, V>::unpack(rg[0], g);
+    RowVec<T, V>::unpack(ry[0], y);
+#pragma unroll
+    for (int a = 0; a + 1 < AHEAD; ++a) { rg[a] = rg[a + 1]; ry[a] = ry[a + 1]; }
+    {
+      const int64_t rn = min(i + AHEAD, r1 - 1);
+      rg[AHEAD - 1] = RowVec<T, V>::load_raw(p.g, rn * p.ldg + col);
+      ry[AHEAD - 1] = RowVec<T, V>::load_raw(ysrc, rn * ldy + col);
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      dz[k] = g[k] * act_grad_from_output(p.act, y[k]);
+      db[k] += dz[k];
+    }
+    if (p.dz) RowVec<T, V>::store(p.dz, i * p.ldz + col, dz);
+  }
+  if (p.dbias) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[wave][lane * V + k] = db[k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 64 * V; c += 256) {
+      const int64_t cc = (int64_t)blockIdx.x * 64 * V + c;
+      if (cc < p.n) atomicAdd(p.dbias + cc, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    }
+  }
+}
+__global__ __launch_bounds__(64) void dense_act_bwd_scalar_kernel(const DenseBwdParams p, int rows_per_block) {
+  const int64_t col = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (col >= p.n) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(p.m, r0 + rows_per_block);
+  float db = 0.0f;
+  for (int64_t i = r0; i < r1; ++i) {
+    const float yv = p.y ? ld_elem(p.y, p.dtype, i * p.ldy + col) : 0.0f;
+    const float dz = ld_elem(p.g, p.dtype, i * p.ldg + col) * act_grad_from_output(p.act, yv);
+    db += dz;
+    if (p.dz) st_elem(p.dz, p.dtype, i * p.ldz + col, dz);
+  }
+  if (p.dbias) atomicAdd(p.dbias + col, db);
+}
+
+extern "C" int krs_dense_act_bwd(const void* g, int64_t ld_g, const void* y, int64_t ld_y, void* dz, int64_t ld_dz,
+                                 float* dbias, int64_t m, int64_t n, int act, int dtype, void* stream) {
+  KRS_REQUIRE(g && (dz || dbias), "dense_act_bwd: null operand");
+  KRS_REQUIRE(act == KRS_ACT_NONE || y, "dense_act_bwd: an activation needs the saved output y");
+  KRS_REQUIRE(m >= 0 && n >= 0 && ld_g >= n && (!y || ld_y >= n) && (!dz || ld_dz >= n), "dense_act_bwd: bad sizes");
+  KRS_REQUIRE(dtype == KRS_F32 || dtype == KRS_BF16, "dense_act_bwd: dtype must be f32 or bf16");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dbias) KRS_HIP(hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), st));
+  if (m == 0 || n == 0) return KRS_OK;
+  DenseBwdParams p{g, y, dz, dbias, m, n, ld_g, ld_y, ld_dz, act, dtype};
+  const int v = dtype == KRS_BF16 ? 8 : 4;
+  const int es = dtype == KRS_BF16 ? 2 : 4;
+  bool vec = n % v == 0 && ld_g % v == 0 && (!y || ld_y % v == 0) && (!dz || ld_dz % v == 0);
+  for (const void* q : {g, y, (const void*)dz}) vec = vec && reinterpret_cast<uintptr_t>(q) % 16 == 0;
+  (void)es;
+  const int64_t cols = vec ? n / v : n;
+  const int64_t strips = ceil_div(cols, 64);
+  int64_t chunks = ceil_div(4096, strips);
+  if (chunks > m) chunks = m;
+  const int rows_per_block = (int)ceil_div(m, chunks);
+  if (vec) {
+    const dim3 grid4((unsigned)strips, (unsigned)ceil_div(ceil_div(m, rows_per_block), 4));
+    if (dtype == KRS_BF16) hipLaunchKernelGGL((dense_act_bwd_vec_kernel<uint16_t, 8>), grid4, dim3(256), 0, st, p, rows_per_block);
+    else hipLaunchKernelGGL((dense_act_bwd_vec_kernel<float, 4>), grid4, dim3(256), 0, st, p, rows_per_block);
+  } else {
+    hipLaunchKernelGGL(dense_act_bwd_scalar_kernel, dim3((unsigned)strips, (unsigned)ceil_div(m, rows_per_block)), dim3(64), 0,
+                       st, p, rows_per_block);
+  }
+  KRS_CHECK_LAUNCH("dense_act_bwd_kernel");
+  return KRS_OK;
+}
+
 // Weight preparation of a Dense / FeatureCross step: dst = cast(src) and dst_t = cast(src)^T in one pass over
 // a 64 x 64 tile staged in LDS (padded rows: conflict-free in both directions).  The weights are a few MB, so
 // the separate cast + transposed copy of every step were launch-bound (four ~16 us launches per cross layer).

@@ -124,6 +124,27 @@ def colsum(a: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def dense_act_bwd(g: torch.Tensor, y: torch.Tensor | None, act: int, want_dbias: bool = True):
+    """(dz, dbias) of a Dense layer's bias + activation epilogue: dz = g * act'(y) from the saved output y
+    (None without an activation), dbias = fp32 column sums of dz (None if not wanted); krs_dense_act_bwd."""
+    g = _rowmajor(g, "dense_act_bwd g")
+    m, n = g.shape
+    if y is not None:
+        y = _rowmajor(y, "dense_act_bwd y")
+        if y.dtype != g.dtype or tuple(y.shape) != (m, n):
+            raise L.KrsError("dense_act_bwd: y must have the shape and dtype of g")
+    need_dz = act != L.ACT_NONE
+    dz = torch.empty((m, n), dtype=g.dtype, device=g.device) if need_dz else None
+    db = torch.empty(n, dtype=torch.float32, device=g.device) if want_dbias else None
+    if need_dz or want_dbias:
+        rc = L.lib().krs_dense_act_bwd(L.ptr(g), C.c_int64(g.stride(0)), L.ptr(y if need_dz else None),
+                                       C.c_int64(y.stride(0) if (y is not None and need_dz) else n),
+                                       L.ptr(dz), C.c_int64(n), L.ptr(db), C.c_int64(m), C.c_int64(n), C.c_int(act),
+                                       C.c_int(L.fdtype(g)), L.stream_ptr())
+        L.check(rc, "krs_dense_act_bwd")
+    return (dz if need_dz else g), db
+
+
 def cast_transpose(w: torch.Tensor, dtype: torch.dtype, want_plain: bool = True, want_t: bool = True):
     """(w.to(dtype), w.to(dtype).t().contiguous()) of a 2-D weight in ONE launch (krs_cast_transpose); an output
     that is not wanted is None; the plain one is `w` itself when it already has the dtype and is row-major."""

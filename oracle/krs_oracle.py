@@ -274,6 +274,22 @@ def dot_interaction_bwd(feats, grad_out, self_interaction=False, skip_gather=Fal
     return grads
 
 
+def dense_act_bwd(g, y, act):
+    """include/krs.h krs_dense_act_bwd (autodiff of keras.layers.Dense's activation + bias, derivative from the saved
+    output): g, y fp32 arrays or bf16 bit patterns; returns (dz in the input format, dbias fp32 = column sums of the
+    unrounded products accumulated in float64)."""
+    bf = g.dtype == np.uint16
+    gf = bf16_bits_to_f32(g) if bf else np.asarray(g, np.float32)
+    if act in (None, "none", 0):
+        d = np.ones_like(gf)
+    else:
+        yf = bf16_bits_to_f32(y) if bf else np.asarray(y, np.float32)
+        d = {"relu": (yf > 0).astype(np.float32), "sigmoid": yf * (np.float32(1) - yf),
+             "tanh": np.float32(1) - yf * yf}[act]
+    dz = (gf * d).astype(np.float32)
+    return (f32_to_bf16_bits(dz) if bf else dz), dz.astype(np.float64).sum(0).astype(np.float32)
+
+
 def dense_adagrad(p, g, acc, lr, eps):
     """include/krs.h krs_dense_adagrad (keras / torch Adagrad on a dense fp32 weight, epsilon outside the root):
     returns (new p, new acc); fp32 arithmetic with the fused multiply-add of acc + g*g done in float64 and

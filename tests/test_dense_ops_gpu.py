@@ -224,6 +224,28 @@ def test_cast_transpose_is_bit_exact(src, dst, rows, cols):
     assert np.array_equal(to_np(wt2), ko.cast_transpose(np.ascontiguousarray(to_np(wide)[:, 2:2 + cols]), dst == torch.bfloat16)[1])
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,n", [(300, 1024), (65, 7), (1, 8), (4099, 256), (33, 1)])
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "tanh", "none"])
+def test_dense_act_bwd(dt, m, n, act):
+    from keras_rs_amd import _lib as KL
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(m * 13 + n)
+    g = _t(rng.uniform(-1, 1, (m, n)), dt)
+    y = _t(rng.uniform(-1, 1, (m, n)) if act != "sigmoid" else rng.uniform(0, 1, (m, n)), dt)
+    code = {"relu": KL.ACT_RELU, "sigmoid": KL.ACT_SIGMOID, "tanh": KL.ACT_TANH, "none": KL.ACT_NONE}[act]
+    dz, db = D.dense_act_bwd(g, None if act == "none" else y, code)
+    edz, edb = ko.dense_act_bwd(to_np(g), to_np(y), act)
+    if act in ("relu", "none"):
+        assert np.array_equal(to_np(dz), edz)                               # one multiply, one rounding: bit-exact
+    else:   # 1 - y*y / y*(1 - y) may be contracted into a fused multiply-add on the device
+        np.testing.assert_allclose(to_f32(to_np(dz)), to_f32(edz), rtol=2 ** -7 if dt == torch.bfloat16 else 1e-6, atol=1e-7)
+    np.testing.assert_allclose(db.cpu().numpy(), edb, rtol=1e-5, atol=1e-4 * max(1.0, m / 100))
+    if act == "none":
+        assert dz.data_ptr() == g.data_ptr()                                # nothing copied
+
+
 def test_dense_adagrad_one_launch_matches_torch_and_the_oracle():
     # keras_rs_amd.optim.Adagrad (krs_dense_adagrad): a list of weights of odd sizes (vector path, scalar tails, an
     # unaligned view, > 32 tensors = two launches) against torch.optim.Adagrad and the numpy restatement, 3 steps
