@@ -1359,41 +1359,157 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
 // one column of the WIDE operand (coalesced across the workgroup), the THIN operand's rows are
 // staged in LDS and broadcast, K is split over blockIdx.y into fp32 slabs (fixed-order reduce).
 constexpr int kThinMax = 16;
-__global__ __launch_bounds__(256) void gemm_thin_kernel(const GemmParams p, int in_dtype, int thin_is_a) {
-  __shared__ float thin[128][kThinMax];
-  const char* wide_p = thin_is_a ? p.b : p.a;
-  const char* thin_p = thin_is_a ? p.a : p.b;
+// ES: operand element size (2 = bf16, 4 = fp32); NT: thin extent rounded up to 1 / 4 / 8 / 16 (the LDS rows are
+// read as float4).  Eight rows of the wide operand are requested before they are consumed; a split is 256 rows of K
+// (pick_splits), so the 13 x 512 and 256 x 1 gradients of the DLRM MLPs run as ~500 workgroups instead of 128 that
+// each walked 1024 rows one dependent load at a time (394 us -> see DESIGN.md).
+template <int ES, int NT>
+__global__ __launch_bounds__(256) void gemm_thin_kernel(const GemmParams p, int thin_is_a) {
+  typedef typename std::conditional<ES == 2, uint16_t, float>::type elem_t;
+  __shared__ __attribute__((aligned(16))) float thin[128][NT];
+  const elem_t* wide_p = reinterpret_cast<const elem_t*>(thin_is_a ? p.b : p.a);
+  const elem_t* thin_p = reinterpret_cast<const elem_t*>(thin_is_a ? p.a : p.b);
   const int64_t ldw = thin_is_a ? p.ldb : p.lda, ldt = thin_is_a ? p.lda : p.ldb;
   const int64_t n_wide = thin_is_a ? p.n : p.m;
   const int n_thin = (int)(thin_is_a ? p.m : p.n);
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t ccol = col < n_wide ? col : n_wide - 1;   // idle threads load a valid column and store nothing
   const int split = blockIdx.y;
   const int64_t kbeg = (int64_t)split * p.k_per_split;
   const int64_t kend = min(p.k, kbeg + p.k_per_split);
-  float acc[kThinMax];
+  auto cvt = [](elem_t v) -> float {
+    if constexpr (ES == 2) return bf16_to_f32(v);
+    else return v;
+  };
+  float acc[NT];
 #pragma unroll
-  for (int i = 0; i < kThinMax; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < NT; ++i) acc[i] = 0.0f;
   for (int64_t k0 = kbeg; k0 < kend; k0 += 128) {
     const int rows = (int)min<int64_t>(128, kend - k0);
     __syncthreads();
-    for (int e = threadIdx.x; e < 128 * kThinMax; e += 256) {
-      const int r = e / kThinMax, i = e % kThinMax;
-      thin[r][i] = (r < rows && i < n_thin) ? ld_elem(thin_p, in_dtype, (k0 + r) * ldt + i) : 0.0f;
+    for (int e = threadIdx.x; e < 128 * NT; e += 256) {
+      const int r = e / NT, i = e % NT;
+      thin[r][i] = (r < rows && i < n_thin) ? cvt(thin_p[(k0 + r) * ldt + i]) : 0.0f;
     }
     __syncthreads();
-    if (col < n_wide) {
-      for (int r = 0; r < rows; ++r) {
-        const float w = ld_elem(wide_p, in_dtype, (k0 + r) * ldw + col);
+    for (int r = 0; r < rows; r += 8) {
+      elem_t wv[8];
 #pragma unroll
-        for (int i = 0; i < kThinMax; ++i) acc[i] = fmaf(thin[r][i], w, acc[i]);
+      for (int q = 0; q < 8; ++q) wv[q] = wide_p[min(k0 + r + q, kend - 1) * ldw + ccol];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float w = r + q < rows ? cvt(wv[q]) : 0.0f;
+        if constexpr (NT == 1) {
+          acc[0] = fmaf(thin[r + q][0], w, acc[0]);
+        } else {
+#pragma unroll
+          for (int i4 = 0; i4 < NT / 4; ++i4) {
+            const float4 t = *reinterpret_cast<const float4*>(&thin[(r + q) & 127][i4 * 4]);
+            acc[i4 * 4 + 0] = fmaf(t.x, w, acc[i4 * 4 + 0]);
+            acc[i4 * 4 + 1] = fmaf(t.y, w, acc[i4 * 4 + 1]);
+            acc[i4 * 4 + 2] = fmaf(t.z, w, acc[i4 * 4 + 2]);
+            acc[i4 * 4 + 3] = fmaf(t.w, w, acc[i4 * 4 + 3]);
+          }
+        }
       }
     }
   }
   if (col >= n_wide) return;
-  for (int i = 0; i < n_thin; ++i) {
-    const int64_t m = thin_is_a ? i : col, n = thin_is_a ? col : i;
-    if (p.splits > 1) p.slabs[((int64_t)split * p.m + m) * p.n + n] = acc[i];
-    else epilogue_store(p, m, n, acc[i]);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    if (i < n_thin) {
+      const int64_t m = thin_is_a ? i : col, n = thin_is_a ? col : i;
+      if (p.splits > 1) p.slabs[((int64_t)split * p.m + m) * p.n + n] = acc[i];
+      else epilogue_store(p, m, n, acc[i]);
+    }
+  }
+}
+
+// Products with ONE tiny dimension on the output side or in the contraction, row-major A (the last Dense of the
+// DLRM top MLP: 256 -> 1 unit, forward and data gradient; one thread per output element with 64-bit divisions
+// took 235 us for either):
+//   gemm_rowdot_kernel  N <= 8, any K: 16 lanes per row of A, each lane walks its 16-byte chunks of the row and
+//                       keeps N partial dots; butterfly reduction; lane 0 stores through the epilogue
+//   gemm_smallk_kernel  K <= 16, N a multiple of 8: a thread owns 8 consecutive outputs of one row
+template <int ES>
+__global__ __launch_bounds__(256) void gemm_rowdot_kernel(const GemmParams p) {
+  typedef typename std::conditional<ES == 2, uint16_t, float>::type elem_t;
+  constexpr int VE = 16 / ES;
+  const int sub = threadIdx.x & 15;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t r = row < p.m ? row : p.m - 1;
+  const elem_t* a = reinterpret_cast<const elem_t*>(p.a) + r * p.lda;
+  const elem_t* b = reinterpret_cast<const elem_t*>(p.b);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  for (int64_t k0 = (int64_t)sub * VE; k0 < p.k; k0 += 16 * VE) {
+    float av[VE];
+    if (k0 + VE <= p.k && (reinterpret_cast<uintptr_t>(a + k0) & 15) == 0) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(a + k0);
+      if constexpr (ES == 2) {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[2 * q] = __uint_as_float(w[q] << 16); av[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+      } else {
+        av[0] = __uint_as_float(raw.x); av[1] = __uint_as_float(raw.y); av[2] = __uint_as_float(raw.z); av[3] = __uint_as_float(raw.w);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < VE; ++q) {
+        if constexpr (ES == 2) av[q] = k0 + q < p.k ? bf16_to_f32(a[k0 + q]) : 0.0f;
+        else av[q] = k0 + q < p.k ? a[k0 + q] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < p.n) {
+#pragma unroll
+        for (int q = 0; q < VE; ++q) {
+          if (k0 + q < p.k) {
+            const elem_t bv = p.b_nk ? b[(int64_t)j * p.ldb + k0 + q] : b[(k0 + q) * p.ldb + j];
+            float bf;
+            if constexpr (ES == 2) bf = bf16_to_f32(bv); else bf = bv;
+            acc[j] = fmaf(av[q], bf, acc[j]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int o = 8; o; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+  if (sub == 0 && row < p.m)
+    for (int j = 0; j < p.n; ++j) epilogue_store(p, row, j, acc[j]);
+}
+
+template <int ES>
+__global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmParams p) {
+  typedef typename std::conditional<ES == 2, uint16_t, float>::type elem_t;
+  const int64_t n8 = p.n / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.m * n8) return;
+  const int64_t i = idx / n8, j0 = (idx - i * n8) * 8;
+  const elem_t* a = reinterpret_cast<const elem_t*>(p.a) + i * p.lda;
+  const elem_t* b = reinterpret_cast<const elem_t*>(p.b);
+  auto f = [](elem_t v) -> float {
+    if constexpr (ES == 2) return bf16_to_f32(v);
+    else return v;
+  };
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+  for (int kk = 0; kk < (int)p.k; ++kk) {
+    const float av = f(a[kk]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaf(av, f(p.b_nk ? b[(j0 + j) * p.ldb + kk] : b[(int64_t)kk * p.ldb + j0 + j]), v[j]);
+  }
+  if (p.ep_vec) {
+    epilogue_store_vec8(p, i, j0, v);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) epilogue_store(p, i, j0 + j, v[j]);
   }
 }
 
@@ -1451,6 +1567,10 @@ int gemm_pipe() {
 // -- 2 x 14 tiles of the C3 weight gradients: 9 splits = 252 workgroups in ONE round (16 splits were 448
 // workgroups = 1.75 rounds, and 113 MB of slabs instead of 64).
 int pick_splits(int64_t m, int64_t n, int64_t k, int a_is_km) {
+  if (a_is_km && k >= 1024 && std::min(m, n) <= 16) {   // gemm_thin_kernel: 256 rows of K per split
+    const int64_t s = k / 256;
+    return (int)(s > 256 ? 256 : s);
+  }
   if (a_is_km && m >= 256 && n >= 256 && k % 64 == 0 && k >= 4096) {
     const int64_t t256 = ceil_div(m, 256) * ceil_div(n, 256);
     const double slab = (double)m * (double)n * 6.45e-5;   // slab write + read of one split, in units of one k step of a tile
@@ -1970,13 +2090,37 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
     }
     const int thin_is_a = m <= n;
     const int64_t n_wide = thin_is_a ? n : m;
-    hipLaunchKernelGGL(gemm_thin_kernel, dim3((unsigned)ceil_div(n_wide, 256), (unsigned)p.splits), dim3(256), 0, st, p,
-                       in_dtype, thin_is_a);
+    const int64_t n_thin = thin_is_a ? m : n;
+    const dim3 tgrid((unsigned)ceil_div(n_wide, 256), (unsigned)p.splits);
+#define KRS_THIN(ES_, NT_) hipLaunchKernelGGL((gemm_thin_kernel<ES_, NT_>), tgrid, dim3(256), 0, st, p, thin_is_a)
+#define KRS_THIN_NT(ES_)                                          \
+  {                                                               \
+    if (n_thin <= 1) KRS_THIN(ES_, 1);                            \
+    else if (n_thin <= 4) KRS_THIN(ES_, 4);                       \
+    else if (n_thin <= 8) KRS_THIN(ES_, 8);                       \
+    else KRS_THIN(ES_, 16);                                       \
+  }
+    if (in_dtype == KRS_BF16) KRS_THIN_NT(2) else KRS_THIN_NT(4)
+#undef KRS_THIN_NT
+#undef KRS_THIN
     KRS_CHECK_LAUNCH("gemm_thin_kernel");
     if (p.splits > 1) {
       hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p);
       KRS_CHECK_LAUNCH("gemm_slab_reduce_kernel");
     }
+    return KRS_OK;
+  }
+  if (!p.a_km && p.splits == 1 && n <= 8 && k >= 32 && m >= 1024) {
+    if (in_dtype == KRS_BF16) hipLaunchKernelGGL(gemm_rowdot_kernel<2>, dim3((unsigned)ceil_div(m, 16)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_rowdot_kernel<4>, dim3((unsigned)ceil_div(m, 16)), dim3(256), 0, st, p);
+    KRS_CHECK_LAUNCH("gemm_rowdot_kernel");
+    return KRS_OK;
+  }
+  if (!p.a_km && p.splits == 1 && k <= 16 && n % 8 == 0 && m * n >= (1 << 16)) {
+    const unsigned blocks = (unsigned)ceil_div(m * (n / 8), 256);
+    if (in_dtype == KRS_BF16) hipLaunchKernelGGL(gemm_smallk_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(gemm_smallk_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
+    KRS_CHECK_LAUNCH("gemm_smallk_kernel");
     return KRS_OK;
   }
   hipLaunchKernelGGL(gemm_generic_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p, in_dtype);

@@ -30,7 +30,10 @@ def _tol(dt, k):
 @pytest.mark.parametrize("m,n,k", [(1, 3, 3), (5, 7, 9), (128, 128, 64), (130, 200, 72), (256, 512, 512),
                                    (300, 136, 1000), (64, 3456, 512), (130, 200, 1088), (257, 512, 3456),
                                    (700, 300, 1024), (512, 768, 2048),  # the last three: 256x256-tile kernel
-                                   (13, 520, 4100), (264, 1, 4100), (16, 16, 9000)])  # tn: thin weight-gradient kernel
+                                   (13, 520, 4100), (264, 1, 4100), (16, 16, 9000),  # tn: thin weight-gradient kernel
+                                   (3, 700, 1030), (8, 300, 2048), (520, 5, 1500),      # ... its 4- / 8-wide builds
+                                   (2048, 1, 256), (1500, 3, 77), (1100, 8, 40),        # nn / nt: gemm_rowdot_kernel
+                                   (2048, 256, 1), (300, 512, 5), (5000, 16, 16)])      # nn / nt: gemm_smallk_kernel
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
 def test_gemm_layouts(m, n, k, dt, layout):
@@ -44,6 +47,27 @@ def test_gemm_layouts(m, n, k, dt, layout):
     c, _ = D.gemm(a_in, b_in, a_is_km=layout == "tn", b_is_nk=layout == "nt")
     exp, _ = ko.gemm(to_np(a), to_np(b), m, n, k)
     np.testing.assert_allclose(to_f32(to_np(c)), to_f32(exp), **_tol(dt, k))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [None, "relu", "sigmoid", "tanh"])
+def test_gemm_tiny_dimension_epilogues(dt, act):
+    # the last Dense of the DLRM top MLP (256 -> 1 unit): y = sigmoid(x k + b) on gemm_rowdot_kernel, and the data
+    # gradient dz k^T (K = 1) on gemm_smallk_kernel
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(3)
+    x = _t(rng.uniform(-1, 1, (3000, 256)), dt)
+    kt = _t(rng.uniform(-0.2, 0.2, (1, 256)), dt)          # [units, in]: given K-contiguous
+    bias = _t(rng.uniform(-0.5, 0.5, (1,)))
+    y, _ = D.gemm(x, kt, b_is_nk=True, bias=bias, act=D.ACTS[act])
+    ey, _ = ko.gemm(to_np(x), to_np(kt), 3000, 1, 256, b_is_nk=True, bias=to_np(bias), act=act)
+    np.testing.assert_allclose(to_f32(to_np(y)), to_f32(ey), **_tol(dt, 256))
+    dz = _t(rng.uniform(-1, 1, (3000, 1)), dt)
+    k = _t(rng.uniform(-0.2, 0.2, (256, 1)), dt)           # [in, units] = [N, K]
+    dx, _ = D.gemm(dz, k, b_is_nk=True)
+    edx, _ = ko.gemm(to_np(dz), to_np(k), 3000, 256, 1, b_is_nk=True)
+    np.testing.assert_allclose(to_f32(to_np(dx)), to_f32(edx), **_tol(dt, 1))
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
