@@ -1360,9 +1360,8 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
 // staged in LDS and broadcast, K is split over blockIdx.y into fp32 slabs (fixed-order reduce).
 constexpr int kThinMax = 16;
 // ES: operand element size (2 = bf16, 4 = fp32); NT: thin extent rounded up to 1 / 4 / 8 / 16 (the LDS rows are
-// read as float4).  Eight rows of the wide operand are requested before they are consumed; a split is 256 rows of K
-// (pick_splits), so the 13 x 512 and 256 x 1 gradients of the DLRM MLPs run as ~500 workgroups instead of 128 that
-// each walked 1024 rows one dependent load at a time (394 us -> see DESIGN.md).
+// read as float4).  Eight rows of the wide operand are requested before they are consumed (the first version
+// walked its 1024 rows one dependent load at a time behind a run-time dtype switch: 394 us for the 13 x 512 gradient).
 template <int ES, int NT>
 __global__ __launch_bounds__(256) void gemm_thin_kernel(const GemmParams p, int thin_is_a) {
   typedef typename std::conditional<ES == 2, uint16_t, float>::type elem_t;
@@ -1485,31 +1484,43 @@ __global__ __launch_bounds__(256) void gemm_rowdot_kernel(const GemmParams p) {
 }
 
 template <int ES>
-__global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmParams p, int rows_per_wg) {
   typedef typename std::conditional<ES == 2, uint16_t, float>::type elem_t;
-  const int64_t n8 = p.n / 8;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= p.m * n8) return;
-  const int64_t i = idx / n8, j0 = (idx - i * n8) * 8;
-  const elem_t* a = reinterpret_cast<const elem_t*>(p.a) + i * p.lda;
-  const elem_t* b = reinterpret_cast<const elem_t*>(p.b);
+  extern __shared__ __attribute__((aligned(16))) float bs[];   // B as fp32 [K][N]: a thread reads its 8 columns as 2 x float4
   auto f = [](elem_t v) -> float {
     if constexpr (ES == 2) return bf16_to_f32(v);
     else return v;
   };
-  float v[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-  for (int kk = 0; kk < (int)p.k; ++kk) {
-    const float av = f(a[kk]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaf(av, f(p.b_nk ? b[(j0 + j) * p.ldb + kk] : b[(int64_t)kk * p.ldb + j0 + j]), v[j]);
+  const elem_t* b = reinterpret_cast<const elem_t*>(p.b);
+  const int K = (int)p.k, N = (int)p.n;
+  for (int e = threadIdx.x; e < K * N; e += 256) {
+    const int kk = e / N, j = e - kk * N;
+    bs[e] = f(p.b_nk ? b[(int64_t)j * p.ldb + kk] : b[(int64_t)kk * p.ldb + j]);
   }
-  if (p.ep_vec) {
-    epilogue_store_vec8(p, i, j0, v);
-  } else {
+  __syncthreads();
+  const int n8 = N / 8;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t items = (int64_t)min<int64_t>(rows_per_wg, p.m - row0) * n8;
+  for (int64_t it = threadIdx.x; it < items; it += 256) {
+    const int64_t i = row0 + it / n8;
+    const int j0 = (int)(it % n8) * 8;
+    const elem_t* a = reinterpret_cast<const elem_t*>(p.a) + i * p.lda;
+    float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) epilogue_store(p, i, j0 + j, v[j]);
+    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    for (int kk = 0; kk < K; ++kk) {
+      const float av = f(a[kk]);
+      const float4 b0 = *reinterpret_cast<const float4*>(bs + kk * N + j0);
+      const float4 b1 = *reinterpret_cast<const float4*>(bs + kk * N + j0 + 4);
+      v[0] = fmaf(av, b0.x, v[0]); v[1] = fmaf(av, b0.y, v[1]); v[2] = fmaf(av, b0.z, v[2]); v[3] = fmaf(av, b0.w, v[3]);
+      v[4] = fmaf(av, b1.x, v[4]); v[5] = fmaf(av, b1.y, v[5]); v[6] = fmaf(av, b1.z, v[6]); v[7] = fmaf(av, b1.w, v[7]);
+    }
+    if (p.ep_vec) {
+      epilogue_store_vec8(p, i, j0, v);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) epilogue_store(p, i, j0 + j, v[j]);
+    }
   }
 }
 
@@ -1567,9 +1578,9 @@ int gemm_pipe() {
 // -- 2 x 14 tiles of the C3 weight gradients: 9 splits = 252 workgroups in ONE round (16 splits were 448
 // workgroups = 1.75 rounds, and 113 MB of slabs instead of 64).
 int pick_splits(int64_t m, int64_t n, int64_t k, int a_is_km) {
-  if (a_is_km && k >= 1024 && std::min(m, n) <= 16) {   // gemm_thin_kernel: 256 rows of K per split
-    const int64_t s = k / 256;
-    return (int)(s > 256 ? 256 : s);
+  if (a_is_km && k >= 1024 && std::min(m, n) <= 16) {   // gemm_thin_kernel: >= 512 rows of K per split, <= 128 splits
+    const int64_t s = k / 512;                            // (256 splits made the slab reduction the longer kernel,
+    return (int)(s > 128 ? 128 : s);                      //  64 left half of the CUs without a workgroup)
   }
   if (a_is_km && m >= 256 && n >= 256 && k % 64 == 0 && k >= 4096) {
     const int64_t t256 = ceil_div(m, 256) * ceil_div(n, 256);
@@ -2116,10 +2127,12 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
     KRS_CHECK_LAUNCH("gemm_rowdot_kernel");
     return KRS_OK;
   }
-  if (!p.a_km && p.splits == 1 && k <= 16 && n % 8 == 0 && m * n >= (1 << 16)) {
-    const unsigned blocks = (unsigned)ceil_div(m * (n / 8), 256);
-    if (in_dtype == KRS_BF16) hipLaunchKernelGGL(gemm_smallk_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(gemm_smallk_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
+  if (!p.a_km && p.splits == 1 && k <= 16 && n % 8 == 0 && n <= 1024 && m * n >= (1 << 16)) {
+    const int rows_per_wg = 64;
+    const unsigned blocks = (unsigned)ceil_div(m, rows_per_wg);
+    const size_t lds = (size_t)k * n * sizeof(float);   // <= 64 KB
+    if (in_dtype == KRS_BF16) hipLaunchKernelGGL(gemm_smallk_kernel<2>, dim3(blocks), dim3(256), lds, st, p, rows_per_wg);
+    else hipLaunchKernelGGL(gemm_smallk_kernel<4>, dim3(blocks), dim3(256), lds, st, p, rows_per_wg);
     KRS_CHECK_LAUNCH("gemm_smallk_kernel");
     return KRS_OK;
   }
