@@ -51,8 +51,8 @@ HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--tables", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--dim", type=int, default=128)
