@@ -10,6 +10,10 @@
 // the layer needs (forward, data gradient, weight gradient).  MFMA throughout:
 // v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, exact fmaf chain), fp32
 // accumulators in registers, a lane's operand = 16 bytes of LDS.  Kernels, by shape:
+//   * gemm_pp256_kernel     what the big bf16 shapes dispatch to (both operand layouts): the 256x256 tile on a
+//                           four-stage LDS-DMA ring, ping-pong wave groups, counted vmcnt, epilogue operands fetched
+//                           under the tail of the main loop; bit-identical to the two-stage kernels below, which stay
+//                           as pipeline 0 of krs_gemm_set_option;
 //   * gemm_glds256_kernel   both operands K-contiguous, K % 64 == 0, M, N >= 256: 256x256 tile,
 //                           8 waves, two 64 KB stages filled by LDS-DMA (global_load_lds), XOR
 //                           swizzle on the source side;
@@ -23,6 +27,7 @@
 //                           (K-strided operands transposed in registers), one 36 KB buffer,
 //                           three workgroups per CU;
 //   * gemm_thin_kernel      weight gradients with min(M, N) <= 16 (13 dense inputs, 1 unit);
+//   * gemm_rowdot_kernel / gemm_smallk_kernel   N <= 8 / K <= 16 with a row-major A (the 1-unit and 13-input Dense layers);
 //   * gemm_generic_kernel   anything else (the reference's toy shapes, d = 3).
 // Epilogue on the accumulator, staged through LDS so that a lane owns 8 consecutive columns:
 // + bias, activation, cross (x0*(v+diag*x)+x), + beta*R, one rounding to the output dtype; the
@@ -1661,8 +1666,8 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     const dim3 grid256((unsigned)(ceil_div(ceil_div(p.m, 256), 8) * 8 * ceil_div(p.n, 256)));
     if constexpr (ES == 2) {
       const int pipe = gemm_pipe();
-      // (the residual-add form with a short K -- dx = dh U^T + g, cache-resident operands -- measured 4 % faster
-      // on the two-stage loop: nothing to hide there, and the ring pays two barriers per 8 MFMA)
+      // (the residual-add form with a short K -- dx = dh U^T + g -- was 4 % faster on the two-stage loop until its R
+      // operands were fetched under the ring's tail: 340 -> 301 us)
       if (pipe && p.k % 32 == 0) {
         const int nt_ = (int)ceil_div(p.n, 256);
 #define KRS_PP_LAUNCH(NS, EP, SC)                                                                    \
