@@ -5,6 +5,8 @@ SURVEY.md section 8 rows a4 (embedding), a9 (FeatureCross) and a11 (DotInteracti
 
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from keras_rs_amd import _lib as L
@@ -88,7 +90,7 @@ class SlabGradRelay:
     (krs_dot_interaction_bwd_accumulate) and returns no gradient for them.  The leading inputs (the bottom-MLP
     output) keep their ordinary gradient tensors, so whatever else consumes them is unaffected.  Not used when
     the concat result is still referenced and retains its gradient or has hooks (its .grad would show the joined
-    value)."""
+    value), nor when one of the slab's feature views does (it would see no gradient from the interaction)."""
 
     __slots__ = ("buf", "task", "out_ref")
     joined = 0   # times the in-kernel path was taken (read by the tests)
@@ -239,6 +241,8 @@ class DotInteractionFn(torch.autograd.Function):
         ctx.save_for_backward(*feats)
         ctx.flags = (self_interaction, skip_gather)
         ctx.relay, ctx.n_heads = relay, n_heads
+        # the joined path hands the slab views no gradient of their own: not when somebody watches one of them
+        ctx.view_refs = [weakref.ref(t) for t in feats[n_heads:]] if relay is not None else []
         return D.dot_interaction_fwd(feats, self_interaction, skip_gather)
 
     @staticmethod
@@ -246,7 +250,8 @@ class DotInteractionFn(torch.autograd.Function):
         feats = ctx.saved_tensors
         si, sg = ctx.flags
         relay = ctx.relay
-        if relay is not None and relay.buf is not None:
+        watched = any((t := r()) is not None and (t.retains_grad or t._backward_hooks) for r in ctx.view_refs)
+        if relay is not None and relay.buf is not None and not watched:
             buf, task = relay.buf, torch._C._current_graph_task_id()
             n, (batch, dim) = len(feats), feats[0].shape
             if (relay.task == task and task != -1 and tuple(buf.shape) == (batch, n * dim) and buf.is_contiguous()

@@ -800,6 +800,8 @@ def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
             x0 = kl.concat_features(feats)
         if mode == "retain":
             x0.retain_grad()
+        if mode == "watch_view":
+            emb["b"].retain_grad()
         y = kl.FeatureCross(kernel_initializer=kl_base.GlorotUniform(seed=1), dtype=policy)(x0, x0)
         if mode == "dropped":     # a model's forward returns and the concat result is referenced by the graph only
             del x0, feats, emb
@@ -814,7 +816,7 @@ def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
     took_d, gd_d, tabs_d, _ = run("dropped")
     assert took_d == 1 and torch.equal(gd, gd_d) and all(torch.equal(tabs[k], tabs_d[k]) for k in tabs)
     tol = dict(rtol=2 ** -6, atol=2e-2) if dt == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
-    for mode in ("retain", "dot_last"):
+    for mode in ("retain", "dot_last", "watch_view"):
         took_m, gd_m, tabs_m, gx0 = run(mode)
         assert took_m == 0
         torch.testing.assert_close(gd, gd_m, **tol)
