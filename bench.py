@@ -46,6 +46,7 @@ ML_PERF_HOTS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100
 CRITEO_VOCABS = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282, 10, 2209, 11938,
                  155, 4, 976, 14, 40000000, 40000000, 40000000, 590152, 12973, 108, 36]
 HBM_PEAK = 8.0e12  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK = 2.5e15  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
 def parse():
@@ -78,6 +79,15 @@ def parse():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo stages through the host and lets "
                          "several ranks share one GPU: a functional rig, not a measurement)")
+    ap.add_argument("--exchange", choices=["static", "exact"], default="static",
+                    help="sharded runs: 'static' = fixed-capacity blocks, no host wait in the step (the reference's "
+                         "max_ids_per_partition contract); 'exact' = data-dependent sizes through one host wait")
+    ap.add_argument("--probe-steps", type=int, default=3,
+                    help="extra steps after each timed region with event spans around the C-ABI calls (K2 apply, GEMMs): "
+                         "the `roofline_step` entries; 0 = off")
+    ap.add_argument("--rccl-self", action="store_true",
+                    help="with --force-sharded at N = 1: route the layer's collectives through a ONE-rank RCCL communicator "
+                         "instead of device copies (proves the RCCL call path on a one-GPU box)")
     ap.add_argument("--full-model", action="store_true",
                     help="also time one training step of the whole DLRM-DCN-v2 model (examples/dlrm_dcn_v2.py: bottom "
                          "MLP, embeddings, 3 cross layers, top MLP, BCE), reported under `full_model`; never `value`")
@@ -95,22 +105,61 @@ def parse():
     return a
 
 
-def dist_setup(n, backend="nccl"):
-    if n <= 1:
-        return 0, 1, 0
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (RANK unset): start the N ranks ourselves,
+    one process per GPU, as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 with a
+    free port (the reference's entry point enumerates its devices itself too: examples/ml_perf/main.py:117-119).
+    Returns the launcher's exit code; rank 0's JSON line goes to this process's stdout unchanged."""
+    import subprocess
+
+    port = _free_port()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL peer buffers)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(n, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dist_setup(n, backend="nccl", single_rank_group=False):
+    """(rank, world, local device, backend actually used)."""
     import torch.distributed as dist
 
+    if n <= 1:
+        if single_rank_group:
+            # --force-sharded dry run: a ONE-rank RCCL communicator, so that the layer's collectives
+            # (all_to_all_single with split sizes, all_reduce) really go through RCCL on this GPU
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend, rank=0, world_size=1,
+                                    **({"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}))
+            return 0, 1, 0, backend
+        return 0, 1, 0, None
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     world = int(os.environ["WORLD_SIZE"])
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        # RCCL refuses two ranks on one GPU: fall back to the functional rig (ranks share the GPUs, collectives
+        # over gloo staged through the host) and say so in the line -- not a measurement of the links
+        backend = "gloo"
     if backend == "gloo":
-        local = local % torch.cuda.device_count()
+        local = local % n_dev
         torch.cuda.set_device(local)
         dist.init_process_group("gloo")
     else:
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local)     # bind LOCAL_RANK's device before any allocation
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    return rank, world, local
+    return rank, world, local, backend
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 class Model(torch.nn.Module):
@@ -138,7 +187,9 @@ class Model(torch.nn.Module):
         if world > 1 or a.force_sharded:
             from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
-            self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=a.dim)
+            self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=a.dim,
+                                                         exchange=a.exchange)
+            self.embedding._collectives_at_world1 = bool(a.rccl_self)
         else:
             # the dense feature's 128 columns are reserved in front of the 26 embeddings: the lookups land
             # directly in the [B, 3456] interaction input (concat-free layout)
@@ -306,22 +357,36 @@ def cpu_baseline(a, hots):
     torch_all = max(tried, key=lambda r: r["value"])
     torch_one = torch_leg(1, max(b // 4, 64), 1, 3)
     torch.set_num_threads(n_thr)
-    return {
-        "value": lookups / t_port, "unit": "lookups/s", "cores": n_thr, "kind": "port",
+    port = {
+        "value": lookups / t_port, "unit": "lookups/s", "threads": n_thr,
         "embed_fwd_lookups_per_s": lookups / t_emb,
         "ms_per_step_on_sample": t_port * 1e3,
-        "sample": f"batch {b} of the C3 workload ({a.tables} tables x {vocab} rows x {a.dim} bf16, sum L = "
-                  f"{sum(hots)}, {a.cross_layers} x FeatureCross(d={d}, p={p})): oracle/krs_oracle.c with OpenMP on "
-                  f"{n_thr} threads -- gather+pool (3 warm-ups + {n_emb} runs, median) + one cross layer forward+backward "
+        "sample": f"oracle/krs_oracle.c (the parity checker: plain loops, OpenMP on {n_thr} threads, not tuned) -- "
+                  f"gather+pool (3 warm-ups + {n_emb} runs, median) + one cross layer forward+backward "
                   f"on {bc} rows scaled to the sample (1 + {n_layer} runs, median) x {a.cross_layers}; no table update",
-        "torch_cpu": {"all_threads": torch_all, "one_thread": torch_one, "pool_sizes_tried": tried,
-                      "note": "fp32 embedding_bag (sparse gradients) + matmul / elementwise cross stack, autograd "
-                              "backward, no table update: the op composition Keras-on-CPU runs for this path"},
+    }
+    # `value` = the BEST host composition of the path (the number a reader compares with): the reference's op
+    # composition on torch's CPU kernels at the best intra-op pool size; the C oracle is reported beside it
+    return {
+        "value": torch_all["value"], "unit": "lookups/s", "cores": torch_all["threads"], "kind": "port",
+        "implementation": "the reference's composition (embedding_bag with sparse gradients -> matmul + bias + "
+                          "elementwise cross stack -> autograd backward) on torch's CPU kernels, fp32, no table update",
+        "ms_per_step_on_sample": torch_all["ms_per_step"],
+        "embed_fwd_lookups_per_s": torch_all["embed_fwd_lookups_per_s"],
+        "sample": f"batch {b} of the C3 workload ({a.tables} tables x {vocab} rows x {a.dim}, sum L = "
+                  f"{sum(hots)}, {a.cross_layers} x FeatureCross(d={d}, p={p})), 2 warm-ups + {torch_all['timed_runs']} "
+                  f"timed steps (median), intra-op pool sizes tried: {[r['threads'] for r in tried]} of {n_thr} hardware threads",
+        "host_threads": n_thr,
+        "torch_cpu": {"all_threads": torch_all, "one_thread": torch_one, "pool_sizes_tried": tried},
+        "oracle_port": port,
     }
 
 
-def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, loader=None):
-    """Times `steps` steps of the hot path for one bag-length list; returns (seconds, K1 seconds).
+def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, loader=None, probe_steps=0):
+    """Times `steps` steps of the hot path for one bag-length list.  Returns a dict: `elapsed` (wall seconds of the
+    timed region, max over ranks), `k1_s` (one K1 launch, events), `step_ms` (per-step GPU time of the timed steps,
+    from events recorded at the step boundaries) and, with `probe_steps`, `probe` (in-step kernel spans of that many
+    EXTRA steps run after the timed region; keras_rs_amd/probe.py).
     With `loader`, every step takes its preprocessed ids from it (host-resident inputs)."""
     ids, dense = make_inputs(a, hots, b_local, rank, dev)
     pre = model.embedding.preprocess(ids)
@@ -362,26 +427,15 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     # K1 launch duration, measured live with events on the launch stream, between the warm-up and the
     # timed steps (one krs_embed_bag_fwd launch per event pair).
     k1_s = None
-    if world > 1 or a.force_sharded:
+    sharded = world > 1 or a.force_sharded
+    if sharded:
         # sharded run: the embedding call contains the all-to-alls, so K1 is timed on its own in the form
         # the owner side runs it (row gather of this rank's share of the lookups from its shard)
         emb = model.embedding
         nloc = b_local * sum(hots)
         rows = torch.randint(0, emb.shard.shape[0], (nloc,), device=dev, dtype=torch.int32)
-        for _ in range(3):
-            emb.kernels.gather_rows(emb.shard.data, rows)
-        torch.cuda.synchronize()
-        for _ in range(4):
-            gpu_block(dev, 3.0)  # launches are enqueued behind a busy GPU: events bracket the kernel alone
-            for _ in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                emb.kernels.gather_rows(emb.shard.data, rows)
-                e1.record()
-                k1_ev.append((e0, e1))
-            torch.cuda.synchronize()
-        k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
-    if world == 1 and not a.force_sharded:
+        call = lambda: emb.kernels.gather_rows(emb.shard.data, rows)   # noqa: E731
+    else:
         # One K1 launch per event pair, through the thin op wrapper (krs_embed_bag_fwd on the layer's own
         # tables / descriptors, same slab shape as the layer call).  A blocker kernel is queued first, so
         # the event pairs and launches are all enqueued while the GPU is still busy: the interval between
@@ -391,28 +445,31 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         n = len(group.bags.features)
         lead = model.embedding.slab_lead_cols
         slab = torch.empty((b_local, lead + n * a.dim), dtype=torch.bfloat16, device=dev)
-        call = lambda: group.bags.forward(fi["ids"], b_local, hots=fi["hots"], offsets=fi["offsets"],
+        call = lambda: group.bags.forward(fi["ids"], b_local, hots=fi["hots"], offsets=fi["offsets"],   # noqa: E731
                                           out=slab[:, lead:])
-        for _ in range(3):
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    for _ in range(4):
+        gpu_block(dev, 3.0)  # launches are enqueued behind a busy GPU: events bracket the kernel alone
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             call()
+            e1.record()
+            k1_ev.append((e0, e1))
         torch.cuda.synchronize()
-        for _ in range(4):
-            gpu_block(dev, 3.0)
-            for _ in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                call()
-                e1.record()
-                k1_ev.append((e0, e1))
-            torch.cuda.synchronize()
-        k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
+    k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    marks[0].record()
+    for i in range(steps):
         step()
+        marks[i + 1].record()     # step boundaries on the launch stream: per-step GPU time, no host wait
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -422,7 +479,64 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, k1_s
+    res = {"elapsed": elapsed, "k1_s": k1_s,
+           "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
+    if probe_steps > 0:
+        from keras_rs_amd import probe
+
+        step()
+        probe.start()
+        for _ in range(probe_steps):
+            step()
+        res["probe"] = probe.stop()
+        res["probe_steps"] = probe_steps
+        if not sharded:
+            # unique touched rows (K2's algorithmic bytes need them): measurement bookkeeping, outside every timed region
+            res["unique_rows"] = int(sum(torch.unique(v.reshape(-1)).numel() for v in ids.values()))
+    ex = getattr(model.embedding, "last_exchange", None)
+    if ex:
+        res["exchange"] = dict(ex)
+    return res
+
+
+def step_stats(step_ms):
+    """Median / max of the per-step GPU times and how many steps stalled (> 1.5 x median)."""
+    med = float(np.median(step_ms))
+    return {"median_ms": med, "min_ms": float(np.min(step_ms)), "max_ms": float(np.max(step_ms)),
+            "steps_over_1.5x_median": int(sum(t > 1.5 * med for t in step_ms)),
+            "source": "HIP events at the step boundaries of the timed steps (GPU time; `ms_per_step` is wall clock / steps)"}
+
+
+def roofline_step(a, hots, b_local, res):
+    """In-step roofline entries from the probe spans (events around the C-ABI calls inside real steps, GPU backlogged):
+    K2 apply against HBM (SURVEY.md section 8d bytes with U = distinct touched rows of this batch), the FeatureCross
+    GEMMs in aggregate against the dense bf16 MFMA peak, K1 and the K2 plan as they run inside the step."""
+    pr, n = res.get("probe"), res.get("probe_steps", 0)
+    if not pr or not n:
+        return None
+    out = []
+    nnz, bags, d = b_local * sum(hots), b_local * a.tables, a.dim
+    if "k2_apply" in pr and "unique_rows" in res:
+        u = res["unique_rows"]
+        # bags*D*s_g (gradient) + nnz*12 (sorted key + (bag, position)) + U*(2*D*s_t + 2*D*4 Adagrad accumulator)
+        slot = 8 if a.rowwise_adagrad else 2 * d * 4
+        alg = bags * d * 2 + nnz * 12 + u * (2 * d * 2 + slot)
+        sec = pr["k2_apply"]["ms_total"] / n * 1e-3
+        out.append({"kernel": "bag_apply_kernel<adagrad> (K2 apply, krs_embed_bag_bwd_fused_adagrad)", "bound": "hbm",
+                    "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK,
+                    "launch_us": sec * 1e6, "algorithmic_bytes": alg, "unique_rows": u, "traffic": None})
+    if "gemm" in pr:
+        fl = pr["gemm"]["work_total"] / n
+        sec = pr["gemm"]["ms_total"] / n * 1e-3
+        out.append({"kernel": "krs_gemm x %d per step (FeatureCross h / cross / dK / dh / dU / dx products, aggregate)"
+                              % (pr["gemm"]["calls"] // n), "bound": "mfma", "achieved": fl / sec / 1e12,
+                    "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / sec / MFMA_BF16_PEAK,
+                    "ms_per_step": sec * 1e3, "flops_per_step": fl, "traffic": None})
+    for key, label in (("k1", "K1 inside the step (beside the K2 plan on the side stream)"),
+                       ("k2_plan", "K2 plan (radix sort + segment list; side stream)")):
+        if key in pr:
+            out.append({"kernel": label, "ms_per_step": pr[key]["ms_total"] / n, "calls_per_step": pr[key]["calls"] // n})
+    return out
 
 
 def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False):
@@ -455,7 +569,9 @@ def pmc_traffic(kernel):
 
 def main():
     a = parse()
-    rank, world, local = dist_setup(a.gpus, a.dist_backend)
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(a.gpus))
+    rank, world, local, backend = dist_setup(a.gpus, a.dist_backend, single_rank_group=a.force_sharded and a.rccl_self)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     b_local = a.batch // world
@@ -474,10 +590,14 @@ def main():
     model = Model(a, primary, world, rank)
     model.embedding.build(None)
     opt_box = [None]
-    elapsed, k1_s = measure(model, a, primary, world, rank, dev, b_local, a.steps, a.warmup, opt_box)
-    # the other C3 bag-length list (SURVEY.md section 8d lists both), same tables and model, shorter run
+    r1 = measure(model, a, primary, world, rank, dev, b_local, a.steps, a.warmup, opt_box, probe_steps=a.probe_steps)
+    # the other C3 bag-length list (SURVEY.md section 8d lists both), same tables and model, shorter run.  The
+    # shapes change (ids, plan workspace), so the leg gets its own warm-up of at least 5 steps: the caching
+    # allocator re-carves its blocks during the first steps after a shape change
     sec_steps = max(3, a.steps // 2)
-    elapsed2, k1_s2 = measure(model, a, secondary, world, rank, dev, b_local, sec_steps, 2, opt_box)
+    r2 = measure(model, a, secondary, world, rank, dev, b_local, sec_steps, max(5, a.warmup), opt_box,
+                 probe_steps=a.probe_steps)
+    elapsed, k1_s, elapsed2, k1_s2 = r1["elapsed"], r1["k1_s"], r2["elapsed"], r2["k1_s"]
     host = None
     if a.host_inputs > 0 and world == 1 and not a.force_sharded:
         # ids start in host memory: a small pool of batches cycles through the loader threads, which
@@ -493,7 +613,7 @@ def main():
                 yield from pool
 
         loader = ThreadedDataLoader(model.embedding.preprocess, cycle(), num_workers=a.host_inputs, buffer_size=4)
-        el_h, _ = measure(model, a, primary, world, rank, dev, b_local, a.steps, a.warmup, opt_box, loader=loader)
+        el_h = measure(model, a, primary, world, rank, dev, b_local, a.steps, a.warmup, opt_box, loader=loader)["elapsed"]
         loader.stop()
         id_bytes = 4 * b_local * sum(primary)
         host = {"ms_per_step": el_h / a.steps * 1e3, "value": a.batch * sum(primary) / (el_h / a.steps),
@@ -522,7 +642,7 @@ def main():
         full = {"ms_per_step": dt * 1e3, "value": a.batch * sum(primary) / dt, "unit": "lookups/s",
                 "model": "bottom MLP 13-512-256-128 (relu), 26 embeddings, 3 x FeatureCross(3456, 512), top MLP "
                          "3456-1024-1024-512-256-1 (relu / sigmoid), BCE, Adagrad everywhere"}
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
@@ -542,6 +662,13 @@ def main():
     else:
         shape_name, rows_desc = "C3 DLRM-small", "%d" % a.vocab
     ids_desc = "power-law ids (id = perm(floor(V u^%g)))" % a.id_skew if a.id_skew > 0 else "uniform ids"
+    sharded = world > 1 or a.force_sharded
+    if world > 1 and backend == "gloo":
+        backend_desc = ("gloo, staged through the host" + (
+            ": %d ranks share %d GPU(s), a functional rig, NOT a measurement of the links"
+            % (world, torch.cuda.device_count()) if world > torch.cuda.device_count() else ""))
+    else:
+        backend_desc = {"nccl": "nccl (RCCL)", None: None}.get(backend, backend)
     out = {
         "metric": "embedding lookups/sec + DCN fwd+bwd step time, 26-table DLRM batch 65 536",
         "value": lookups / (elapsed / a.steps),
@@ -553,6 +680,7 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
+        "ranks": world, "backend": backend_desc,
         "config": {
             "workload": ("%s: %d tables x %s rows x %d (bf16), global batch %d, %s, %s, "
                          "DotInteraction(F=%d) + %d x FeatureCross(d=%d, projection=%d), fused %s on tables"
@@ -562,21 +690,32 @@ def main():
                             else "Adagrad")),
             "global_batch": a.batch,
             "parallelism": ("single GPU" if world == 1 and not a.force_sharded else
-                            "sharded code path on ONE GPU (dry run: device copies stand in for the links)" if world == 1
+                            "sharded code path on ONE GPU (dry run: %s)" % (
+                                "collectives through a one-rank RCCL communicator" if backend else
+                                "device copies stand in for the links") if world == 1
                             else f"tables MOD row-sharded over {world} GPUs, dense part DP"),
         },
+        "step_stats": step_stats(r1["step_ms"]),
     }
+    if sharded and "exchange" in r1:
+        ex = r1["exchange"]
+        out["a2a_bytes_per_step"] = ex.get("bytes_per_step")
+        out["exchange"] = {k: v for k, v in ex.items() if k in ("mode", "bytes", "capacity", "overflowed")}
     second = {"workload": "same tables / model, " + describe(secondary),
               "value": a.batch * sum(secondary) / (elapsed2 / sec_steps), "unit": "lookups/s",
-              "ms_per_step": elapsed2 / sec_steps * 1e3, "steps": sec_steps}
+              "ms_per_step": elapsed2 / sec_steps * 1e3, "steps": sec_steps, "warmup": max(5, a.warmup),
+              "step_stats": step_stats(r2["step_ms"])}
     if k1_s is not None:
-        sharded = world > 1 or a.force_sharded
         n1 = "embed_gather_hot1 (K1 owner-side row gather of the sharded path, rank 0)" if sharded else k1_name(primary)
         n2 = n1 if sharded else k1_name(secondary)
         out["embed_fwd_lookups_per_s"] = world * b_local * sum(primary) / k1_s
         out["roofline"] = k1_roofline(a, primary, b_local, k1_s, n1, sharded)
         second["embed_fwd_lookups_per_s"] = world * b_local * sum(secondary) / k1_s2
         second["roofline"] = k1_roofline(a, secondary, b_local, k1_s2, n2, sharded)
+    for res, tgt, hots in ((r1, out, primary), (r2, second, secondary)):
+        rs = roofline_step(a, hots, b_local, res)
+        if rs:
+            tgt["roofline_step"] = rs
     out["also"] = second
     if host is not None:
         out["host_inputs"] = host

@@ -61,6 +61,7 @@ typedef enum krs_activation {
  * is raised (SURVEY.md section 8c decision on keras ops.take out-of-range). */
 #define KRS_FLAG_ID_OUT_OF_RANGE 1
 #define KRS_FLAG_BAD_OFFSETS 2
+#define KRS_FLAG_CAPACITY_OVERFLOW 4   /* krs_shard_route_static: lookups beyond the static capacity were dropped */
 
 /* One embedding table ([vocab, dim] row-major).  Lives in DEVICE memory as an
  * array indexed by krs_feature.table.  Replaces the `embeddings` variable of
@@ -422,6 +423,28 @@ int krs_mod_bucketize(const void* ids, int id_type, int64_t nnz, int n_shards,
  *
  * krs_publish_i64: copies src[0..n) to page-locked host memory (host_dst, device-visible) and then
  * writes `seq` to host_dst[n]; the host polls host_dst[n] instead of synchronising the stream.
+ *
+ * STATIC-CAPACITY form (krs_shard_route_static / krs_shard_unpack_static).  The reference makes every
+ * buffer of the SparseCore exchange static with TableConfig.max_ids_per_partition /
+ * max_unique_ids_per_partition (distributed_embedding_config.py:54-61), drops what does not fit
+ * (allow_id_dropping=True, jax/embedding_utils.py:187-197) and learns better limits from running statistics
+ * (update_stats, jax/distributed_embedding.py:657-664).  Same contract here: every (home, owner) pair
+ * exchanges a block of fixed size, so the all-to-alls have equal splits and the host needs no count:
+ *   block = [lookups kept, segments kept, need_l, need_s | rows[cap_lookups] |
+ *            weights[cap_lookups] (only with emit_weights) | segment lengths[cap_segments]]   (int32 words;
+ *            krs_shard_static_block_words() of them; unused slots are 0)
+ * krs_shard_route_static writes n_shards such blocks into `packed`: owner d keeps the first cap_segments
+ * segments of its bucket and of those the first cap_lookups lookups (a segment cut by the limit keeps its
+ * head); anything dropped raises KRS_FLAG_CAPACITY_OVERFLOW in err_flag.  need_l / need_s = the largest
+ * per-owner lookup / segment count of THIS call, repeated in every header (each rank learns every rank's
+ * needs from the blocks it receives).  seg_grow is [n_shards*cap_segments] (gradient row of every segment
+ * SLOT d*cap_segments + j; 0 for unused slots), bag_seg holds slots (-1 for no / dropped segment),
+ * counts as in the exact form (before dropping).  Capacities must be multiples of 4.  When nothing
+ * overflows, the kept lookups, their order and the segments are those of krs_shard_route.
+ * krs_shard_unpack_static (owner): n_sources received blocks -> rows / w [n_sources*cap_lookups] (compact,
+ * source order; the unused tail is row -1 / weight 0: outside every segment, and an invalid id for the
+ * backward plan), offsets[n_sources*cap_segments + 1] (CSR over the segment SLOTS; unused slots are empty),
+ * stats[4] (optional) = max need_l, max need_s over the sources, lookups, segments received.
  * ------------------------------------------------------------------------- */
 typedef struct krs_shard_feature {
   int64_t ids_base;   /* dense bags: position of the feature's first id in `ids` */
@@ -445,6 +468,17 @@ int krs_shard_unpack(const int32_t* packed, int n_sources, const int64_t* lookup
                      void* workspace, size_t workspace_bytes, void* stream);
 int krs_shard_combine(const void* partials, const int32_t* bag_seg, int batch, int n_feats, int n_shards,
                       int dim, int dtype, void* out, int64_t out_ld, void* stream);
+int64_t krs_shard_static_block_words(int64_t cap_lookups, int64_t cap_segments, int emit_weights);
+int krs_shard_route_static(const krs_shard_feature* feats, const krs_shard_feature* feats_host, int n_feats,
+                           const void* ids, int id_type, const void* offsets, int offset_type,
+                           const float* weights, int64_t nnz, int batch, int n_shards, int emit_weights,
+                           int64_t cap_lookups, int64_t cap_segments,
+                           int32_t* packed, int32_t* seg_bag, int32_t* seg_grow, int32_t* bag_seg,
+                           int64_t* counts, int32_t* err_flag,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int krs_shard_unpack_static(const int32_t* packed, int n_sources, int64_t cap_lookups, int64_t cap_segments,
+                            int weighted, int32_t* rows, float* w, int32_t* offsets, int64_t* stats,
+                            void* workspace, size_t workspace_bytes, void* stream);
 int krs_publish_i64(const int64_t* src, int n, int64_t* host_dst, int64_t seq, void* stream);
 
 #ifdef __cplusplus

@@ -23,6 +23,7 @@ COMBINERS = {"sum": SUM, "mean": MEAN, "sqrtn": SQRTN}
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 FLAG_ID_OUT_OF_RANGE = 1
 FLAG_BAD_OFFSETS = 2
+FLAG_CAPACITY_OVERFLOW = 4
 
 # struct layouts of include/krs.h
 TABLE_DT = np.dtype(
@@ -87,6 +88,9 @@ SYMBOLS = [
     "krs_shard_unpack_workspace_bytes",
     "krs_shard_unpack",
     "krs_shard_combine",
+    "krs_shard_static_block_words",
+    "krs_shard_route_static",
+    "krs_shard_unpack_static",
     "krs_publish_i64",
 ]
 
@@ -112,6 +116,7 @@ def lib() -> C.CDLL:
                      "krs_mod_bucketize_workspace_bytes", "krs_shard_route_workspace_bytes",
                      "krs_shard_unpack_workspace_bytes"):
             getattr(_lib, name).restype = C.c_size_t
+        _lib.krs_shard_static_block_words.restype = C.c_int64
     return _lib
 
 

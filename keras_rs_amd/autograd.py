@@ -329,6 +329,12 @@ class EmbedBagFusedFn(torch.autograd.Function):
         if ctx.needs_input_grad[8]:  # a backward will follow (not under torch.no_grad())
             main = torch.cuda.current_stream()
             side = _side_stream(ids.device)
+            # The descriptor blocks are uploaded (and cached) by whoever asks first: do that HERE, on the main
+            # stream, so that the copy is ordered before both users -- the plan (side waits for main below) and
+            # the gather (main).  Uploaded on the side stream by a cold cache, the gather on main would have read
+            # them with nothing ordering it behind the copy (first step, first-seen batch size, after .to()).
+            bags.table_desc()
+            bags.feature_desc(batch, hots, ids.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 ws = bags.plan_backward(ids, batch, hots=hots, offsets=offsets)

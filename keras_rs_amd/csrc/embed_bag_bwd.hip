@@ -667,7 +667,7 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
     const int64_t row = (int64_t)key - tb.row_base;
     const float a_new = tb.slot[row] + ss / (float)p.dim;
     if (col_live) {
-      const float inv = tb.lr / sqrtf(a_new);
+      const float inv = a_new > 0.0f ? tb.lr / sqrtf(a_new) : 0.0f;  // untouched accumulator + zero gradient: leave the row
 #pragma unroll
       for (int k = 0; k < N; ++k) wv[k] = wv[k] - inv * acc[k];
       store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
@@ -719,7 +719,7 @@ __device__ __forceinline__ void finish_row(const ApplyParams& p, uint32_t u, uin
       const bool t_al = (reinterpret_cast<uintptr_t>(tb.weights) & 15) == 0;
       float wv[N];
       load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
-      const float inv = tb.lr / sqrtf(a_new);
+      const float inv = a_new > 0.0f ? tb.lr / sqrtf(a_new) : 0.0f;  // untouched accumulator + zero gradient: leave the row
 #pragma unroll
       for (int k = 0; k < N; ++k) wv[k] = wv[k] - inv * tot[k];
       store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, in
     }
     for (int o = lpr / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float a_new = tb.slot[row] + ss / (float)p.dim;
-    const float inv = tb.lr / sqrtf(a_new);
+    const float inv = a_new > 0.0f ? tb.lr / sqrtf(a_new) : 0.0f;  // untouched accumulator + zero gradient: leave the row
     for (int c = sub; c < p.dim; c += lpr) {
       const int64_t off = row * p.dim + c;
       st_elem(tb.weights, table_dtype, off, ld_elem(tb.weights, table_dtype, off) - inv * column_grad(c));
@@ -1188,6 +1188,9 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
     kp.keys = to_sorted ? l.keys_in : l.keys_sorted;
     kp.vals = to_sorted ? l.vals_in : l.vals_sorted;
     const int64_t n_bags = (int64_t)n_feats * batch;
+    // lookup positions outside every bag (offsets[n_bags] < nnz: the padded tail of a static-capacity exchange)
+    // must not carry stale keys: all ones = the invalid key, which sorts behind every row and is skipped
+    KRS_HIP(hipMemsetAsync(kp.keys, 0xff, (size_t)nnz * sizeof(uint32_t), st));
     hipLaunchKernelGGL(bag_keys_kernel, dim3((unsigned)ceil_div(n_bags, 16)), dim3(256), 0, st, kp);
     KRS_CHECK_LAUNCH("bag_keys_kernel");
   }

@@ -46,10 +46,13 @@ struct RouteWs {
   int32_t* blk_heads;    // [n_blocks] segment heads per block, then exclusive offsets
   int32_t* seg_first;    // [nnz + 1]  first bucket-order position of every segment
   int32_t* scan_sums;    // workspace of the histogram scan
-  int64_t* meta;         // [64]: start[0..N] (N+1 entries: bucket starts, start[N] = valid lookups), 17: n_seg,
-                         //       18..18+N: seg_start[d], 36..36+N: packed base of owner d
+  int64_t* meta;         // [128]: start[0..N] (N+1 entries: bucket starts, start[N] = valid lookups), 17: n_seg,
+                         //       18..18+N: seg_start[d], 36..36+N: packed base of owner d; static-capacity form:
+                         //       64..64+N: lookups kept for owner d, 81..81+N: segments kept for owner d
 };
-constexpr int kMetaNseg = 17, kMetaSegStart = 18, kMetaPackBase = 36;
+constexpr int kMetaNseg = 17, kMetaSegStart = 18, kMetaPackBase = 36, kMetaKeepCnt = 64, kMetaKeepSeg = 81;
+constexpr int kMetaWords = 128;
+constexpr int kStaticHeader = 4;     // words in front of every static block: lookups, segments, need_l, need_s
 
 struct RouteParams {
   const krs_shard_feature* feats;
@@ -73,6 +76,9 @@ struct RouteParams {
   int32_t* bag_seg;
   int64_t* counts;
   int32_t* err_flag;
+  // static-capacity form (krs_shard_route_static): every owner's block has cap_l lookup and cap_s segment slots
+  int64_t cap_l, cap_s;     // 0 = exact form
+  int64_t block_words;      // kStaticHeader + cap_l * (1 + emit_w) + cap_s
 };
 
 __device__ __forceinline__ int64_t bag_lo(const RouteParams& p, const krs_shard_feature& f, int64_t bag, int b) {
@@ -266,8 +272,10 @@ __global__ __launch_bounds__(256) void route_segments_kernel(const RouteParams p
     while (d + 1 < p.n_shards && q >= start[d + 1]) ++d;
     p.ws.seg_first[s] = (int32_t)q;
     p.seg_bag[s] = bag;
-    p.seg_grow[s] = (bag % p.batch) * n_feats + bag / p.batch;
-    p.bag_seg[(int64_t)bag * p.n_shards + d] = s;
+    if (p.cap_l == 0) {     // (the static form numbers the segments by their slot: route_pack_static_kernel)
+      p.seg_grow[s] = (bag % p.batch) * n_feats + bag / p.batch;
+      p.bag_seg[(int64_t)bag * p.n_shards + d] = s;
+    }
     if (q == start[d]) p.ws.meta[kMetaSegStart + d] = s;
     ++s;
   }
@@ -298,6 +306,76 @@ __global__ void route_finalize_kernel(const RouteParams p) {
     base += words;
   }
   p.ws.seg_first[n_seg] = (int32_t)n_valid;
+  if (p.cap_l > 0) {
+    // Static-capacity form: owner d's block sits at d * block_words and holds the FIRST cap_s segments of its
+    // bucket and of those the first cap_l lookups; what does not fit is dropped and flagged (the reference's
+    // allow_id_dropping=True, jax/embedding_utils.py:187-197).  need_l / need_s = the capacities this call would
+    // have needed; they travel in every block header so that all ranks see the same maxima (update_stats).
+    int64_t need_l = 0, need_s = 0;
+    bool over = false;
+    for (int d = 0; d < n; ++d) {
+      const int64_t cnt = p.counts[d], segs = p.counts[n + d];
+      need_l = cnt > need_l ? cnt : need_l;
+      need_s = segs > need_s ? segs : need_s;
+      int64_t keep_s = segs < p.cap_s ? segs : p.cap_s;
+      int64_t keep_l = cnt;
+      if (keep_s < segs) keep_l = (int64_t)p.ws.seg_first[p.ws.meta[kMetaSegStart + d] + keep_s] - p.ws.meta[d];
+      if (keep_l > p.cap_l) keep_l = p.cap_l;
+      over = over || keep_l < cnt || keep_s < segs;
+      p.ws.meta[kMetaKeepCnt + d] = keep_l;
+      p.ws.meta[kMetaKeepSeg + d] = keep_s;
+    }
+    for (int d = 0; d < n; ++d) {
+      int32_t* h = p.packed + d * p.block_words;
+      h[0] = (int32_t)p.ws.meta[kMetaKeepCnt + d];
+      h[1] = (int32_t)p.ws.meta[kMetaKeepSeg + d];
+      h[2] = (int32_t)need_l;
+      h[3] = (int32_t)need_s;
+    }
+    if (over && p.err_flag) atomicOr(p.err_flag, KRS_FLAG_CAPACITY_OVERFLOW);
+  }
+}
+
+// static-capacity form of the send buffer: per owner a block of block_words words
+//   [lookups kept, segments kept, need_l, need_s | rows[cap_l] | weights[cap_l] (if emitted) | segment lengths[cap_s]]
+// (the buffer was zeroed), the gradient row of every segment SLOT (0 for empty slots) and (bag, owner) -> slot.
+__global__ __launch_bounds__(256) void route_pack_static_kernel(const RouteParams p) {
+  __shared__ int64_t start[kMaxShards + 1], sstart[kMaxShards + 1], keep_l[kMaxShards], keep_s[kMaxShards];
+  if ((int)threadIdx.x <= p.n_shards) {
+    start[threadIdx.x] = p.ws.meta[threadIdx.x];
+    sstart[threadIdx.x] = p.ws.meta[kMetaSegStart + threadIdx.x];
+  }
+  if ((int)threadIdx.x < p.n_shards) {
+    keep_l[threadIdx.x] = p.ws.meta[kMetaKeepCnt + threadIdx.x];
+    keep_s[threadIdx.x] = p.ws.meta[kMetaKeepSeg + threadIdx.x];
+  }
+  __syncthreads();
+  const int64_t n_valid = start[p.n_shards], n_seg = sstart[p.n_shards];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_valid) {
+    int d = 0;
+    while (d + 1 < p.n_shards && i >= start[d + 1]) ++d;
+    const int64_t k = i - start[d];
+    if (k < keep_l[d]) {
+      int32_t* blk = p.packed + d * p.block_words + kStaticHeader;
+      blk[k] = p.ws.rows_b[i];
+      if (p.emit_w) blk[p.cap_l + k] = __float_as_int(p.ws.w_b[i]);
+    }
+  }
+  if (i < n_seg) {
+    int d = 0;
+    while (d + 1 < p.n_shards && i >= sstart[d + 1]) ++d;
+    const int64_t j = i - sstart[d];
+    const int bag = p.seg_bag[i];
+    if (j < keep_s[d]) {
+      const int64_t end_kept = start[d] + keep_l[d];
+      int64_t hi = p.ws.seg_first[i + 1], lo = p.ws.seg_first[i];
+      hi = hi < end_kept ? hi : end_kept;
+      p.packed[d * p.block_words + kStaticHeader + p.cap_l * (1 + p.emit_w) + j] = (int32_t)(hi > lo ? hi - lo : 0);
+      p.seg_grow[d * p.cap_s + j] = (bag % p.batch) * p.n_feats + bag / p.batch;
+      p.bag_seg[(int64_t)bag * p.n_shards + d] = (int32_t)(d * p.cap_s + j);
+    }
+  }
 }
 
 // the send buffer: per owner [rows | weights (bit patterns) | segment lengths]
@@ -358,6 +436,62 @@ __global__ __launch_bounds__(256) void unpack_kernel(const UnpackParams p) {
     p.offsets[i] = p.packed[p.pack_base[s] + cnt * (1 + p.weighted) + (i - p.seg_start[s])];   // lengths, scanned next
   }
   if (i == n_seg) p.offsets[n_seg] = 0;
+}
+
+// static-capacity form: the received blocks (one per source, block_words apart, header in front) -> compact rows /
+// weights (source order; the tail up to n_src * cap_l is padded with row -1, weight 0: no segment refers to it and K2's
+// plan sorts it behind every valid row), segment LENGTHS at the segment's slot s * cap_s + j (0 for empty slots;
+// scanned to CSR offsets next), stats = [max need_l, max need_s, lookups, segments] over the sources.
+struct UnpackStaticParams {
+  const int32_t* packed;
+  int n_src;
+  int weighted;
+  int64_t cap_l, cap_s, block_words;
+  int32_t* rows;
+  float* w;
+  int32_t* offsets;      // [n_src * cap_s + 1]
+  int64_t* stats;        // [4] or null
+};
+
+__global__ __launch_bounds__(256) void unpack_static_kernel(const UnpackStaticParams p) {
+  __shared__ int64_t cnt[kMaxShards], segs[kMaxShards], pre[kMaxShards + 1];
+  if (threadIdx.x == 0) {
+    int64_t run = 0, nl = 0, ns = 0, tot_s = 0;
+    for (int s = 0; s < p.n_src; ++s) {
+      const int32_t* h = p.packed + s * p.block_words;
+      int64_t c = h[0], g = h[1];
+      c = c < 0 ? 0 : (c > p.cap_l ? p.cap_l : c);
+      g = g < 0 ? 0 : (g > p.cap_s ? p.cap_s : g);
+      cnt[s] = c; segs[s] = g; pre[s] = run;
+      run += c; tot_s += g;
+      nl = h[2] > nl ? h[2] : nl;
+      ns = h[3] > ns ? h[3] : ns;
+    }
+    pre[p.n_src] = run;
+    if (blockIdx.x == 0 && p.stats) { p.stats[0] = nl; p.stats[1] = ns; p.stats[2] = run; p.stats[3] = tot_s; }
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t slots_l = (int64_t)p.n_src * p.cap_l, slots_s = (int64_t)p.n_src * p.cap_s;
+  if (i < slots_l) {
+    const int s = (int)(i / p.cap_l);
+    const int64_t k = i - (int64_t)s * p.cap_l;
+    if (k < cnt[s]) {
+      const int32_t* blk = p.packed + s * p.block_words + kStaticHeader;
+      p.rows[pre[s] + k] = blk[k];
+      if (p.weighted) p.w[pre[s] + k] = __int_as_float(blk[p.cap_l + k]);
+    }
+    if (i >= pre[p.n_src]) {
+      p.rows[i] = -1;
+      if (p.weighted) p.w[i] = 0.0f;
+    }
+  }
+  if (i < slots_s) {
+    const int s = (int)(i / p.cap_s);
+    const int64_t j = i - (int64_t)s * p.cap_s;
+    p.offsets[i] = j < segs[s] ? p.packed[s * p.block_words + kStaticHeader + p.cap_l * (1 + p.weighted) + j] : 0;
+  }
+  if (i == slots_s) p.offsets[slots_s] = 0;
 }
 
 // ---- home side -------------------------------------------------------------------------------------
@@ -433,7 +567,7 @@ RouteWs carve(void* workspace, int64_t nnz, int64_t n_bags, int n_shards, int n_
     return q;
   };
   RouteWs w;
-  w.meta = reinterpret_cast<int64_t*>(take(64 * sizeof(int64_t)));
+  w.meta = reinterpret_cast<int64_t*>(take(kMetaWords * sizeof(int64_t)));
   w.bag_of_pos = reinterpret_cast<int32_t*>(take((size_t)nnz * 4));
   w.scale = reinterpret_cast<float*>(take((size_t)n_bags * 4));
   w.dest = reinterpret_cast<uint8_t*>(take((size_t)nnz));
@@ -462,12 +596,13 @@ extern "C" size_t krs_shard_route_workspace_bytes(int64_t nnz, int64_t n_bags, i
   return bytes;
 }
 
-extern "C" int krs_shard_route(const krs_shard_feature* feats, const krs_shard_feature* feats_host, int n_feats,
-                               const void* ids, int id_type, const void* offsets, int offset_type,
-                               const float* weights, int64_t nnz, int batch, int n_shards, int emit_weights,
-                               int32_t* packed, int32_t* seg_bag, int32_t* seg_grow, int32_t* bag_seg,
-                               int64_t* counts, int32_t* err_flag, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+static int shard_route_impl(const krs_shard_feature* feats, const krs_shard_feature* feats_host, int n_feats,
+                            const void* ids, int id_type, const void* offsets, int offset_type,
+                            const float* weights, int64_t nnz, int batch, int n_shards, int emit_weights,
+                            int64_t cap_l, int64_t cap_s,
+                            int32_t* packed, int32_t* seg_bag, int32_t* seg_grow, int32_t* bag_seg,
+                            int64_t* counts, int32_t* err_flag, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   KRS_REQUIRE(n_shards >= 1 && n_shards <= kMaxShards, "shard_route: n_shards must be in [1, %d]", kMaxShards);
   KRS_REQUIRE(n_feats >= 1 && n_feats <= kMaxFeats, "shard_route: n_feats must be in [1, %d]", kMaxFeats);
   KRS_REQUIRE(nnz >= 0 && nnz < 0x7fffffffLL && batch >= 0, "shard_route: nnz must fit int32");
@@ -477,6 +612,15 @@ extern "C" int krs_shard_route(const krs_shard_feature* feats, const krs_shard_f
   const int64_t n_bags = (int64_t)batch * n_feats;
   KRS_REQUIRE(n_bags * n_shards < 0x7fffffffLL, "shard_route: batch * n_feats * n_shards must fit int32");
   KRS_HIP(hipMemsetAsync(bag_seg, 0xff, (size_t)(n_bags > 0 ? n_bags : 1) * n_shards * sizeof(int32_t), st));
+  const int64_t block_words = kStaticHeader + cap_l * (1 + (emit_weights != 0)) + cap_s;
+  if (cap_l > 0) {
+    KRS_REQUIRE(cap_l % 4 == 0 && cap_s % 4 == 0 && cap_s > 0, "shard_route_static: capacities must be multiples of 4");
+    KRS_REQUIRE(block_words * n_shards < 0x7fffffffLL && cap_s * n_shards < 0x7fffffffLL,
+                "shard_route_static: the packed buffer must fit int32 indexing");
+    KRS_REQUIRE(packed && seg_grow, "shard_route_static: null argument");
+    KRS_HIP(hipMemsetAsync(packed, 0, (size_t)block_words * n_shards * sizeof(int32_t), st));
+    KRS_HIP(hipMemsetAsync(seg_grow, 0, (size_t)cap_s * n_shards * sizeof(int32_t), st));
+  }
   if (nnz == 0) {
     KRS_HIP(hipMemsetAsync(counts, 0, (size_t)3 * n_shards * sizeof(int64_t), st));
     return KRS_OK;
@@ -499,6 +643,7 @@ extern "C" int krs_shard_route(const krs_shard_feature* feats, const krs_shard_f
   if (workspace_bytes < need) return fail(KRS_ERR_WORKSPACE, "shard_route: workspace too small (%zu < %zu)", workspace_bytes, need);
   p.packed = packed; p.seg_bag = seg_bag; p.seg_grow = seg_grow; p.bag_seg = bag_seg; p.counts = counts;
   p.err_flag = err_flag;
+  p.cap_l = cap_l; p.cap_s = cap_s; p.block_words = block_words;
   const unsigned bag_blocks = (unsigned)ceil_div(n_bags, 256);
   if (offsets) hipLaunchKernelGGL(route_expand_kernel, dim3(bag_blocks), dim3(256), 0, st, p);
   if (p.any_scale) hipLaunchKernelGGL(route_scale_kernel, dim3(bag_blocks), dim3(256), 0, st, p);
@@ -511,9 +656,38 @@ extern "C" int krs_shard_route(const krs_shard_feature* feats, const krs_shard_f
                      p.ws.meta + kMetaNseg);
   hipLaunchKernelGGL(route_segments_kernel, dim3(p.n_blocks), dim3(256), 0, st, p);
   hipLaunchKernelGGL(route_finalize_kernel, dim3(1), dim3(64), 0, st, p);
-  hipLaunchKernelGGL(route_pack_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, p);
+  if (cap_l > 0) hipLaunchKernelGGL(route_pack_static_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(route_pack_kernel, dim3((unsigned)ceil_div(nnz, 256)), dim3(256), 0, st, p);
   KRS_CHECK_LAUNCH("krs_shard_route");
   return KRS_OK;
+}
+
+extern "C" int krs_shard_route(const krs_shard_feature* feats, const krs_shard_feature* feats_host, int n_feats,
+                               const void* ids, int id_type, const void* offsets, int offset_type,
+                               const float* weights, int64_t nnz, int batch, int n_shards, int emit_weights,
+                               int32_t* packed, int32_t* seg_bag, int32_t* seg_grow, int32_t* bag_seg,
+                               int64_t* counts, int32_t* err_flag, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  return shard_route_impl(feats, feats_host, n_feats, ids, id_type, offsets, offset_type, weights, nnz, batch, n_shards,
+                          emit_weights, 0, 0, packed, seg_bag, seg_grow, bag_seg, counts, err_flag, workspace,
+                          workspace_bytes, stream);
+}
+
+extern "C" int64_t krs_shard_static_block_words(int64_t cap_lookups, int64_t cap_segments, int emit_weights) {
+  return kStaticHeader + cap_lookups * (1 + (emit_weights != 0)) + cap_segments;
+}
+
+extern "C" int krs_shard_route_static(const krs_shard_feature* feats, const krs_shard_feature* feats_host, int n_feats,
+                                      const void* ids, int id_type, const void* offsets, int offset_type,
+                                      const float* weights, int64_t nnz, int batch, int n_shards, int emit_weights,
+                                      int64_t cap_lookups, int64_t cap_segments,
+                                      int32_t* packed, int32_t* seg_bag, int32_t* seg_grow, int32_t* bag_seg,
+                                      int64_t* counts, int32_t* err_flag, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  KRS_REQUIRE(cap_lookups > 0 && cap_segments > 0, "shard_route_static: capacities must be positive");
+  return shard_route_impl(feats, feats_host, n_feats, ids, id_type, offsets, offset_type, weights, nnz, batch, n_shards,
+                          emit_weights, cap_lookups, cap_segments, packed, seg_bag, seg_grow, bag_seg, counts, err_flag,
+                          workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t krs_shard_unpack_workspace_bytes(int64_t total_segments) {
@@ -545,6 +719,29 @@ extern "C" int krs_shard_unpack(const int32_t* packed, int n_sources, const int6
   // lengths -> exclusive offsets (offsets[n_seg] = total)
   scan::exclusive(offsets, offsets, n_seg + 1, reinterpret_cast<int32_t*>(workspace), nullptr, st);
   KRS_CHECK_LAUNCH("krs_shard_unpack");
+  return KRS_OK;
+}
+
+extern "C" int krs_shard_unpack_static(const int32_t* packed, int n_sources, int64_t cap_lookups, int64_t cap_segments,
+                                       int weighted, int32_t* rows, float* w, int32_t* offsets, int64_t* stats,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  KRS_REQUIRE(n_sources >= 1 && n_sources <= kMaxShards, "shard_unpack_static: n_sources must be in [1, %d]", kMaxShards);
+  KRS_REQUIRE(cap_lookups > 0 && cap_segments > 0 && cap_lookups % 4 == 0 && cap_segments % 4 == 0,
+              "shard_unpack_static: capacities must be positive multiples of 4");
+  KRS_REQUIRE(packed && rows && offsets && (!weighted || w), "shard_unpack_static: null argument");
+  KRS_REQUIRE(cap_lookups * n_sources < 0x7fffffffLL, "shard_unpack_static: lookups must fit int32");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  UnpackStaticParams p;
+  p.packed = packed; p.n_src = n_sources; p.weighted = weighted != 0; p.cap_l = cap_lookups; p.cap_s = cap_segments;
+  p.block_words = kStaticHeader + cap_lookups * (1 + p.weighted) + cap_segments;
+  p.rows = rows; p.w = w; p.offsets = offsets; p.stats = stats;
+  const int64_t n_seg = cap_segments * n_sources;
+  if (workspace_bytes < krs_shard_unpack_workspace_bytes(n_seg) || !workspace)
+    return fail(KRS_ERR_WORKSPACE, "shard_unpack_static: workspace too small");
+  const int64_t span = std::max<int64_t>(cap_lookups * n_sources, n_seg + 1);
+  hipLaunchKernelGGL(unpack_static_kernel, dim3((unsigned)ceil_div(span, 256)), dim3(256), 0, st, p);
+  scan::exclusive(offsets, offsets, n_seg + 1, reinterpret_cast<int32_t*>(workspace), nullptr, st);
+  KRS_CHECK_LAUNCH("krs_shard_unpack_static");
   return KRS_OK;
 }
 

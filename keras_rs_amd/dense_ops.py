@@ -13,6 +13,7 @@ from typing import Sequence
 import torch
 
 from keras_rs_amd import _lib as L
+from keras_rs_amd import probe
 
 ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID,
         "tanh": L.ACT_TANH}
@@ -22,7 +23,10 @@ def _rowmajor(t: torch.Tensor, what: str) -> torch.Tensor:
     L.require_device(t, what)
     if t.dim() != 2:
         raise L.KrsError(f"{what}: expected a matrix, got shape {tuple(t.shape)}")
-    return t if t.stride(1) == 1 else t.contiguous()
+    # a row-broadcast view (strides (0, 1), e.g. the gradient of y.sum(0)) has no leading dimension a kernel can walk
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        return t.contiguous()
+    return t
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_is_km: bool = False, b_is_nk: bool = False,
@@ -72,12 +76,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_is_km: bool = False, b_is_nk: bo
         ep.r, ep.ldr, ep.beta = r.data_ptr(), r.stride(0), float(beta)
     wsb = L.lib().krs_gemm_workspace_bytes(C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int(int(a_is_km)))
     ws = torch.empty(int(wsb), dtype=torch.uint8, device=a.device) if wsb else None
-    rc = L.lib().krs_gemm(
-        L.ptr(a), C.c_int64(a.stride(0)), C.c_int(int(a_is_km)),
-        L.ptr(b), C.c_int64(b.stride(0)), C.c_int(int(b_is_nk)),
-        L.ptr(c), C.c_int64(c.stride(0)), C.c_int64(m), C.c_int64(n), C.c_int64(k),
-        C.c_int(L.fdtype(a)), C.c_int(L.fdtype(c)), C.byref(ep),
-        L.ptr(ws), C.c_size_t(int(wsb)), L.stream_ptr())
+    with probe.span("gemm", 2.0 * m * n * k):
+        rc = L.lib().krs_gemm(
+            L.ptr(a), C.c_int64(a.stride(0)), C.c_int(int(a_is_km)),
+            L.ptr(b), C.c_int64(b.stride(0)), C.c_int(int(b_is_nk)),
+            L.ptr(c), C.c_int64(c.stride(0)), C.c_int64(m), C.c_int64(n), C.c_int64(k),
+            C.c_int(L.fdtype(a)), C.c_int(L.fdtype(c)), C.byref(ep),
+            L.ptr(ws), C.c_size_t(int(wsb)), L.stream_ptr())
     L.check(rc, "krs_gemm")
     return c, u
 

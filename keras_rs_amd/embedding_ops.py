@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from keras_rs_amd import _lib as L
+from keras_rs_amd import probe
 
 
 class FusedBags:
@@ -106,14 +107,16 @@ class FusedBags:
         scale = torch.empty(n_feats * batch, dtype=torch.float32, device=dev) if want_scale else None
         if weights is not None and weights.dtype != torch.float32:
             weights = weights.float()
-        rc = L.lib().krs_embed_bag_fwd(
-            L.ptr(self.table_desc()), L.ptr(self.feature_desc(batch, hots, dev)), C.c_int(n_feats),
-            L.ptr(ids), C.c_int(L.itype(ids)),
-            L.ptr(offsets), C.c_int(L.itype(offsets) if offsets is not None else L.I32),
-            L.ptr(weights), C.c_int64(ids.numel()), C.c_int(batch), C.c_int(self.dim),
-            C.c_int(L.fdtype(self.tables[0])),
-            L.ptr(out), C.c_int(L.fdtype(out)), C.c_int64(out.stride(0)),
-            L.ptr(scale), L.ptr(err_flag), L.stream_ptr())
+        tdesc, fdesc = self.table_desc(), self.feature_desc(batch, hots, dev)
+        with probe.span("k1"):
+            rc = L.lib().krs_embed_bag_fwd(
+                L.ptr(tdesc), L.ptr(fdesc), C.c_int(n_feats),
+                L.ptr(ids), C.c_int(L.itype(ids)),
+                L.ptr(offsets), C.c_int(L.itype(offsets) if offsets is not None else L.I32),
+                L.ptr(weights), C.c_int64(ids.numel()), C.c_int(batch), C.c_int(self.dim),
+                C.c_int(L.fdtype(self.tables[0])),
+                L.ptr(out), C.c_int(L.fdtype(out)), C.c_int64(out.stride(0)),
+                L.ptr(scale), L.ptr(err_flag), L.stream_ptr())
         L.check(rc, "krs_embed_bag_fwd")
         return out, scale
 
@@ -126,12 +129,14 @@ class FusedBags:
         nnz = ids.numel()
         nbytes = L.lib().krs_embed_bag_bwd_workspace_bytes(C.c_int64(nnz))
         ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=ids.device)
-        rc = L.lib().krs_embed_bag_bwd_plan(
-            L.ptr(self.table_desc()), L.ptr(self.feature_desc(batch, hots, ids.device)),
-            C.c_int(len(self.features)), L.ptr(ids), C.c_int(L.itype(ids)),
-            L.ptr(offsets), C.c_int(L.itype(offsets) if offsets is not None else L.I32),
-            C.c_int(batch), C.c_int64(nnz), C.c_int64(self.total_rows),
-            L.ptr(ws), C.c_size_t(ws.numel()), L.ptr(err_flag), L.stream_ptr())
+        tdesc, fdesc = self.table_desc(), self.feature_desc(batch, hots, ids.device)
+        with probe.span("k2_plan"):
+            rc = L.lib().krs_embed_bag_bwd_plan(
+                L.ptr(tdesc), L.ptr(fdesc),
+                C.c_int(len(self.features)), L.ptr(ids), C.c_int(L.itype(ids)),
+                L.ptr(offsets), C.c_int(L.itype(offsets) if offsets is not None else L.I32),
+                C.c_int(batch), C.c_int64(nnz), C.c_int64(self.total_rows),
+                L.ptr(ws), C.c_size_t(ws.numel()), L.ptr(err_flag), L.stream_ptr())
         L.check(rc, "krs_embed_bag_bwd_plan")
         return ws
 
@@ -171,12 +176,14 @@ class FusedBags:
         if kind in ("sgd", "adagrad", "adagrad_rowwise"):
             fn = {"sgd": L.lib().krs_embed_bag_bwd_fused_sgd, "adagrad": L.lib().krs_embed_bag_bwd_fused_adagrad,
                   "adagrad_rowwise": L.lib().krs_embed_bag_bwd_fused_adagrad_rowwise}[kind]
-            rc = fn(*head, *tail)
+            with probe.span("k2_apply"):
+                rc = fn(*head, *tail)
         elif kind in ("adam", "ftrl"):
             if hyper is None or len(hyper) != 4:
                 raise L.KrsError(f"fused {kind} needs its four hyper-parameters")
             fn = {"adam": L.lib().krs_embed_bag_bwd_fused_adam, "ftrl": L.lib().krs_embed_bag_bwd_fused_ftrl}[kind]
-            rc = fn(*head, *(C.c_float(float(h)) for h in hyper), *tail)
+            with probe.span("k2_apply"):
+                rc = fn(*head, *(C.c_float(float(h)) for h in hyper), *tail)
         else:
             raise L.KrsError(f"unknown fused optimizer {kind!r}")
         L.check(rc, f"krs_embed_bag_bwd_fused_{kind}")

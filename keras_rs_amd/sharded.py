@@ -141,6 +141,52 @@ class HipShardKernels:
         L.check(rc, "krs_shard_unpack")
         return rows[:n_cnt], (None if w is None else w[:n_cnt]), off
 
+    def route_static(self, desc: np.ndarray, ids, offsets, weights, batch: int, n_shards: int, emit_w: bool,
+                     cap_l: int, cap_s: int, err_flag=None):
+        """krs_shard_route_static: fixed-size blocks.  Returns dict(packed [n_shards, W] int32, seg_grow
+        [n_shards*cap_s], bag_seg (segment SLOTS), counts [3, n_shards] on the device)."""
+        dev = ids.device
+        key = (desc.tobytes(), str(dev))
+        ddev = self._desc_cache.get(key)
+        if ddev is None:
+            ddev = self._desc_cache[key] = L.struct_to_device(desc, dev)
+        nnz, n_feats = ids.numel(), len(desc)
+        n_bags = batch * n_feats
+        words = int(L.lib().krs_shard_static_block_words(C.c_int64(cap_l), C.c_int64(cap_s), C.c_int(int(emit_w))))
+        packed = torch.empty((n_shards, words), dtype=torch.int32, device=dev)
+        seg_bag = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        seg_grow = torch.empty(n_shards * cap_s, dtype=torch.int32, device=dev)
+        bag_seg = torch.empty((max(n_bags, 1), n_shards), dtype=torch.int32, device=dev)
+        counts = torch.empty((3, n_shards), dtype=torch.int64, device=dev)
+        wsb = int(L.lib().krs_shard_route_workspace_bytes(C.c_int64(nnz), C.c_int64(n_bags), C.c_int(n_shards)))
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        if weights is not None and weights.dtype != torch.float32:
+            weights = weights.float()
+        rc = L.lib().krs_shard_route_static(
+            L.ptr(ddev), desc.ctypes.data_as(C.c_void_p), C.c_int(n_feats), L.ptr(ids), C.c_int(L.itype(ids)),
+            L.ptr(offsets), C.c_int(L.itype(offsets) if offsets is not None else L.I32), L.ptr(weights),
+            C.c_int64(nnz), C.c_int(batch), C.c_int(n_shards), C.c_int(int(emit_w)), C.c_int64(cap_l), C.c_int64(cap_s),
+            L.ptr(packed), L.ptr(seg_bag), L.ptr(seg_grow), L.ptr(bag_seg), L.ptr(counts), L.ptr(err_flag), L.ptr(ws),
+            C.c_size_t(ws.numel()), L.stream_ptr())
+        L.check(rc, "krs_shard_route_static")
+        return dict(packed=packed, seg_grow=seg_grow, bag_seg=bag_seg, counts=counts)
+
+    def unpack_static(self, packed, cap_l: int, cap_s: int, weighted: bool):
+        """krs_shard_unpack_static: (rows int32 [n*cap_l], w | None, offsets int32 [n*cap_s + 1], stats int64 [4])."""
+        dev = packed.device
+        n = packed.shape[0]
+        rows = torch.empty(n * cap_l, dtype=torch.int32, device=dev)
+        w = torch.empty(n * cap_l, dtype=torch.float32, device=dev) if weighted else None
+        off = torch.empty(n * cap_s + 1, dtype=torch.int32, device=dev)
+        stats = torch.empty(4, dtype=torch.int64, device=dev)
+        wsb = int(L.lib().krs_shard_unpack_workspace_bytes(C.c_int64(n * cap_s)))
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        rc = L.lib().krs_shard_unpack_static(L.ptr(packed), C.c_int(n), C.c_int64(cap_l), C.c_int64(cap_s),
+                                             C.c_int(int(weighted)), L.ptr(rows), L.ptr(w), L.ptr(off), L.ptr(stats),
+                                             L.ptr(ws), C.c_size_t(wsb), L.stream_ptr())
+        L.check(rc, "krs_shard_unpack_static")
+        return rows, w, off, stats
+
     def combine(self, partials, bag_seg, batch: int, n_feats: int, dim: int, out):
         """krs_shard_combine into `out` (a [batch, n_feats*dim] row-major window of the slab)."""
         rc = L.lib().krs_shard_combine(L.ptr(partials), L.ptr(bag_seg), C.c_int(batch), C.c_int(n_feats),
@@ -259,8 +305,29 @@ class ShardedDistributedEmbedding(base.Layer):
 
     def __init__(self, feature_configs: dict[str, FeatureConfig], *, process_group=None, kernels=None,
                  slab_lead_cols: int = 0, replicate_below: int = 0, grad_average: bool = False,
-                 partial_dtype=None, **kwargs: Any):
+                 partial_dtype=None, exchange: str = "exact", capacity="auto", capacity_headroom: float = 1.25,
+                 **kwargs: Any):
         super().__init__(**kwargs)
+        if exchange not in ("exact", "static"):
+            raise ValueError(f"exchange must be 'exact' or 'static', got {exchange!r}")
+        # "exact": the all-to-alls carry exactly the lookups of the step; their sizes reach the host through ONE
+        #   wait per lookup (krs_publish_i64).
+        # "static": the reference's SparseCore contract (static buffers sized by max_ids_per_partition /
+        #   max_unique_ids_per_partition, ids beyond them dropped, limits learnt from running statistics:
+        #   distributed_embedding_config.py:54-61, jax/embedding_utils.py:187-197, jax/distributed_embedding.py:657-664):
+        #   every (home, owner) pair exchanges a fixed-size block, no count ever reaches the host, the step has no
+        #   host wait.  capacity = "auto": expected per-owner load of a uniform id distribution x capacity_headroom
+        #   (MOD interleaving balances any distribution over ROWS; needs dense bags); "table_config": the sums of
+        #   TableConfig.max_ids_per_partition / max_unique_ids_per_partition over the group's features; or an
+        #   explicit (lookups, segments) pair per (home, owner) block.  Lookups that do not fit are dropped and
+        #   counted (`overflow_steps`), and the capacity grows to the need every rank has seen (same step on all ranks).
+        self.exchange = exchange
+        self._capacity_spec = capacity
+        self.capacity_headroom = float(capacity_headroom)
+        self._caps: dict = {}            # (group, batch, hots) -> [cap_lookups, cap_segments]
+        self._stats_q: dict = {}         # group -> list of (step, event, pinned stats, caps key)
+        self._stat_step: dict = {}
+        self.overflow_steps = 0
         self.slab_lead_cols = int(slab_lead_cols)  # as DistributedEmbedding: room for layers.concat_features
         self._pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -318,6 +385,7 @@ class ShardedDistributedEmbedding(base.Layer):
                                                     name=f"{self.name}_replicated")
         self._anchor = None
         self._host_counts = None
+        self._collectives_at_world1 = False   # bench --rccl-self: run the collectives through a one-rank communicator
         self._err_dev = self._err_host = self._err_event = None
         self.last_exchange: dict = {}    # host-side counts of the last lookup (tests / load-balance diagnostics)
 
@@ -519,10 +587,12 @@ class ShardedDistributedEmbedding(base.Layer):
             self._err_event.record()
         return {p: out[p] for p in self._paths}
 
-    def _a2a(self, send: torch.Tensor, send_counts: list, recv_counts: list) -> torch.Tensor:
-        recv = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        if self.world == 1:
-            recv.copy_(send)
+    def _a2a(self, send: torch.Tensor, send_counts: list | None = None, recv_counts: list | None = None) -> torch.Tensor:
+        """all-to-all of the leading dimension; without counts every pair exchanges send.shape[0] / world rows."""
+        n_recv = send.shape[0] if recv_counts is None else sum(recv_counts)
+        recv = torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if self.world == 1 and not (dist.is_initialized() and self._collectives_at_world1):
+            recv.copy_(send)     # dry run on one GPU: a device copy stands in for the links
         elif send.is_cuda and dist.get_backend(self._pg) == "gloo":
             # gloo has no device all-to-all: stage through the host (debugging / single-GPU test rigs only;
             # production runs use the nccl = RCCL backend)
@@ -564,19 +634,121 @@ class ShardedDistributedEmbedding(base.Layer):
             base_pos += batch * hot
         return desc
 
+    # ---------------------------------------------------------------- static-capacity exchange
+    def _capacity(self, gi, g, batch, hots, nnz):
+        """[cap_lookups, cap_segments] of one (home, owner) block for this group and batch shape, or None when the
+        static form cannot be sized (ragged bags without an explicit capacity) -> exact exchange."""
+        key = (gi, batch, None if hots is None else tuple(hots))
+        cap = self._caps.get(key)
+        if cap is not None:
+            return cap, key
+        n, spec = self.world, self._capacity_spec
+        up4 = lambda v: int(-(-int(v) // 4) * 4)   # noqa: E731
+        n_bags = batch * len(g.paths)
+        if isinstance(spec, (tuple, list)):
+            cap = [up4(spec[0]), up4(spec[1])]
+        elif spec == "table_config":
+            tcs = [g.table_configs[t] for t in g.table_of_feature]
+            cap = [up4(sum(tc.max_ids_per_partition for tc in tcs)), up4(sum(tc.max_unique_ids_per_partition for tc in tcs))]
+        elif spec == "auto" and hots is not None:
+            h = self.capacity_headroom
+            exp_l = nnz / n
+            exp_s = sum(batch * (1.0 - (1.0 - 1.0 / n) ** hot) for hot in hots)
+            cap = [min(up4(nnz), up4(h * exp_l + 64)), min(up4(n_bags), up4(h * exp_s + 64))]
+        else:
+            return None, key
+        cap = [max(cap[0], 4), max(cap[1], 4)]
+        self._caps[key] = cap
+        return cap, key
+
+    def _note_stats(self, gi, stats, key):
+        """Running statistics of the static exchange (the reference's update_stats): `stats` = device int64[4] of
+        this step's unpack (max need_l / need_s over ALL ranks' blocks: identical on every rank).  They are copied to
+        page-locked memory behind an event and looked at two steps later -- long complete, so no wait -- on every
+        rank at the same step: a need above the capacity grows it (x 1.125) for the steps that follow."""
+        step = self._stat_step.get(gi, 0)
+        self._stat_step[gi] = step + 1
+        q = self._stats_q.setdefault(gi, [])
+        if stats.is_cuda:
+            host = torch.empty(4, dtype=torch.int64).pin_memory()
+            host.copy_(stats, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = stats.clone(), None
+        q.append((step, ev, host, key))
+        while q and q[0][0] <= step - 2:
+            _, ev0, h0, key0 = q.pop(0)
+            if ev0 is not None:
+                ev0.synchronize()
+            need_l, need_s = int(h0[0]), int(h0[1])
+            cap = self._caps.get(key0)
+            self.last_exchange.update(need=(need_l, need_s), received=(int(h0[2]), int(h0[3])))
+            if cap is not None and (need_l > cap[0] or need_s > cap[1]):
+                self.overflow_steps += 1
+                up64 = lambda v: int(-(-int(v) // 64) * 64)   # noqa: E731
+                if need_l > cap[0]:
+                    cap[0] = up64(need_l * 1.125)
+                if need_s > cap[1]:
+                    cap[1] = up64(need_s * 1.125)
+
+    def _forward_static(self, gi, g, cap, key, ids, batch, hots, offsets, weights, lead, emit_w):
+        k, n = self.kernels, self.world
+        cap_l, cap_s = cap
+        dev = ids.device
+        n_feats = len(g.paths)
+        shard = getattr(self, g.pname).data
+        r = k.route_static(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, cap_l, cap_s,
+                           self._err_flag(dev))
+        recv_packed = self._a2a(r["packed"])                                    # [n, W]: equal splits, no counts
+        rows, w, off, stats = k.unpack_static(recv_packed, cap_l, cap_s, emit_w)
+        pdt = self._partial_dtype or self.compute_dtype
+        if isinstance(pdt, str):
+            pdt = {"float32": torch.float32, "bfloat16": torch.bfloat16}[pdt]
+        partial = k.pool_segments(shard, rows, off, w, pdt)                       # [n * cap_s, dim]: one per segment slot
+        back = self._a2a(partial)
+        slab = torch.empty((batch, lead + n_feats * g.dim), dtype=back.dtype, device=dev)
+        k.combine(back, r["bag_seg"], batch, n_feats, g.dim, slab[:, lead:])
+        if slab.dtype != self.compute_dtype:
+            slab = slab.to(self.compute_dtype)
+        es = back.element_size()
+        words = r["packed"].shape[1]
+        off_rank = (n - 1) / n if n > 1 else 1.0   # one-GPU dry run: what the stand-in copies move
+        self.last_exchange = dict(mode="static", capacity=(cap_l, cap_s),
+                                  bytes=dict(ids_fwd=4 * n * words, partials_fwd=n * cap_s * g.dim * es,
+                                             grads_bwd=n * cap_s * g.dim * es),
+                                  bytes_per_step=int(off_rank * (4 * n * words + 2 * n * cap_s * g.dim * es)),
+                                  overflow_steps=self.overflow_steps)
+        self._note_stats(gi, stats, key)
+        saved = dict(batch=batch, seg_grow=r["seg_grow"], send_segs=None, recv_segs=None,
+                     rows=rows, off=off, w=w, pdt=pdt, out_meta=(slab.dtype, slab.device))
+        return slab, saved
+
     def _forward_impl(self, gi, ids, batch, hots, offsets, weights, lead):
         k, n, g = self.kernels, self.world, self._sgroups[gi]
         dev = ids.device
         n_feats = len(g.paths)
         shard = getattr(self, g.pname).data
         emit_w = weights is not None or any(g.table_configs[t].combiner != "sum" for t in g.table_of_feature)
+        if self.exchange == "static":
+            cap, key = self._capacity(gi, g, batch, hots, ids.numel())
+            if cap is not None:
+                return self._forward_static(gi, g, cap, key, ids, batch, hots, offsets, weights, lead, emit_w)
         r = k.route(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, self._err_flag(dev))
         mine, theirs = self._exchange_sizes(r["counts"])
         send_cnt, send_segs, send_words = mine
         recv_cnt, recv_segs, recv_words = theirs
         n_seg = sum(send_segs)
-        self.last_exchange = dict(send_lookups=send_cnt, recv_lookups=recv_cnt, send_segments=send_segs,
-                                  recv_segments=recv_segs)
+        es_p = 2 if (self._partial_dtype or self.compute_dtype) in (torch.bfloat16, "bfloat16") else 4
+        own = self.rank if n > 1 else -1      # the block a rank sends itself crosses no link
+        off_words = sum(wd for d, wd in enumerate(send_words) if d != own)
+        off_segs = sum(sg for d, sg in enumerate(send_segs) if d != own)
+        self.last_exchange = dict(mode="exact", send_lookups=send_cnt, recv_lookups=recv_cnt, send_segments=send_segs,
+                                  recv_segments=recv_segs,
+                                  bytes=dict(ids_fwd=4 * sum(send_words), partials_fwd=n_seg * g.dim * es_p,
+                                             grads_bwd=n_seg * g.dim * es_p),
+                                  bytes_per_step=int(4 * off_words + 2 * off_segs * g.dim * es_p) if n > 1 else
+                                  int(4 * sum(send_words) + 2 * n_seg * g.dim * es_p))
         # to the owners: ONE packed buffer (rows | weights | segment lengths per owner)
         recv_packed = self._a2a(r["packed"][:sum(send_words)], send_words, recv_words)
         rows, w, off = k.unpack(recv_packed, recv_cnt, recv_segs, emit_w)

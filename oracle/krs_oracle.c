@@ -212,7 +212,7 @@ int krs_oracle_apply_optimizer2(void* table, int table_dtype, float* acc, const 
           if ((l & o) == 0) { float a = part[l], b = part[l | o]; part[l] = a + b; part[l | o] = b + a; }
         }
       const float a_new = acc[r] + part[0] / (float)dim;
-      const float inv = lr / sqrtf(a_new);
+      const float inv = a_new > 0.0f ? lr / sqrtf(a_new) : 0.0f;   /* zero accumulator + zero gradient: row unchanged */
       for (int c = 0; c < dim; ++c) {
         int64_t i = r * dim + c;
         st(table, table_dtype, i, ld(table, table_dtype, i) - inv * grad[i]);

@@ -435,6 +435,80 @@ def shard_unpack(packed, lookups, segments, weighted):
     return rows[:n_cnt], (w[:n_cnt] if weighted else None), off
 
 
+STATIC_HEADER = 4
+FLAG_CAPACITY_OVERFLOW = 4
+
+
+def shard_static_block_words(cap_l, cap_s, emit_weights):
+    return STATIC_HEADER + cap_l * (1 + int(bool(emit_weights))) + cap_s
+
+
+def shard_route_static(feats, ids, offsets, weights, batch, n_shards, emit_weights, cap_l, cap_s):
+    """Static-capacity form of shard_route (include/krs.h: krs_shard_route_static), restated on top of the exact
+    oracle: the reference's static buffers + id dropping (distributed_embedding_config.py:54-61,
+    jax/embedding_utils.py:187-197).  Owner d's block = [kept lookups, kept segments, need_l, need_s | rows[cap_l] |
+    weights[cap_l] | segment lengths[cap_s]]; owner d keeps its first cap_s segments and of those the first cap_l
+    lookups.  Returns dict(packed [n_shards, W], seg_grow [n_shards*cap_s], bag_seg (slots), counts, flags)."""
+    r = shard_route(feats, ids, offsets, weights, batch, n_shards, emit_weights)
+    ew = int(bool(emit_weights))
+    n_feats = len(feats)
+    W = shard_static_block_words(cap_l, cap_s, ew)
+    packed = np.zeros((n_shards, W), np.int32)
+    seg_grow = np.zeros(n_shards * cap_s, np.int32)
+    bag_seg = np.full((max(batch * n_feats, 1), n_shards), -1, np.int32)
+    cnt, segs, words = (r["counts"][k] for k in range(3))
+    need_l, need_s = int(cnt.max(initial=0)), int(segs.max(initial=0))
+    flags = r["flags"]
+    base, seg0 = 0, 0
+    for d in range(n_shards):
+        c, g = int(cnt[d]), int(segs[d])
+        blk = r["packed"][base: base + int(words[d])]
+        rows, wts, lens = blk[:c], blk[c: c + c * ew], blk[c * (1 + ew):]
+        keep_s = min(g, cap_s)
+        keep_l = min(int(lens[:keep_s].sum()), cap_l)
+        if keep_l < c or keep_s < g:
+            flags |= FLAG_CAPACITY_OVERFLOW
+        packed[d, :4] = (keep_l, keep_s, need_l, need_s)
+        packed[d, 4: 4 + keep_l] = rows[:keep_l]
+        if ew:
+            packed[d, 4 + cap_l: 4 + cap_l + keep_l] = wts[:keep_l]
+        ends = np.minimum(np.cumsum(lens[:keep_s]), keep_l)
+        starts = np.minimum(np.concatenate([[0], np.cumsum(lens[:keep_s])[:-1]]), keep_l) if keep_s else np.zeros(0, np.int64)
+        packed[d, 4 + cap_l * (1 + ew): 4 + cap_l * (1 + ew) + keep_s] = (ends - starts).astype(np.int32)
+        for j in range(keep_s):
+            bag = int(r["seg_bag"][seg0 + j])
+            seg_grow[d * cap_s + j] = (bag % batch) * n_feats + bag // batch
+            bag_seg[bag, d] = d * cap_s + j
+        base += int(words[d])
+        seg0 += g
+    return dict(packed=packed, seg_grow=seg_grow, bag_seg=bag_seg, counts=r["counts"], flags=flags)
+
+
+def shard_unpack_static(packed, cap_l, cap_s, weighted):
+    """Owner side of the static form (krs_shard_unpack_static): packed [n_src, W] -> rows / w [n_src*cap_l] (compact,
+    tail = -1 / 0), offsets [n_src*cap_s + 1] over the segment slots, stats [4]."""
+    packed = np.ascontiguousarray(packed, np.int32)
+    n_src = packed.shape[0]
+    wt = int(bool(weighted))
+    rows = np.full(n_src * cap_l, -1, np.int32)
+    w = np.zeros(n_src * cap_l, np.float32)
+    lens = np.zeros(n_src * cap_s + 1, np.int64)
+    run = 0
+    nl = ns = tot_s = 0
+    for s in range(n_src):
+        c = int(np.clip(packed[s, 0], 0, cap_l))
+        g = int(np.clip(packed[s, 1], 0, cap_s))
+        rows[run: run + c] = packed[s, 4: 4 + c]
+        if wt:
+            w[run: run + c] = packed[s, 4 + cap_l: 4 + cap_l + c].view(np.float32)
+        lens[s * cap_s: s * cap_s + g] = packed[s, 4 + cap_l * (1 + wt): 4 + cap_l * (1 + wt) + g]
+        run += c
+        tot_s += g
+        nl, ns = max(nl, int(packed[s, 2])), max(ns, int(packed[s, 3]))
+    off = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int32)
+    return rows, (w if wt else None), off, np.array([nl, ns, run, tot_s], np.int64)
+
+
 def shard_combine(partials, bag_seg, batch, n_feats, dim, out=None):
     n_shards = bag_seg.shape[1]
     if out is None:

@@ -113,7 +113,8 @@ def main():
     all_g = [{f"f{i}": np.random.default_rng(130 + r * 10 + i).uniform(0, 1, (B, D)).astype(np.float32)
               for i in range(4)} for r in range(world)]
 
-    layer = ShardedDistributedEmbedding(configs(), slab_lead_cols=8)
+    exchange = sys.argv[2] if len(sys.argv) > 2 else "exact"
+    layer = ShardedDistributedEmbedding(configs(), slab_lead_cols=8, exchange=exchange)
     layer.build(None)
     layer.set_embedding_tables(full)
     out = layer(all_ids[rank], all_w[rank])
@@ -134,7 +135,9 @@ def main():
                                    rtol=1e-5, atol=1e-5)
     for k, v in ref.get_embedding_tables().items():
         np.testing.assert_allclose(got_tables[k], v.cpu().numpy(), rtol=2e-5, atol=2e-6)
-    if kind == "adagrad":
+    if exchange == "static":
+        assert layer.last_exchange["mode"] == "static" and layer.overflow_steps == 0
+    if kind == "adagrad" and exchange == "exact":
         criteo_shaped(rank, world, kl, ShardedDistributedEmbedding)
     dist.barrier()
     if rank == 0:

@@ -30,6 +30,19 @@ class OracleShardKernels:
         rows, w, off = ko.shard_unpack(packed.numpy(), lookups, segments, weighted)
         return torch.from_numpy(rows.copy()), (None if w is None else torch.from_numpy(w.copy())), torch.from_numpy(off)
 
+    def route_static(self, desc, ids, offsets, weights, batch, n_shards, emit_w, cap_l, cap_s, err_flag=None):
+        r = ko.shard_route_static(desc.view(ko.SHARD_FEATURE_DT), np.ascontiguousarray(ids.numpy()),
+                                  None if offsets is None else np.ascontiguousarray(offsets.numpy()),
+                                  None if weights is None else weights.numpy(), batch, n_shards, emit_w, cap_l, cap_s)
+        self.flags = r["flags"]
+        return dict(packed=torch.from_numpy(r["packed"]), seg_grow=torch.from_numpy(r["seg_grow"]),
+                    bag_seg=torch.from_numpy(r["bag_seg"]), counts=torch.from_numpy(r["counts"].copy()))
+
+    def unpack_static(self, packed, cap_l, cap_s, weighted):
+        rows, w, off, stats = ko.shard_unpack_static(packed.numpy(), cap_l, cap_s, weighted)
+        return (torch.from_numpy(rows), None if w is None else torch.from_numpy(w), torch.from_numpy(off),
+                torch.from_numpy(stats))
+
     def combine(self, partials, bag_seg, batch, n_feats, dim, out):
         res = ko.shard_combine(np.ascontiguousarray(partials.numpy()), bag_seg.numpy(), batch, n_feats, dim)
         out.copy_(torch.from_numpy(res))
@@ -61,7 +74,7 @@ class OracleShardKernels:
                                None if weights is None else np.ascontiguousarray(weights.numpy()), None,
                                np.ascontiguousarray(seg_grads.numpy() * np.float32(grad_scale)), n_seg, t.shape[1])
         touched = np.zeros(t.shape[0], np.uint8)
-        touched[r] = 1
+        touched[r[: int(offsets[-1])]] = 1     # (the static form pads `rows` behind the last segment with -1)
         ko.apply_optimizer(t, None if slot is None else slot.numpy(), dense, touched, lr, kind, hyper)
 
 
@@ -88,7 +101,16 @@ def main():
         feats[f"f{i}"] = kl.FeatureConfig(f"f{i}", tc, (B, hots[i]), (B, D))
     for i, tc in enumerate(tcs):
         tc.combiner = combs[i]
-    layer = ShardedDistributedEmbedding(feats, kernels=OracleShardKernels(), device="cpu", slab_lead_cols=3 * rank)
+    exchange = sys.argv[3] if len(sys.argv) > 3 else "exact"
+    kw = {}
+    if exchange == "static_tiny":
+        # a capacity the first steps overflow: lookups are dropped (flag raised), the running statistics grow the
+        # capacity on every rank at the same step, and from then on the result is the exact one
+        exchange, kw = "static", dict(capacity=(4, 4))
+    elif exchange == "static_cfg":
+        exchange, kw = "static", dict(capacity="table_config")
+    layer = ShardedDistributedEmbedding(feats, kernels=OracleShardKernels(), device="cpu", slab_lead_cols=3 * rank,
+                                        exchange=exchange, **kw)
     rng = np.random.default_rng(7)
     full = {f"t{i}": rng.uniform(-1, 1, (V[i], D)).astype(np.float32) for i in range(3)}
     layer.set_embedding_tables(full)
@@ -112,7 +134,15 @@ def main():
         w = {k: w[k] * keep[k] for k in ids}
     else:
         keep = {k: np.ones(v.shape, bool) for k, v in ids.items()}
+        if kw.get("capacity") == (4, 4):
+            with torch.no_grad():
+                for _ in range(3):      # steps 0-2 overflow; step 0's statistics are read at step 2
+                    layer(ids, w if use_w else None)
+                    assert layer.kernels.flags & ko.FLAG_CAPACITY_OVERFLOW
+            assert layer.overflow_steps >= 1 and min(next(iter(layer._caps.values()))) >= 8
         out = layer(ids, w if use_w else None)
+        if exchange == "static":
+            assert layer.last_exchange["mode"] == "static" and not layer.kernels.flags & ko.FLAG_CAPACITY_OVERFLOW
     g = {k: torch.from_numpy(rng_r.uniform(0, 1, (B, D)).astype(np.float32)) for k in out}
     sum((o * g[k]).sum() for k, o in out.items()).backward()
 

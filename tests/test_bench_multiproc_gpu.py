@@ -31,3 +31,42 @@ def test_two_rank_bench_run_over_gloo():
     assert d["unit"] == "lookups/s" and d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
     assert "row-sharded over 2 GPUs" in d["config"]["parallelism"] and d["config"]["global_batch"] == 4096
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
+
+
+def _json_line(stdout):
+    return json.loads([ln for ln in stdout.strip().splitlines() if ln.startswith("{")][-1])
+
+
+def test_bare_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (RANK unset) starts its two ranks itself; with more ranks
+    than GPUs and the default backend it falls back to gloo and says so in the line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["value"] > 0
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        assert "gloo" in d["backend"] and "NOT a measurement" in d["backend"]
+    else:
+        assert "RCCL" in d["backend"]
+    assert d["a2a_bytes_per_step"] > 0 and d["exchange"]["mode"] == "static"
+    assert d["step_stats"]["median_ms"] > 0 and "roofline_step" in d
+
+
+def test_sharded_step_through_a_one_rank_rccl_communicator():
+    """--force-sharded --rccl-self: the sharded layer's collectives (all_to_all_single of the packed blocks, of the
+    partials and of the gradients) run through RCCL itself on a one-rank communicator -- the call path the multi-GPU
+    run takes, on the one GPU of the test box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    for exchange in ("static", "exact"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--rccl-self", "--exchange", exchange,
+               "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--batch", "8192", "--vocab", "100000"]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _json_line(r.stdout)
+        assert d["backend"] == "nccl (RCCL)" and d["exchange"]["mode"] == exchange and d["a2a_bytes_per_step"] > 0
+        assert "one-rank RCCL communicator" in d["config"]["parallelism"]

@@ -80,6 +80,74 @@ def test_route_unpack_match_oracle(n_shards, csr, weighted, id64, bad):
     assert int(off_[-1]) == int(counts[0].sum())
 
 
+@pytest.mark.parametrize("n_shards", [1, 2, 5, 8])
+@pytest.mark.parametrize("csr,weighted", [(False, False), (False, True), (True, True)])
+@pytest.mark.parametrize("fit", ["roomy", "tight_lookups", "tight_segments"])
+def test_static_route_unpack_match_oracle(n_shards, csr, weighted, fit):
+    """Static-capacity form (krs_shard_route_static / krs_shard_unpack_static) bit for bit against the oracle, with
+    room to spare (nothing dropped: the kept lookups ARE the exact form's) and with capacities that drop lookups /
+    segments (the reference's allow_id_dropping contract: what is dropped and the overflow flag must agree)."""
+    from keras_rs_amd.sharded import HipShardKernels
+
+    rng = np.random.default_rng(n_shards * 11 + csr * 5 + weighted)
+    batch = 257
+    vocabs = [5, 2000, 91, 30_000]
+    combs = ["sum", "mean", "sqrtn", "mean"] if weighted else ["sum"] * 4
+    local_off, off = [], 0
+    for v in vocabs:
+        local_off.append(off)
+        off += -(-v // n_shards)
+    if csr:
+        lens = rng.integers(0, 9, size=(len(vocabs), batch))
+        offsets = np.concatenate([[0], np.cumsum(lens.reshape(-1))]).astype(np.int32)
+        ids = np.concatenate([rng.integers(0, vocabs[f], int(lens[f].sum())) for f in range(len(vocabs))])
+        hots = None
+    else:
+        hots = [2, 1, 6, 21]
+        ids = np.concatenate([rng.integers(0, vocabs[f], batch * hots[f]) for f in range(len(vocabs))])
+        offsets = None
+    ids = ids.astype(np.int32)
+    w = rng.uniform(-1, 1, len(ids)).astype(np.float32) if weighted else None
+    emit_w = weighted
+    desc = _desc(n_shards, batch, hots, vocabs, combs, local_off)
+    exact = ko.shard_route(desc, ids, offsets, w, batch, n_shards, emit_w)
+    need_l, need_s = int(exact["counts"][0].max()), int(exact["counts"][1].max())
+    up4 = lambda v: -(-int(v) // 4) * 4  # noqa: E731
+    cap_l, cap_s = {"roomy": (up4(need_l * 1.2 + 4), up4(need_s * 1.2 + 4)),
+                    "tight_lookups": (max(4, up4(need_l * 0.7) - 4), up4(need_s + 4)),
+                    "tight_segments": (up4(need_l + 4), max(4, up4(need_s * 0.6) - 4))}[fit]
+    exp = ko.shard_route_static(desc, ids, offsets, w, batch, n_shards, emit_w, cap_l, cap_s)
+    assert bool(exp["flags"] & ko.FLAG_CAPACITY_OVERFLOW) == (fit != "roomy")
+
+    k = HipShardKernels()
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    got = k.route_static(desc, torch.from_numpy(ids).to(DEV), None if offsets is None else torch.from_numpy(offsets).to(DEV),
+                         None if w is None else torch.from_numpy(w).to(DEV), batch, n_shards, emit_w, cap_l, cap_s, err)
+    assert int(err.item()) == exp["flags"]
+    np.testing.assert_array_equal(got["counts"].cpu().numpy(), exp["counts"])
+    np.testing.assert_array_equal(got["packed"].cpu().numpy(), exp["packed"])
+    np.testing.assert_array_equal(got["seg_grow"].cpu().numpy(), exp["seg_grow"])
+    np.testing.assert_array_equal(got["bag_seg"].cpu().numpy(), exp["bag_seg"])
+
+    rows, wv, off_, stats = k.unpack_static(got["packed"], cap_l, cap_s, emit_w)
+    e_rows, e_w, e_off, e_stats = ko.shard_unpack_static(exp["packed"], cap_l, cap_s, emit_w)
+    np.testing.assert_array_equal(rows.cpu().numpy(), e_rows)
+    np.testing.assert_array_equal(off_.cpu().numpy(), e_off)
+    np.testing.assert_array_equal(stats.cpu().numpy(), e_stats)
+    if emit_w:
+        np.testing.assert_array_equal(wv.cpu().numpy().view(np.uint32), e_w.view(np.uint32))
+    if fit == "roomy":
+        # nothing dropped: the compact rows / weights / segment lengths are the exact form's
+        counts = exact["counts"]
+        words = int(counts[2].sum())
+        x_rows, x_w, x_off = ko.shard_unpack(exact["packed"][:words], counts[0], counts[1], emit_w)
+        n = len(x_rows)
+        np.testing.assert_array_equal(e_rows[:n], x_rows)
+        assert (e_rows[n:] == -1).all()
+        lens = np.diff(e_off)
+        np.testing.assert_array_equal(lens[lens > 0], np.diff(x_off)[np.diff(x_off) > 0])
+
+
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
 @pytest.mark.parametrize("dim", [128, 20])
 def test_combine_matches_oracle(dtype, dim):

@@ -17,15 +17,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind,weighted,world", [("sgd", "w", 2), ("adagrad", "w", 2), ("adagrad", "now", 2),
-                                                 ("sgd", "now", 3), ("adam", "w", 2), ("ftrl", "now", 2),
-                                                 ("adagrad", "wragged", 2), ("sgd", "nowragged", 2)])
-def test_sharded_embedding_matches_unsharded_oracle(kind, weighted, world):
+@pytest.mark.parametrize("kind,weighted,world,exchange", [
+    ("sgd", "w", 2, "exact"), ("adagrad", "w", 2, "exact"), ("adagrad", "now", 2, "exact"), ("sgd", "now", 3, "exact"),
+    ("adam", "w", 2, "exact"), ("ftrl", "now", 2, "exact"), ("adagrad", "wragged", 2, "exact"),
+    ("sgd", "nowragged", 2, "exact"),
+    # static-capacity exchange (no size ever reaches the host): sized automatically, from the TableConfig limits, and
+    # from a capacity the first steps overflow (ids dropped + flagged, limits learnt from the running statistics)
+    ("adagrad", "w", 2, "static"), ("sgd", "now", 3, "static"), ("adam", "w", 2, "static_cfg"),
+    ("adagrad", "w", 2, "static_tiny"), ("sgd", "now", 3, "static_tiny"), ("adagrad", "wragged", 2, "static")])
+def test_sharded_embedding_matches_unsharded_oracle(kind, weighted, world, exchange):
     # weighted: user weights on every feature; "now": none (mean / sqrtn scales are still folded in);
     # "...ragged": bags of varying length (some empty) given as Ragged values + row offsets
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "_sharded_worker.py"), kind, weighted]
+           os.path.join(ROOT, "tests", "_sharded_worker.py"), kind, weighted, exchange]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 0 and f"SHARDED_OK {kind}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

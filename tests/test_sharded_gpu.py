@@ -18,10 +18,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("kind", ["sgd", "adagrad", "adam"])
-def test_sharded_world2_on_hip_matches_single_gpu_layer(kind):
+@pytest.mark.parametrize("kind,exchange", [("sgd", "exact"), ("adagrad", "exact"), ("adam", "exact"),
+                                           ("sgd", "static"), ("adagrad", "static")])
+def test_sharded_world2_on_hip_matches_single_gpu_layer(kind, exchange):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "_sharded_hip_worker.py"), kind]
+           os.path.join(ROOT, "tests", "_sharded_hip_worker.py"), kind, exchange]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and f"SHARDED_HIP_OK {kind}" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
