@@ -395,6 +395,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     g_xl = torch.full((b_local, (a.tables + 1) * a.dim), scale, dtype=torch.bfloat16, device=dev)
     n_inter = (a.tables + 1) * a.tables // 2
     g_inter = torch.full((b_local, n_inter), 0.1 * scale, dtype=torch.bfloat16, device=dev)
+    dp = world > 1 or (a.force_sharded and a.rccl_self)   # dense gradients go through the all-reduce
 
     def step():
         xl, inter = model(dense, pre if loader is None else next(loader))
@@ -406,18 +407,18 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
             from keras_rs_amd.optim import Adagrad   # torch.optim.Adagrad's arithmetic, one launch (krs_dense_adagrad)
 
             opt_box[0] = Adagrad(params, lr=0.0034, initial_accumulator_value=0.1)
-            if world > 1:
+            if dp:
                 # dense weights are data-parallel: from the next backward on, each gradient's all-reduce starts
                 # the moment autograd has produced it and overlaps the rest of the backward pass
                 from keras_rs_amd.dp import GradAllReduce
 
                 # (same communicator as the embedding's all-to-alls: RCCL runs them in issue order, no second
                 # communicator whose kernels could interleave differently on different ranks)
-                opt_box.append(GradAllReduce(params))
+                opt_box.append(GradAllReduce(params, run_at_world1=True))
                 for p in params:
                     opt_box[1].launch(p)
         opt = opt_box[0]
-        if world > 1:
+        if dp:
             opt_box[1].wait()
         opt.step()
         opt.zero_grad(set_to_none=True)

@@ -280,11 +280,13 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
 enum { KRS_GEMM_OPT_PIPELINE = 0 };
 int krs_gemm_set_option(int key, int value);
 
-/* Tuning switch of krs_embed_bag_fwd (process-wide; results never depend on it).
+/* Tuning switches of krs_embed_bag_fwd / krs_embed_bag_bwd_* (process-wide; results never depend on them).
  *   KRS_EMBED_OPT_HOT1: the pure row gather of one-hot bags -- bit 0: 16 instead of 8 row loads in
  *   flight per lane; bit 1: walk the lookups sample-major, so that a wave's stores cover contiguous
- *   bytes of the output slab (default 3, or the environment variable KRS_EMBED_HOT1 at first use). */
-enum { KRS_EMBED_OPT_HOT1 = 0 };
+ *   bytes of the output slab (default 3, or the environment variable KRS_EMBED_HOT1 at first use).
+ *   KRS_EMBED_OPT_APPLY: the per-segment kernel of the backward -- 0 = bag_apply_fast_kernel (batched metadata,
+ *   software-pipelined row / gradient loads; default), 1 = the round-1 kernel (kept for A/B). */
+enum { KRS_EMBED_OPT_HOT1 = 0, KRS_EMBED_OPT_APPLY = 1 };
 int krs_embed_set_option(int key, int value);
 
 /* Elementwise halves of FeatureCross for the host-composed path (arbitrary

@@ -29,6 +29,8 @@
 #include "krs_scan.h"
 
 namespace krs {
+// krs_embed_set_option(KRS_EMBED_OPT_APPLY, v): 0 = bag_apply_fast_kernel (default), 1 = bag_apply_kernel (A/B, fallback)
+int g_apply_variant = 0;
 namespace {
 
 constexpr uint32_t kInvalidKey = 0xffffffffu;
@@ -695,6 +697,285 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
   }  // segments of this group
 }
 
+// ---- the per-segment kernel, written for memory-level parallelism (round 3) ---------------------------------
+// bag_apply_kernel above is correct but compiles into a chain of dependent round trips: its run-time branches
+// (aligned / unaligned access forms, optional weights and bag scales, descriptors in LDS or in memory) sit
+// AROUND loads, and hipcc closes every such branch with `s_waitcnt vmcnt(0)` -- the ISA of the C3 instance had a
+// full drain between the table-row load, each accumulator load and each gradient row: seven to eight serial
+// round trips per segment, hidden only by occupancy (4.1 TB/s on the algorithmic bytes).  This kernel does the
+// same arithmetic in the same order with NO branch around a load:
+//   * every access is an under-aligned wide vector access (typedefs below: the HSA ABI runs the memory pipeline
+//     in unaligned-access mode, a `global_load_dwordx4` needs no 16-byte alignment), so there is one access form;
+//   * weights / bag scales / LDS descriptors are compile-time cases (the host picks the instance);
+//   * invalid or out-of-range work is CLAMPED to a valid address and masked at the store, never skipped;
+//   * the metadata of the group's kSegsPerGroup segments is fetched in two trips for all of them (bounds; key and
+//     the first two values), and the segments are software-pipelined: the table row, accumulator row and the
+//     first two gradient rows of segment i+1 are requested before segment i is consumed.
+// Per group that is 2 + 1 trips for four segments instead of ~8 each.  Segments longer than two lookups finish
+// in a loop of four gradient rows per trip.  Results are bit-identical to bag_apply_kernel (same fmaf chain in
+// ascending position, same row_update); that kernel stays for descriptor counts beyond the LDS cache.
+typedef u32x4 u32x4_ua __attribute__((aligned(2)));
+typedef u32x2 u32x2_ua __attribute__((aligned(2)));
+
+template <int W>
+struct RawRow {   // W dwords of a row piece, as loaded
+  uint32_t r[W];
+};
+// (table / slot pointers come out of descriptors, i.e. as generic pointers: accessed as such they become FLAT
+//  instructions, which count on the LDS counter too and make hipcc fence them against every ds_read -- the
+//  descriptors live in LDS -- so every access below goes through an explicit global-address-space pointer)
+#define KRS_AS1 __attribute__((address_space(1)))
+template <int W, bool NT>
+__device__ __forceinline__ RawRow<W> raw_load(const void* src) {
+  RawRow<W> o;
+  if constexpr (W == 2) {
+    const KRS_AS1 u32x2_ua* q = (const KRS_AS1 u32x2_ua*)src;
+    const u32x2 v = NT ? __builtin_nontemporal_load(q) : *q;
+    o.r[0] = v[0]; o.r[1] = v[1];
+  } else {
+#pragma unroll
+    for (int i = 0; i < W / 4; ++i) {
+      const KRS_AS1 u32x4_ua* q = (const KRS_AS1 u32x4_ua*)src + i;
+      const u32x4 v = NT ? __builtin_nontemporal_load(q) : *q;
+      o.r[4 * i] = v[0]; o.r[4 * i + 1] = v[1]; o.r[4 * i + 2] = v[2]; o.r[4 * i + 3] = v[3];
+    }
+  }
+  return o;
+}
+template <int W>
+__device__ __forceinline__ void raw_store_nt(void* dst, const RawRow<W>& o) {
+  if constexpr (W == 2) {
+    __builtin_nontemporal_store(u32x2{o.r[0], o.r[1]}, (KRS_AS1 u32x2_ua*)dst);
+  } else {
+#pragma unroll
+    for (int i = 0; i < W / 4; ++i)
+      __builtin_nontemporal_store(u32x4{o.r[4 * i], o.r[4 * i + 1], o.r[4 * i + 2], o.r[4 * i + 3]},
+                                  (KRS_AS1 u32x4_ua*)dst + i);
+  }
+}
+// N elements of type TT <-> fp32
+template <typename TT, int N>
+__device__ __forceinline__ void raw_to_f32(const RawRow<N * (int)sizeof(TT) / 4>& o, float (&f)[N]) {
+  if constexpr (sizeof(TT) == 4) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) f[k] = __uint_as_float(o.r[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+      f[2 * k] = __uint_as_float(o.r[k] << 16);
+      f[2 * k + 1] = __uint_as_float(o.r[k] & 0xffff0000u);
+    }
+  }
+}
+template <typename TT, int N>
+__device__ __forceinline__ RawRow<N * (int)sizeof(TT) / 4> f32_to_raw(const float (&f)[N]) {
+  RawRow<N * (int)sizeof(TT) / 4> o;
+  if constexpr (sizeof(TT) == 4) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) o.r[k] = __float_as_uint(f[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) o.r[k] = pack_bf16x2(f[2 * k], f[2 * k + 1]);
+  }
+  return o;
+}
+
+constexpr int kFastFirst = 2;   // gradient rows requested with the row itself
+constexpr int kFastMore = 4;    // ... and per trip of the remainder loop
+
+template <typename GT, typename TT, int LPR, int MODE, bool HAS_W, bool HAS_SCALE>
+__global__ __launch_bounds__(256) void bag_apply_fast_kernel(const ApplyParams p) {
+  constexpr int N = Piece<GT>::N;
+  constexpr int S = kSegsPerGroup;
+  constexpr int WT = N * (int)sizeof(TT) / 4;   // dwords of a lane's table piece
+  constexpr int WS = N;                         // ... of its fp32 slot piece
+  constexpr bool kFused = mode_is_fused(MODE);
+  constexpr int kSlots = mode_slots(MODE);
+  __shared__ int s_fcol[kMaxLdsDesc];
+  __shared__ int s_ftab[kMaxLdsDesc];
+  __shared__ krs_table s_tab[kMaxLdsDesc];
+  constexpr int GPB = 256 / LPR;
+  const uint32_t n_seg = *p.n_seg;
+  const int64_t u_base = (int64_t)blockIdx.x * (GPB * S);
+  if (u_base >= n_seg) return;
+  for (int f = threadIdx.x; f < p.n_feats; f += 256) {
+    s_fcol[f] = p.feats[f].out_col;
+    s_ftab[f] = p.feats[f].table;
+  }
+  if constexpr (MODE != kSparse)
+    for (int t = threadIdx.x; t < p.n_tables; t += 256) s_tab[t] = p.tables[t];
+  __syncthreads();
+
+  const int sub = threadIdx.x % LPR;
+  const int row_pieces = (int)(((int64_t)p.dim * sizeof(GT)) >> 4);
+  const bool col_live = sub < row_pieces;
+  const int csub = col_live ? sub : 0;
+  const char* grad = reinterpret_cast<const char*>(p.grad) + (int64_t)csub * 16;
+  const uint32_t batch = (uint32_t)p.batch;
+
+  // ---- trip 1: the bounds of the group's segments; trip 2: key and the first two values of each ----
+  int64_t s0[S], e0[S];
+  bool ok[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const int64_t u = u_base + (int64_t)i * GPB + threadIdx.x / LPR;
+    ok[i] = u < n_seg;
+    const int64_t uc = ok[i] ? u : (int64_t)n_seg - 1;
+    const bool has_next = uc + 1 < n_seg;
+    s0[i] = p.seg_start[uc];
+    const int64_t nx = p.seg_start[has_next ? uc + 1 : uc];
+    e0[i] = has_next ? nx : p.nnz;
+  }
+  uint32_t key[S];
+  uint64_t va[S][kFastFirst];
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    key[i] = p.keys[s0[i]];
+#pragma unroll
+    for (int q = 0; q < kFastFirst; ++q) va[i][q] = p.vals[min(s0[i] + q, e0[i] - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    // the trailing run of invalid keys (out-of-range ids; the padded tail of a static-capacity exchange, whose
+    // values were never written): nothing of it may become an address -- bag 0 / position 0 stand in
+    if (key[i] == kInvalidKey) {
+#pragma unroll
+      for (int q = 0; q < kFastFirst; ++q) va[i][q] = 0;
+    }
+    ok[i] = ok[i] && key[i] != kInvalidKey && e0[i] - s0[i] <= kLongSeg;
+  }
+
+  // what a segment has in flight
+  struct InFlight {
+    krs_table tb;
+    int64_t off, row;
+    RawRow<WT> w;
+    RawRow<WS> a, b;
+    float a_row;
+    u32x4 g[kFastFirst];
+    float c[kFastFirst];
+  };
+  auto grad_src = [&](uint32_t bag) {
+    const uint32_t f = bag / batch;
+    const uint32_t b = bag - f * batch;
+    return grad + ((int64_t)b * p.grad_ld + s_fcol[f]) * (int64_t)sizeof(GT);
+  };
+  auto coef_of = [&](uint64_t v) {
+    float c = 1.0f;
+    if constexpr (HAS_W) c = p.weights[(uint32_t)v];
+    if constexpr (HAS_SCALE) c *= p.bag_scale[(uint32_t)(v >> 32)];
+    return c;
+  };
+  auto issue = [&](int i, InFlight& x) {
+    x.tb = krs_table{};
+    x.off = 0;
+    x.row = 0;
+    if constexpr (MODE != kSparse) {
+      const uint32_t f0 = (uint32_t)(va[i][0] >> 32) / batch;
+      x.tb = s_tab[s_ftab[f0]];
+      // (a segment that is not this kernel's to finish still names a table: its row 0 stands in)
+      x.row = ok[i] ? (int64_t)key[i] - x.tb.row_base : 0;
+      x.off = x.row * p.dim + csub * N;
+      if constexpr (kFused) x.w = raw_load<WT, true>(reinterpret_cast<const TT*>(x.tb.weights) + x.off);
+      if constexpr (kSlots >= 1) x.a = raw_load<WS, true>(x.tb.slot + x.off);
+      if constexpr (kSlots == 2) x.b = raw_load<WS, true>(x.tb.slot + (int64_t)x.tb.vocab * p.dim + x.off);
+      if constexpr (MODE == kAdagradRow) x.a_row = *((const KRS_AS1 float*)x.tb.slot + x.row);
+    }
+#pragma unroll
+    for (int q = 0; q < kFastFirst; ++q) {
+      x.g[q] = *(const KRS_AS1 u32x4_ua*)grad_src((uint32_t)(va[i][q] >> 32));
+      x.c[q] = coef_of(va[i][q]);
+    }
+  };
+  auto consume = [&](int i, const InFlight& x) {
+    const int64_t u = u_base + (int64_t)i * GPB + threadIdx.x / LPR;
+    float acc[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kFastFirst; ++q) {
+      if (s0[i] + q < e0[i]) {
+        float gv[N];
+        Piece<GT>::unpack(make_uint4(x.g[q].x, x.g[q].y, x.g[q].z, x.g[q].w), gv);
+#pragma unroll
+        for (int k = 0; k < N; ++k) acc[k] = fmaf(x.c[q], gv[k], acc[k]);
+      }
+    }
+    // the rest of a longer segment, four gradient rows per trip (positions clamped, contributions masked)
+    if (ok[i]) {
+      for (int64_t j0 = s0[i] + kFastFirst; j0 < e0[i]; j0 += kFastMore) {
+        uint64_t vv[kFastMore];
+#pragma unroll
+        for (int q = 0; q < kFastMore; ++q) vv[q] = p.vals[min(j0 + q, e0[i] - 1)];
+        u32x4 raw[kFastMore];
+        float cf[kFastMore];
+#pragma unroll
+        for (int q = 0; q < kFastMore; ++q) {
+          raw[q] = *(const KRS_AS1 u32x4_ua*)grad_src((uint32_t)(vv[q] >> 32));
+          cf[q] = coef_of(vv[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < kFastMore; ++q) {
+          if (j0 + q < e0[i]) {
+            float gv[N];
+            Piece<GT>::unpack(make_uint4(raw[q].x, raw[q].y, raw[q].z, raw[q].w), gv);
+#pragma unroll
+            for (int k = 0; k < N; ++k) acc[k] = fmaf(cf[q], gv[k], acc[k]);
+          }
+        }
+      }
+    }
+    if constexpr (MODE == kAdagradRow) {
+      float ss = 0.0f;
+      if (col_live) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) ss = fmaf(acc[k], acc[k], ss);
+      }
+      ss = row_sumsq<LPR>(ss);      // every lane of the group takes part, whatever `ok` says
+      const float a_new = x.a_row + ss / (float)p.dim;
+      if (ok[i] && col_live) {
+        float wv[N];
+        raw_to_f32<TT, N>(x.w, wv);
+        const float inv = a_new > 0.0f ? x.tb.lr / sqrtf(a_new) : 0.0f;  // untouched accumulator + zero gradient: leave the row
+#pragma unroll
+        for (int k = 0; k < N; ++k) wv[k] = wv[k] - inv * acc[k];
+        raw_store_nt<WT>(reinterpret_cast<TT*>(x.tb.weights) + x.off, f32_to_raw<TT, N>(wv));
+        if (sub == 0) *((KRS_AS1 float*)x.tb.slot + x.row) = a_new;
+      }
+      return;
+    }
+    if (!ok[i] || !col_live) return;
+    if constexpr (MODE == kSparse) {
+      if (sub == 0) p.unique_rows[u] = (int64_t)key[i];
+      float* dst = p.row_grads + u * p.dim + sub * N;
+#pragma unroll
+      for (int k = 0; k < N; ++k) dst[k] = acc[k];
+    } else if constexpr (MODE == kDense) {
+      raw_store_nt<WS>(reinterpret_cast<float*>(x.tb.weights) + x.off, f32_to_raw<float, N>(acc));
+    } else {
+      float wv[N], av[N], bv[N];
+      raw_to_f32<TT, N>(x.w, wv);
+#pragma unroll
+      for (int k = 0; k < N; ++k) { av[k] = 0.0f; bv[k] = 0.0f; }
+      if constexpr (kSlots >= 1) raw_to_f32<float, N>(x.a, av);
+      if constexpr (kSlots == 2) raw_to_f32<float, N>(x.b, bv);
+#pragma unroll
+      for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], acc[k], x.tb.lr, p.hyper);
+      if constexpr (kSlots >= 1) raw_store_nt<WS>(x.tb.slot + x.off, f32_to_raw<float, N>(av));
+      if constexpr (kSlots == 2) raw_store_nt<WS>(x.tb.slot + (int64_t)x.tb.vocab * p.dim + x.off, f32_to_raw<float, N>(bv));
+      raw_store_nt<WT>(reinterpret_cast<TT*>(x.tb.weights) + x.off, f32_to_raw<TT, N>(wv));
+    }
+  };
+
+  InFlight fl[2];
+  issue(0, fl[0]);
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    if (i + 1 < S) issue(i + 1, fl[(i + 1) & 1]);
+    consume(i, fl[i & 1]);
+  }
+}
+
 // Writes one finished row (summed gradient `tot` of segment u, this lane's N columns): dense
 // gradient row, compact (unique_rows, grads) entry, or the fused optimizer update in place.
 // Row-wise Adagrad: EVERY lane of the row's group calls (live = the lane holds columns of the row).
@@ -868,6 +1149,9 @@ __global__ __launch_bounds__(256) void bag_apply_finish_kernel(const ApplyParams
     const MultiSeg ms = p.multi_list[mi];
     const int64_t s0 = p.seg_start[ms.seg];
     const uint32_t key = p.keys[s0];
+    // a trailing run of invalid keys longer than kChunk (out-of-range ids, the padded tail of a static-capacity
+    // exchange) is listed here too: bag_apply_long_kernel wrote no partial rows for it and it names no table row
+    if (key == kInvalidKey) continue;
     float tot[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) tot[k] = 0.0f;
@@ -1050,8 +1334,14 @@ int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
   const int64_t groups = p.nnz;  // upper bound of the segment count (device-side n_seg trims it)
   const int64_t blocks = ceil_div(groups, (256 / lpr) * kSegsPerGroup);
   if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_bwd: grid too large");
+  const bool fast = p.n_feats <= kMaxLdsDesc && p.n_tables <= kMaxLdsDesc && g_apply_variant == 0;
+#define KRS_LAUNCH_FAST(L, W, SC) \
+  hipLaunchKernelGGL((bag_apply_fast_kernel<GT, TT, L, MODE, W, SC>), dim3((unsigned)blocks), dim3(256), 0, st, p)
 #define KRS_LAUNCH_APPLY(L)                                                                             \
-  if (p.weights)                                                                                        \
+  if (fast) {                                                                                           \
+    if (p.weights) { if (p.bag_scale) KRS_LAUNCH_FAST(L, true, true); else KRS_LAUNCH_FAST(L, true, false); }   \
+    else { if (p.bag_scale) KRS_LAUNCH_FAST(L, false, true); else KRS_LAUNCH_FAST(L, false, false); }           \
+  } else if (p.weights)                                                                                 \
     hipLaunchKernelGGL((bag_apply_kernel<GT, TT, L, MODE, true>), dim3((unsigned)blocks), dim3(256), 0, st, p); \
   else                                                                                                  \
     hipLaunchKernelGGL((bag_apply_kernel<GT, TT, L, MODE, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
@@ -1060,6 +1350,7 @@ int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
   else if (lpr == 32) { KRS_LAUNCH_APPLY(32) }
   else { KRS_LAUNCH_APPLY(64) }
 #undef KRS_LAUNCH_APPLY
+#undef KRS_LAUNCH_FAST
   KRS_CHECK_LAUNCH("bag_apply_kernel");
   // hot rows: upper bound of the item count is nnz / kLongSeg + nnz / kChunk; surplus workgroups leave at once
   const int64_t max_long = p.nnz / kLongSeg;

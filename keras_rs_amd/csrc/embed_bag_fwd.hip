@@ -605,7 +605,14 @@ int dispatch_lpr(const EmbedFwdParams& p, int row_pieces, bool one_hot, bool str
 }  // namespace
 }  // namespace krs
 
+namespace krs { extern int g_apply_variant; }   // embed_bag_bwd.hip
+
 extern "C" int krs_embed_set_option(int key, int value) {
+  if (key == KRS_EMBED_OPT_APPLY) {
+    KRS_REQUIRE(value == 0 || value == 1, "krs_embed_set_option: apply variant must be 0 or 1");
+    krs::g_apply_variant = value;
+    return KRS_OK;
+  }
   if (key == KRS_EMBED_OPT_HOT1) {
     KRS_REQUIRE(value >= 0 && value <= 3, "krs_embed_set_option: one-hot gather variant must be 0..3");
     krs::g_hot1 = value;

@@ -16,15 +16,19 @@ import torch.distributed as dist
 
 
 class GradAllReduce:
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, average: bool = True,
+                 run_at_world1: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.average = average
+        # run_at_world1: issue the collectives on a one-rank communicator too (bench --rccl-self: the RCCL call path
+        # on a one-GPU box); otherwise a single rank has nothing to reduce
+        self._active = self.world > 1 or (run_at_world1 and dist.is_initialized())
         # RCCL averages inside the collective; gloo has no AVG, the division follows in wait()
-        self._avg_op = self.world > 1 and average and dist.get_backend(group) == "nccl"
+        self._avg_op = self._active and average and dist.get_backend(group) == "nccl"
         self._pending: list = []
         self._hooks = []
-        if self.world > 1:
+        if self._active:
             for p in params:
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self.launch))
@@ -32,7 +36,7 @@ class GradAllReduce:
     def launch(self, p: torch.nn.Parameter) -> None:
         """Starts the reduction of `p.grad` (what the hook does; callable directly for gradients that
         were produced before the hooks existed)."""
-        if self.world == 1 or p.grad is None:
+        if not self._active or p.grad is None:
             return
         op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
         self._pending.append((dist.all_reduce(p.grad, op=op, group=self.group, async_op=True), p))

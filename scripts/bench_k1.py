@@ -102,8 +102,14 @@ if not a.fmajor_out:
     fb.lrs = [0.0034] * a.tables
     grad = (torch.rand(a.batch, a.tables * a.dim, device=dev) * 1e-3).to(dt)
     nnz = ids.numel()
+    from keras_rs_amd import _lib as L
+    import ctypes as C
     t_plan = timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots))
     ws = fb.plan_backward(ids, a.batch, hots=hots)
-    t_ada = timeit(lambda: fb.backward_fused("adagrad", ws, grad, a.batch, nnz, hots=hots))
-    t_sgd = timeit(lambda: fb.backward_fused("sgd", ws, grad, a.batch, nnz, hots=hots))
-    print(json.dumps({"k2_plan_us": t_plan * 1e6, "k2_adagrad_us": t_ada * 1e6, "k2_sgd_us": t_sgd * 1e6}))
+    for variant in (0, 1, 0, 1):     # KRS_EMBED_OPT_APPLY: 0 = bag_apply_fast_kernel, 1 = the round-1 kernel
+        L.check(L.lib().krs_embed_set_option(C.c_int(1), C.c_int(variant)), "set_option")
+        t_ada = timeit(lambda: fb.backward_fused("adagrad", ws, grad, a.batch, nnz, hots=hots))
+        t_sgd = timeit(lambda: fb.backward_fused("sgd", ws, grad, a.batch, nnz, hots=hots))
+        print(json.dumps({"apply_variant": variant, "k2_plan_us": t_plan * 1e6, "k2_adagrad_us": t_ada * 1e6,
+                          "k2_sgd_us": t_sgd * 1e6}))
+    L.lib().krs_embed_set_option(C.c_int(1), C.c_int(0))

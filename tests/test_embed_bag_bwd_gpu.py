@@ -265,3 +265,121 @@ def test_hot_rows_take_the_workgroup_path(tdt, gdt, dim, batch):
         ko.apply_optimizer(exp_tables[t], exp_slots[t], s["de"][t], None, fb.lrs[t], "adam", hyper)
         np.testing.assert_allclose(to_f32(to_np(s["tables"][t])), to_f32(exp_tables[t]),
                                    rtol=2 ** -7 if tdt == "bf16" else 1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "adam", "adagrad_rowwise"])
+@pytest.mark.parametrize("tdt,gdt,dim,misaligned", [("bf16", "bf16", 128, False), ("bf16", "bf16", 128, True),
+                                                    ("f32", "f32", 64, True), ("bf16", "f32", 32, True),
+                                                    ("f32", "bf16", 24, False)])
+def test_pipelined_apply_kernel_equals_round1_kernel_bit_for_bit(kind, tdt, gdt, dim, misaligned):
+    """bag_apply_fast_kernel (batched metadata, pipelined row / gradient loads, one under-aligned wide access form)
+    against bag_apply_kernel (KRS_EMBED_OPT_APPLY = 1): same fmaf chain, same row update -> identical bits, with
+    table / slot base pointers that are NOT 16-byte aligned too (the memory pipeline runs in unaligned-access mode;
+    the fast kernel has no aligned / unaligned switch), segments of 1 .. ~40 lookups, weights and bag scales."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    batch, n_tables = 257, 3
+    vocabs = [37, 900, 5]
+    hots = [3, 9, 2, 1]
+    tix = [0, 1, 2, 1]
+
+    def alloc(shape, dt, fill=None):
+        # a view that starts one element into a larger buffer when `misaligned` (2 or 4 bytes off 16-byte alignment)
+        n = int(np.prod(shape))
+        big = torch.empty(n + 8, dtype=dt, device=dev)
+        v = big[1:1 + n].view(shape) if misaligned else big[:n].view(shape)
+        if fill is not None:
+            v.copy_(fill)
+        return v
+
+    def build():
+        g = np.random.default_rng(5)
+        tables = [alloc((v, dim), TORCH_DT[tdt], torch.from_numpy(g.uniform(-1, 1, (v, dim)).astype(np.float32)).to(dev))
+                  for v in vocabs]
+        planes = {"sgd": None, "adagrad": 1, "adam": 2, "adagrad_rowwise": 0}[kind]
+        if planes is None:
+            slots = [None] * n_tables
+        elif planes == 0:
+            slots = [alloc((v,), torch.float32, torch.full((v,), 0.1, device=dev)) for v in vocabs]
+        elif planes == 1:
+            slots = [alloc((v, dim), torch.float32, torch.full((v, dim), 0.1, device=dev)) for v in vocabs]
+        else:
+            slots = [alloc((2, v, dim), torch.float32, torch.zeros((2, v, dim), device=dev)) for v in vocabs]
+        fb = FusedBags(tables, [(tix[f], ["sum", "mean", "sqrtn", "sum"][f], 3 + f * dim) for f in range(4)],
+                       slots=slots, lrs=[0.01, 0.02, 0.03])
+        return tables, slots, fb
+
+    ids = torch.from_numpy(np.concatenate([rng.integers(0, vocabs[tix[f]], batch * hots[f]) for f in range(4)]
+                                          ).astype(np.int32)).to(dev)
+    w = torch.from_numpy(rng.uniform(0.1, 1, ids.numel()).astype(np.float32)).to(dev)
+    cols = 3 + 4 * dim + 1
+    grad = torch.from_numpy(rng.uniform(-1, 1, (batch, cols)).astype(np.float32)).to(TORCH_DT[gdt]).to(dev)
+    res = []
+    try:
+        for variant in (0, 1):
+            L.check(L.lib().krs_embed_set_option(C.c_int(1), C.c_int(variant)), "krs_embed_set_option")
+            tables, slots, fb = build()
+            out = torch.empty((batch, cols), dtype=TORCH_DT[tdt], device=dev)
+            _, scale = fb.forward(ids, batch, hots=hots, weights=w, out=out, want_scale=True)
+            ws = fb.plan_backward(ids, batch, hots=hots)
+            hyper = (0.9, 0.999, 1e-7, 0.3) if kind == "adam" else None
+            fb.backward_fused(kind, ws, grad, batch, ids.numel(), hots=hots, weights=w, bag_scale=scale, hyper=hyper)
+            torch.cuda.synchronize()
+            res.append(([t.clone() for t in tables], [None if x is None else x.clone() for x in slots]))
+    finally:
+        L.lib().krs_embed_set_option(C.c_int(1), C.c_int(0))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a is None and b is None) or torch.equal(a, b)
+
+
+@pytest.mark.parametrize("csr", [False, True])
+def test_thousands_of_out_of_range_ids_are_dropped(csr):
+    """A trailing run of invalid keys longer than one hot-row chunk (2048 lookups): it is listed as a multi-chunk
+    segment and must be skipped by every apply kernel (it used to reach bag_apply_finish_kernel, which named a table
+    row from the invalid key).  CSR form with lookups behind the last bag as well (the padded tail of a
+    static-capacity exchange: positions no bag covers, whose plan values are never written)."""
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    V, D, B, hot = 300, 64, 2048, 4
+    table = torch.from_numpy(rng.uniform(-1, 1, (V, D)).astype(np.float32)).to(dev)
+    slot = torch.full((V, D), 0.1, device=dev)
+    ids_np = rng.integers(0, V, B * hot).astype(np.int32)
+    bad = rng.permutation(B * hot)[:5000]
+    ids_np[bad] = -1 - (bad % 7)                        # 5000 out-of-range ids: one invalid run of > 2 chunks
+    grad = torch.from_numpy(rng.uniform(-1, 1, (B, D)).astype(np.float32)).to(dev)
+    fb = FusedBags([table], [(0, "sum", 0)], slots=[slot], lrs=[0.05])
+    if csr:
+        pad = np.full(3000, -1, np.int32)               # behind the last bag
+        ids = torch.from_numpy(np.concatenate([ids_np, pad])).to(dev)
+        offsets = torch.arange(0, B * hot + 1, hot, dtype=torch.int32, device=dev)
+        ws = fb.plan_backward(ids, B, offsets=offsets)
+        fb.backward_fused("adagrad", ws, grad, B, ids.numel())
+    else:
+        ids = torch.from_numpy(ids_np).to(dev)
+        ws = fb.plan_backward(ids, B, hots=[hot])
+        fb.backward_fused("adagrad", ws, grad, B, ids.numel(), hots=[hot])
+    torch.cuda.synchronize()
+    # oracle: the same bags with the invalid lookups removed (weight 0 contributes nothing; dense gradient + Adagrad)
+    w = (ids_np >= 0).astype(np.float32)
+    safe = np.where(ids_np >= 0, ids_np, 0).astype(np.int32)
+    dense = np.zeros((V, D), np.float32)
+    f = ko.make_features([0], ["sum"], [0], hots=[hot], batch=B)
+    ko.embed_bag_bwd_dense(ko.make_tables([dense]), f, safe, None, w, None, grad.cpu().numpy(), B, D)
+    exp_t = rng.uniform(0, 0, (V, D)).astype(np.float32)  # placeholder, replaced below
+    rng2 = np.random.default_rng(3)
+    exp_t = rng2.uniform(-1, 1, (V, D)).astype(np.float32)
+    acc = np.full((V, D), 0.1, np.float32)
+    touched = np.zeros(V, np.uint8)
+    touched[ids_np[ids_np >= 0]] = 1
+    ko.apply_optimizer(exp_t, acc, dense, touched, 0.05, "adagrad")
+    np.testing.assert_allclose(table.cpu().numpy(), exp_t, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(slot.cpu().numpy(), acc, rtol=1e-5, atol=1e-6)
