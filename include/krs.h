@@ -149,6 +149,19 @@ int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature* feats, in
                            void* workspace, size_t workspace_bytes,
                            int* err_flag, void* stream);
 
+/* The same plan for DENSE bags (no offsets) when the caller also holds the descriptors on the HOST
+ * (tables_host / feats_host: host copies of the device arrays).  When the features of every table are
+ * neighbours and tables (and their row bases) ascend with the features, each table's lookups are one
+ * contiguous run and the sort runs per table on the id alone (fewer passes, 8-byte intermediate pairs);
+ * any other layout takes the global sort of krs_embed_bag_bwd_plan.  The workspace it leaves is
+ * consumed by the same apply calls, with one difference: out-of-range ids end their TABLE'S run
+ * instead of the whole array -- which krs_embed_bag_bwd_dense and the fused forms skip wherever they
+ * are; krs_embed_bag_bwd_sparse (output indexed by segment) needs the plan of krs_embed_bag_bwd_plan. */
+int krs_embed_bag_bwd_plan_tables(const krs_table* tables, const krs_table* tables_host, int n_tables,
+                                  const krs_feature* feats, const krs_feature* feats_host, int n_feats,
+                                  const void* ids, int id_type, int batch, int64_t nnz, int64_t total_rows,
+                                  void* workspace, size_t workspace_bytes, int* err_flag, void* stream);
+
 /* Dense parity form: grad_tables[t].weights is the [vocab, dim] fp32 gradient
  * buffer of table t (krs_table array in device memory, same indexing and
  * row_base as `tables`).  Rows that are touched are OVERWRITTEN with their sum;
@@ -285,8 +298,10 @@ int krs_gemm_set_option(int key, int value);
  *   flight per lane; bit 1: walk the lookups sample-major, so that a wave's stores cover contiguous
  *   bytes of the output slab (default 3, or the environment variable KRS_EMBED_HOT1 at first use).
  *   KRS_EMBED_OPT_APPLY: the per-segment kernel of the backward -- 0 = bag_apply_fast_kernel (batched metadata,
- *   software-pipelined row / gradient loads; default), 1 = the round-1 kernel (kept for A/B). */
-enum { KRS_EMBED_OPT_HOT1 = 0, KRS_EMBED_OPT_APPLY = 1 };
+ *   software-pipelined row / gradient loads; default), 1 = the round-1 kernel (kept for A/B).
+ *   KRS_EMBED_OPT_PLAN: krs_embed_bag_bwd_plan_tables -- 0 = table-segmented sort where the layout allows it
+ *   (default), 1 = always the global sort (A/B). */
+enum { KRS_EMBED_OPT_HOT1 = 0, KRS_EMBED_OPT_APPLY = 1, KRS_EMBED_OPT_PLAN = 2 };
 int krs_embed_set_option(int key, int value);
 
 /* Elementwise halves of FeatureCross for the host-composed path (arbitrary

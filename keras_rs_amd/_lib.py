@@ -61,6 +61,7 @@ SYMBOLS = [
     "krs_embed_bag_fwd",
     "krs_embed_bag_bwd_workspace_bytes",
     "krs_embed_bag_bwd_plan",
+    "krs_embed_bag_bwd_plan_tables",
     "krs_embed_bag_bwd_dense",
     "krs_embed_bag_bwd_fused_sgd",
     "krs_embed_bag_bwd_fused_adagrad",

@@ -31,6 +31,8 @@
 namespace krs {
 // krs_embed_set_option(KRS_EMBED_OPT_APPLY, v): 0 = bag_apply_fast_kernel (default), 1 = bag_apply_kernel (A/B, fallback)
 int g_apply_variant = 0;
+// krs_embed_set_option(KRS_EMBED_OPT_PLAN, v): 0 = table-segmented sort where the layout allows it (default), 1 = always the global sort
+int g_plan_variant = 0;
 namespace {
 
 constexpr uint32_t kInvalidKey = 0xffffffffu;
@@ -80,6 +82,7 @@ constexpr int kTile = 4096, kMaxBits = 10, kMaxBins = 1 << kMaxBits;
 constexpr int kHistThreads = 256, kHistItems = kTile / kHistThreads;
 constexpr int kThreads = 512, kWaves = kThreads / 64, kItems = kTile / kThreads;   // scatter: 8 waves x 512 lookups
 constexpr int kGenFeats = 256;   // features whose descriptors the generating pass caches in LDS
+constexpr int kMaxProb = 128;    // tables (problems) of the table-segmented sort
 
 struct Gen {   // key generation for dense bags (first pass)
   const krs_table* tables;
@@ -288,9 +291,266 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const Pass p) {
   (void)bad;   // the histogram pass of the same data reports out-of-range ids
 }
 
+// ---- the same sort, SEGMENTED BY TABLE (round 3) ------------------------------------------------------------
+// Dense bags arrive feature-major, so the lookups of one table already form ONE contiguous run of positions (when
+// the features of a table are neighbours and tables ascend with the features -- what DistributedEmbedding builds).
+// Sorting by the global row then needs no pass over the table bits: every table's run is an independent PROBLEM,
+// sorted in place by the id alone -- ceil(log2(max vocab + 1)) bits, 20 at C3 = TWO passes instead of three -- and
+// the problems' sorted runs, one after the other, are exactly the global order.  Tiles never straddle problems
+// (a problem's last tile may be partial); the count matrix is laid out [problem][digit][tile of the problem], so
+// ONE exclusive scan over it still yields every tile's output offsets (a problem's lookups stay inside its run).
+// Intermediate passes carry (local key, position) = 8 bytes per lookup instead of (key, bag << 32 | position) = 12;
+// the LAST pass writes what the apply kernels read: the global key (row_base + id; all ones for an invalid id) and
+// the 64-bit value, whose bag is recomputed from the position (feature constants in LDS, as the first pass does).
+// Per lookup 40 bytes move instead of 76.  Out-of-range ids sort to the END OF THEIR TABLE'S RUN (sentinel = all
+// ones in the key bits), not to the end of the array: the apply kernels skip invalid segments wherever they are;
+// the compact (sparse) form, whose output is indexed by segment, keeps the global sort.
+struct Seg {
+  int n;                                  // problems
+  uint32_t lookup_start[kMaxProb + 1];    // first lookup position of problem i; [n] = nnz
+  uint32_t tile_start[kMaxProb + 1];      // first tile of problem i; [n] = tiles in all
+  uint32_t row_base[kMaxProb];            // global row of the table's row 0
+};
+struct SegPass {
+  const uint32_t* keys_in;     // FIRST pass: null (keys come from the ids)
+  const uint32_t* pos_in;
+  uint32_t* keys_out;          // LAST pass: global keys
+  uint32_t* pos_out;           // intermediate passes
+  uint64_t* vals_out;          // LAST pass
+  int32_t* counts;
+  int64_t nnz;
+  int shift, bits, key_bits;
+  Gen gen;
+  Seg seg;
+};
+__device__ __forceinline__ int seg_problem(const Seg& sg, uint32_t tile) {
+  int lo = 0, hi = sg.n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (sg.tile_start[mid] <= tile) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ void load_gen_seg(const SegPass& p, GenLds& g, int n_threads) {
+  for (int i = threadIdx.x; i <= p.gen.n_feats; i += n_threads) {
+    if (i < p.gen.n_feats) {
+      const krs_feature ft = p.gen.feats[i];
+      const krs_table tb = p.gen.tables[ft.table];
+      g.base[i] = (uint32_t)ft.ids_base;
+      g.hot[i] = (uint32_t)ft.hot;
+      g.row_base[i] = (uint32_t)tb.row_base;
+      g.vocab[i] = (uint32_t)tb.vocab;
+    } else {
+      g.base[i] = (uint32_t)p.nnz;
+    }
+  }
+}
+__device__ __forceinline__ int gen_feature(const GenLds& g, int n_feats, uint32_t q) {
+  int lo = 0, hi = n_feats;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (g.base[mid] <= q) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// local key of lookup position q: its id, or all ones in the key bits when the id is out of range
+__device__ __forceinline__ uint32_t seg_local_key(const SegPass& p, const GenLds& g, uint32_t q, bool& bad) {
+  const int f = gen_feature(g, p.gen.n_feats, q);
+  const int64_t id = ld_index(p.gen.ids, p.gen.id64, q);
+  if (id >= 0 && id < (int64_t)g.vocab[f]) return (uint32_t)id;
+  bad = true;
+  return (1u << p.key_bits) - 1u;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kHistThreads) void hist_seg_kernel(const SegPass p) {
+  __shared__ int h[kMaxBins];
+  __shared__ GenLds g;
+  const int bins = 1 << p.bits;
+  for (int i = threadIdx.x; i < bins; i += kHistThreads) h[i] = 0;
+  if constexpr (FIRST) load_gen_seg(p, g, kHistThreads);
+  __syncthreads();
+  const int pr = seg_problem(p.seg, blockIdx.x);
+  const uint32_t tl = blockIdx.x - p.seg.tile_start[pr], nt = p.seg.tile_start[pr + 1] - p.seg.tile_start[pr];
+  const int64_t base = (int64_t)p.seg.lookup_start[pr] + (int64_t)tl * kTile;
+  const int64_t end = min<int64_t>(base + kTile, p.seg.lookup_start[pr + 1]);
+  bool bad = false;
+  uint32_t key[kHistItems];
+  if constexpr (FIRST) {
+    int64_t idv[kHistItems];
+#pragma unroll
+    for (int it = 0; it < kHistItems; ++it)
+      idv[it] = ld_index(p.gen.ids, p.gen.id64, min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1));
+#pragma unroll
+    for (int it = 0; it < kHistItems; ++it) {
+      const int64_t q = min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1);
+      const int f = gen_feature(g, p.gen.n_feats, (uint32_t)q);
+      const bool valid = idv[it] >= 0 && idv[it] < (int64_t)g.vocab[f];
+      key[it] = valid ? (uint32_t)idv[it] : (1u << p.key_bits) - 1u;
+      bad = bad || (!valid && base + it * kHistThreads + threadIdx.x < end);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < kHistItems; ++it)
+      key[it] = p.keys_in[min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1)];
+  }
+#pragma unroll
+  for (int it = 0; it < kHistItems; ++it)
+    if (base + it * kHistThreads + threadIdx.x < end) atomicAdd(&h[(key[it] >> p.shift) & (bins - 1)], 1);
+  if constexpr (FIRST)
+    if (bad && p.gen.err_flag) atomicOr(p.gen.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
+  __syncthreads();
+  int32_t* dst = p.counts + (int64_t)bins * p.seg.tile_start[pr];
+  for (int i = threadIdx.x; i < bins; i += kHistThreads) dst[(int64_t)i * nt + tl] = h[i];
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kThreads) void scatter_seg_kernel(const SegPass p) {
+  __shared__ uint16_t cnt[kWaves][kMaxBins];
+  __shared__ uint16_t tile_excl[kMaxBins];
+  __shared__ int gbase[kMaxBins];
+  __shared__ uint32_t skey[kTile];
+  __shared__ uint32_t spos[kTile];
+  __shared__ int wtot[kWaves];
+  __shared__ GenLds g;
+  const int bins = 1 << p.bits;
+  for (int i = threadIdx.x; i < kWaves * kMaxBins; i += kThreads) (&cnt[0][0])[i] = 0;
+  if constexpr (FIRST || LAST) load_gen_seg(p, g, kThreads);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pr = seg_problem(p.seg, blockIdx.x);
+  const uint32_t tl = blockIdx.x - p.seg.tile_start[pr], nt = p.seg.tile_start[pr + 1] - p.seg.tile_start[pr];
+  const int64_t tile0 = (int64_t)p.seg.lookup_start[pr] + (int64_t)tl * kTile;
+  const int64_t tile_end = min<int64_t>(tile0 + kTile, p.seg.lookup_start[pr + 1]);
+  const int64_t base = tile0 + (int64_t)wave * (kTile / kWaves);
+  uint32_t key[kItems], pos[kItems];
+  int rank[kItems];
+  bool bad = false;
+  volatile uint16_t* mine = cnt[wave];
+  // all of the thread's keys are requested before the first is ranked (addresses clamped to the tile, dead slots
+  // masked afterwards): one exposed memory latency per tile instead of one per round of the ranking loop below,
+  // whose LDS counter updates form a dependent chain the loads could not be scheduled across
+  if constexpr (FIRST) {
+    int64_t idv[kItems];
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int64_t q = min<int64_t>(base + it * 64 + lane, tile_end - 1);
+      idv[it] = ld_index(p.gen.ids, p.gen.id64, q);
+    }
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int64_t q = min<int64_t>(base + it * 64 + lane, tile_end - 1);
+      const int f = gen_feature(g, p.gen.n_feats, (uint32_t)q);
+      const bool valid = idv[it] >= 0 && idv[it] < (int64_t)g.vocab[f];
+      key[it] = valid ? (uint32_t)idv[it] : (1u << p.key_bits) - 1u;
+      pos[it] = (uint32_t)q;
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+      const int64_t q = min<int64_t>(base + it * 64 + lane, tile_end - 1);
+      key[it] = p.keys_in[q];
+      pos[it] = p.pos_in[q];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int64_t q = base + it * 64 + lane;
+    const bool live = q < tile_end;
+    if (!live) { key[it] = 0xffffffffu; pos[it] = 0; }
+    const int d = (int)((key[it] >> p.shift) & (bins - 1));
+    unsigned long long peers = __ballot(live);
+    for (int b = 0; b < p.bits; ++b) {
+      const unsigned long long m = __ballot((d >> b) & 1);
+      peers &= ((d >> b) & 1) ? m : ~m;
+    }
+    int r = 0, c = 0;
+    if (live) {
+      r = __popcll(peers & ((1ULL << lane) - 1ULL));
+      const int leader = __ffsll((long long)peers) - 1;
+      if (lane == leader) {
+        c = mine[d];
+        mine[d] = (uint16_t)(c + __popcll(peers));
+      }
+      c = __shfl(c, leader, 64);
+    }
+    rank[it] = c + r;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  int tot[2], run = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = threadIdx.x * 2 + k;
+    tot[k] = 0;
+    if (i < bins)
+      for (int w = 0; w < kWaves; ++w) tot[k] += cnt[w][i];
+    run += tot[k];
+  }
+  int x = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wtot[wave] = x;
+  __syncthreads();
+  int excl = x - run;
+  for (int w = 0; w < wave; ++w) excl += wtot[w];
+  const int32_t* cbase = p.counts + (int64_t)bins * p.seg.tile_start[pr];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = threadIdx.x * 2 + k;
+    if (i < bins) {
+      tile_excl[i] = (uint16_t)excl;
+      gbase[i] = cbase[(int64_t)i * nt + tl];
+      int o = excl;
+      for (int w = 0; w < kWaves; ++w) {
+        const int t = cnt[w][i];
+        cnt[w][i] = (uint16_t)o;
+        o += t;
+      }
+      excl += tot[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int64_t q = base + it * 64 + lane;
+    if (q < tile_end) {
+      const int d = (int)((key[it] >> p.shift) & (bins - 1));
+      const int lp = cnt[wave][d] + rank[it];
+      skey[lp] = key[it];
+      spos[lp] = pos[it];
+    }
+  }
+  __syncthreads();
+  const int n_here = (int)(tile_end - tile0);
+  const uint32_t sentinel = (1u << p.key_bits) - 1u, rb = p.seg.row_base[pr];
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const int i = it * kThreads + threadIdx.x;
+    if (i < n_here) {
+      const uint32_t k = skey[i], q = spos[i];
+      const int d = (int)((k >> p.shift) & (bins - 1));
+      const int o = gbase[d] + (i - (int)tile_excl[d]);
+      if constexpr (LAST) {
+        const int f = gen_feature(g, p.gen.n_feats, q);
+        const uint32_t bag = (uint32_t)f * (uint32_t)p.gen.batch + (q - g.base[f]) / g.hot[f];
+        p.keys_out[o] = k == sentinel ? kInvalidKey : rb + k;
+        p.vals_out[o] = ((uint64_t)bag << 32) | (uint64_t)q;
+      } else {
+        p.keys_out[o] = k;
+        p.pos_out[o] = q;
+      }
+    }
+  }
+  (void)bad;
+}
+
 inline int n_passes(unsigned bits) { return (int)((bits + kMaxBits - 1) / kMaxBits); }
 inline size_t temp_bytes(int64_t nnz) {
-  const int64_t tiles = ceil_div(nnz > 0 ? nnz : 1, kTile);
+  const int64_t tiles = ceil_div(nnz > 0 ? nnz : 1, kTile) + kMaxProb;   // (every problem may end in a partial tile)
   const size_t counts = (size_t)kMaxBins * tiles * sizeof(int32_t);
   return align_up(counts, 256) + align_up(scan::workspace_bytes((int64_t)kMaxBins * tiles), 256) +
          align_up(scan::workspace_bytes(nnz), 256);
@@ -1439,10 +1699,87 @@ extern "C" size_t krs_embed_bag_bwd_workspace_bytes(int64_t nnz) {
   return plan_layout(nullptr, nnz, true).total_bytes;
 }
 
-extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature* feats, int n_feats,
-                                      const void* ids, int id_type, const void* offsets, int off_type,
-                                      int batch, int64_t nnz, int64_t total_rows, void* workspace,
-                                      size_t workspace_bytes, int* err_flag, void* stream) {
+// Table-segmented sort (rs::scatter_seg_kernel) when the host descriptors are given and the lookups are laid out for
+// it: dense bags, the features of a table neighbours, tables (and their row bases) ascending with the features.
+// Returns true when it has enqueued the sort; false = the caller runs the global sort.
+static bool plan_sort_by_table(const PlanLayout& l, const krs_table* tables, const krs_table* tables_host, int n_tables,
+                               const krs_feature* feats, const krs_feature* feats_host, int n_feats, const void* ids,
+                               int id_type, int batch, int64_t nnz, int* err_flag, hipStream_t st) {
+  if (!tables_host || !feats_host || n_feats > rs::kGenFeats || n_tables <= 0) return false;
+  rs::SegPass sp;
+  rs::Seg& sg = sp.seg;
+  sg.n = 0;
+  int64_t pos = 0, max_vocab = 0;
+  int prev_table = -1;
+  for (int f = 0; f < n_feats; ++f) {
+    const krs_feature& ft = feats_host[f];
+    if (ft.hot < 1 || ft.ids_base != pos || ft.table < prev_table || ft.table >= n_tables) return false;
+    if (ft.table != prev_table) {
+      if (sg.n == rs::kMaxProb) return false;
+      const krs_table& tb = tables_host[ft.table];
+      if (prev_table >= 0 && tb.row_base < tables_host[prev_table].row_base + tables_host[prev_table].vocab) return false;
+      sg.lookup_start[sg.n] = (uint32_t)pos;
+      sg.row_base[sg.n] = (uint32_t)tb.row_base;
+      max_vocab = std::max<int64_t>(max_vocab, tb.vocab);
+      ++sg.n;
+      prev_table = ft.table;
+    }
+    pos += (int64_t)batch * ft.hot;
+  }
+  if (pos != nnz || sg.n == 0) return false;
+  sg.lookup_start[sg.n] = (uint32_t)nnz;
+  uint32_t tiles = 0;
+  for (int i = 0; i < sg.n; ++i) {
+    sg.tile_start[i] = tiles;
+    tiles += (uint32_t)ceil_div((int64_t)sg.lookup_start[i + 1] - sg.lookup_start[i], rs::kTile);
+  }
+  sg.tile_start[sg.n] = tiles;
+  if (tiles == 0) return false;
+  // key = id, plus one pattern (all ones) for an out-of-range id
+  unsigned bits = 1;
+  while (bits < 32 && (1ULL << bits) <= (uint64_t)max_vocab) ++bits;
+  if (bits > 31) return false;
+  const int passes = rs::n_passes(bits);
+  char* tp = reinterpret_cast<char*>(l.temp);
+  int32_t* counts = reinterpret_cast<int32_t*>(tp);
+  tp += align_up((size_t)rs::kMaxBins * (ceil_div(nnz, rs::kTile) + rs::kMaxProb) * sizeof(int32_t), 256);
+  int32_t* sums = reinterpret_cast<int32_t*>(tp);
+  sp.counts = counts; sp.nnz = nnz; sp.key_bits = (int)bits;
+  sp.gen.tables = tables; sp.gen.feats = feats; sp.gen.n_feats = n_feats; sp.gen.ids = ids;
+  sp.gen.id64 = id_type == KRS_I64; sp.gen.batch = batch; sp.gen.err_flag = err_flag;
+  // intermediate (key, position) pairs ping-pong between I0 = (keys_in, vals_in as u32) and I1 = (keys_sorted,
+  // vals_sorted as u32); the LAST pass reads I0 and writes the final (keys_sorted, vals_sorted): the pass before it
+  // writes I0, the one before that I1, ...
+  uint32_t* k0 = l.keys_in; uint32_t* q0 = reinterpret_cast<uint32_t*>(l.vals_in);
+  uint32_t* k1 = l.keys_sorted; uint32_t* q1 = reinterpret_cast<uint32_t*>(l.vals_sorted);
+  unsigned done = 0;
+  for (int ps = 0; ps < passes; ++ps) {
+    const bool first = ps == 0, last = ps == passes - 1;
+    sp.bits = (int)((bits - done + (passes - ps) - 1) / (passes - ps));
+    sp.shift = (int)done;
+    const bool out_is_i0 = ((passes - 2 - ps) % 2) == 0;        // (meaningless for the last pass)
+    const bool in_is_i0 = ((passes - 1 - ps) % 2) == 0;         // the last pass reads I0
+    sp.keys_in = first ? nullptr : (in_is_i0 ? k0 : k1);
+    sp.pos_in = first ? nullptr : (in_is_i0 ? q0 : q1);
+    sp.keys_out = last ? l.keys_sorted : (out_is_i0 ? k0 : k1);
+    sp.pos_out = last ? nullptr : (out_is_i0 ? q0 : q1);
+    sp.vals_out = last ? l.vals_sorted : nullptr;
+    if (first) hipLaunchKernelGGL(rs::hist_seg_kernel<true>, dim3(tiles), dim3(rs::kHistThreads), 0, st, sp);
+    else hipLaunchKernelGGL(rs::hist_seg_kernel<false>, dim3(tiles), dim3(rs::kHistThreads), 0, st, sp);
+    scan::exclusive(counts, counts, (int64_t)(1 << sp.bits) * tiles, sums, nullptr, st);
+    if (first && last) hipLaunchKernelGGL((rs::scatter_seg_kernel<true, true>), dim3(tiles), dim3(rs::kThreads), 0, st, sp);
+    else if (first) hipLaunchKernelGGL((rs::scatter_seg_kernel<true, false>), dim3(tiles), dim3(rs::kThreads), 0, st, sp);
+    else if (last) hipLaunchKernelGGL((rs::scatter_seg_kernel<false, true>), dim3(tiles), dim3(rs::kThreads), 0, st, sp);
+    else hipLaunchKernelGGL((rs::scatter_seg_kernel<false, false>), dim3(tiles), dim3(rs::kThreads), 0, st, sp);
+    done += (unsigned)sp.bits;
+  }
+  return true;
+}
+
+static int plan_impl(const krs_table* tables, const krs_table* tables_host, int n_tables, const krs_feature* feats,
+                     const krs_feature* feats_host, int n_feats, const void* ids, int id_type, const void* offsets,
+                     int off_type, int batch, int64_t nnz, int64_t total_rows, void* workspace,
+                     size_t workspace_bytes, int* err_flag, void* stream) {
   KRS_REQUIRE(tables && feats && (ids || nnz == 0), "embed_bag_bwd_plan: null argument");
   KRS_REQUIRE(n_feats > 0 && batch > 0 && nnz >= 0, "embed_bag_bwd_plan: bad sizes");
   KRS_REQUIRE(total_rows > 0 && total_rows < 0xffffffffLL, "embed_bag_bwd_plan: total_rows must fit 32-bit keys");
@@ -1454,6 +1791,17 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
   if (workspace_bytes < l.total_bytes)
     return fail(KRS_ERR_WORKSPACE, "embed_bag_bwd_plan: workspace %zu < %zu bytes", workspace_bytes, l.total_bytes);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int n_tiles = (int)ceil_div(nnz, rs::kTile);
+  char* tp = reinterpret_cast<char*>(l.temp);
+  int32_t* counts = reinterpret_cast<int32_t*>(tp);
+  tp += align_up((size_t)rs::kMaxBins * (n_tiles + rs::kMaxProb) * sizeof(int32_t), 256);
+  int32_t* sums = reinterpret_cast<int32_t*>(tp);
+  tp += align_up(scan::workspace_bytes((int64_t)rs::kMaxBins * (n_tiles + rs::kMaxProb)), 256);
+  int32_t* sums2 = reinterpret_cast<int32_t*>(tp);
+  const bool by_table = offsets == nullptr && g_plan_variant == 0 &&
+                        plan_sort_by_table(l, tables, tables_host, n_tables, feats, feats_host, n_feats, ids, id_type,
+                                           batch, nnz, err_flag, st);
+  if (!by_table) {
   KeyParams kp;
   kp.tables = tables; kp.feats = feats; kp.n_feats = n_feats; kp.ids = ids; kp.id64 = id_type == KRS_I64;
   kp.offsets = offsets; kp.off64 = off_type == KRS_I64; kp.batch = batch; kp.keys = l.keys_in; kp.vals = l.vals_in;
@@ -1463,13 +1811,6 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
   unsigned bits = 1;
   while (bits < 32 && (1ULL << bits) <= (uint64_t)total_rows) ++bits;
   const int passes = rs::n_passes(bits);
-  const int n_tiles = (int)ceil_div(nnz, rs::kTile);
-  char* tp = reinterpret_cast<char*>(l.temp);
-  int32_t* counts = reinterpret_cast<int32_t*>(tp);
-  tp += align_up((size_t)rs::kMaxBins * n_tiles * sizeof(int32_t), 256);
-  int32_t* sums = reinterpret_cast<int32_t*>(tp);
-  tp += align_up(scan::workspace_bytes((int64_t)rs::kMaxBins * n_tiles), 256);
-  int32_t* sums2 = reinterpret_cast<int32_t*>(tp);
   // ping-pong between (keys_in, vals_in) and (keys_sorted, vals_sorted); the LAST pass must write the sorted pair
   // dense bags: keys are generated inside the first pass (feature constants cached in LDS)
   const bool gen = offsets == nullptr && n_feats <= rs::kGenFeats;
@@ -1508,6 +1849,7 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
     done += (unsigned)p.bits;
     to_sorted = !to_sorted;
   }
+  }
   KRS_CHECK_LAUNCH("embed_bag_bwd_plan: radix sort");
   // segment list: heads per block -> one-workgroup scan of the block counts -> head positions
   const unsigned nb = (unsigned)ceil_div(nnz, 256);
@@ -1522,6 +1864,23 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
                      l.multi_list);
   KRS_CHECK_LAUNCH("long_list_kernel");
   return KRS_OK;
+}
+
+extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature* feats, int n_feats,
+                                      const void* ids, int id_type, const void* offsets, int off_type,
+                                      int batch, int64_t nnz, int64_t total_rows, void* workspace,
+                                      size_t workspace_bytes, int* err_flag, void* stream) {
+  return plan_impl(tables, nullptr, 0, feats, nullptr, n_feats, ids, id_type, offsets, off_type, batch, nnz, total_rows,
+                   workspace, workspace_bytes, err_flag, stream);
+}
+
+extern "C" int krs_embed_bag_bwd_plan_tables(const krs_table* tables, const krs_table* tables_host, int n_tables,
+                                             const krs_feature* feats, const krs_feature* feats_host, int n_feats,
+                                             const void* ids, int id_type, int batch, int64_t nnz, int64_t total_rows,
+                                             void* workspace, size_t workspace_bytes, int* err_flag, void* stream) {
+  KRS_REQUIRE(tables_host && feats_host && n_tables > 0, "embed_bag_bwd_plan_tables: null host descriptors");
+  return plan_impl(tables, tables_host, n_tables, feats, feats_host, n_feats, ids, id_type, nullptr, KRS_I32, batch, nnz,
+                   total_rows, workspace, workspace_bytes, err_flag, stream);
 }
 
 extern "C" int krs_embed_bag_bwd_dense(const krs_table* grad_tables, int n_tables, const krs_feature* feats,

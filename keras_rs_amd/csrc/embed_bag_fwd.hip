@@ -605,12 +605,17 @@ int dispatch_lpr(const EmbedFwdParams& p, int row_pieces, bool one_hot, bool str
 }  // namespace
 }  // namespace krs
 
-namespace krs { extern int g_apply_variant; }   // embed_bag_bwd.hip
+namespace krs { extern int g_apply_variant, g_plan_variant; }   // embed_bag_bwd.hip
 
 extern "C" int krs_embed_set_option(int key, int value) {
   if (key == KRS_EMBED_OPT_APPLY) {
     KRS_REQUIRE(value == 0 || value == 1, "krs_embed_set_option: apply variant must be 0 or 1");
     krs::g_apply_variant = value;
+    return KRS_OK;
+  }
+  if (key == KRS_EMBED_OPT_PLAN) {
+    KRS_REQUIRE(value == 0 || value == 1, "krs_embed_set_option: plan variant must be 0 or 1");
+    krs::g_plan_variant = value;
     return KRS_OK;
   }
   if (key == KRS_EMBED_OPT_HOT1) {

@@ -46,6 +46,8 @@ class FusedBags:
         self._tab_key = None
         self._tab_dev = None
         self._feat_cache: dict = {}
+        self._feat_host: dict = {}
+        self._tab_host = None
 
     # ---- descriptors ------------------------------------------------------
     def table_desc(self, weights=None, slots=None) -> torch.Tensor:
@@ -69,7 +71,7 @@ class FusedBags:
                       self.row_bases[i], w.shape[0], self.lrs[i])
         dev = L.struct_to_device(arr, weights[0].device)
         if cacheable:
-            self._tab_key, self._tab_dev = key, dev
+            self._tab_key, self._tab_dev, self._tab_host = key, dev, arr
         return dev
 
     def feature_desc(self, batch: int, hots: Sequence[int] | None, device) -> torch.Tensor:
@@ -85,6 +87,7 @@ class FusedBags:
                 base += batch * hot
             dev = L.struct_to_device(arr, device)
             self._feat_cache[key] = dev
+            self._feat_host[key] = arr
         return dev
 
     # ---- K1 ---------------------------------------------------------------
@@ -122,14 +125,28 @@ class FusedBags:
 
     # ---- K2 ---------------------------------------------------------------
     def plan_backward(self, ids: torch.Tensor, batch: int, hots: Sequence[int] | None = None,
-                      offsets: torch.Tensor | None = None, err_flag: torch.Tensor | None = None):
-        """Sorts the lookups by global row (krs_embed_bag_bwd_plan).  Returns the opaque
-        workspace tensor the apply calls consume; depends only on the ids, not on gradients."""
+                      offsets: torch.Tensor | None = None, err_flag: torch.Tensor | None = None,
+                      global_order: bool = False):
+        """Sorts the lookups by global row (krs_embed_bag_bwd_plan / _plan_tables).  Returns the opaque
+        workspace tensor the apply calls consume; depends only on the ids, not on gradients.
+        global_order: out-of-range ids must form ONE trailing run (what backward_sparse needs); otherwise dense
+        bags take the table-segmented sort, which leaves them at the end of their table's run."""
         L.require_device(ids, "ids")
         nnz = ids.numel()
         nbytes = L.lib().krs_embed_bag_bwd_workspace_bytes(C.c_int64(nnz))
         ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=ids.device)
         tdesc, fdesc = self.table_desc(), self.feature_desc(batch, hots, ids.device)
+        if hots is not None and not global_order:
+            th = self._tab_host
+            fh = self._feat_host[(batch, tuple(hots), str(ids.device))]
+            with probe.span("k2_plan"):
+                rc = L.lib().krs_embed_bag_bwd_plan_tables(
+                    L.ptr(tdesc), th.ctypes.data_as(C.c_void_p), C.c_int(len(th)),
+                    L.ptr(fdesc), fh.ctypes.data_as(C.c_void_p), C.c_int(len(self.features)),
+                    L.ptr(ids), C.c_int(L.itype(ids)), C.c_int(batch), C.c_int64(nnz), C.c_int64(self.total_rows),
+                    L.ptr(ws), C.c_size_t(ws.numel()), L.ptr(err_flag), L.stream_ptr())
+            L.check(rc, "krs_embed_bag_bwd_plan_tables")
+            return ws
         with probe.span("k2_plan"):
             rc = L.lib().krs_embed_bag_bwd_plan(
                 L.ptr(tdesc), L.ptr(fdesc),

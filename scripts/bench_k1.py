@@ -104,6 +104,9 @@ if not a.fmajor_out:
     nnz = ids.numel()
     from keras_rs_amd import _lib as L
     import ctypes as C
+    for pv in (1, 0, 1, 0):          # KRS_EMBED_OPT_PLAN: 1 = global sort, 0 = table-segmented sort
+        L.check(L.lib().krs_embed_set_option(C.c_int(2), C.c_int(pv)), "set_option")
+        print(json.dumps({"plan_variant": pv, "k2_plan_us": timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots)) * 1e6}))
     t_plan = timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots))
     ws = fb.plan_backward(ids, a.batch, hots=hots)
     for variant in (0, 1, 0, 1):     # KRS_EMBED_OPT_APPLY: 0 = bag_apply_fast_kernel, 1 = the round-1 kernel
@@ -112,4 +115,32 @@ if not a.fmajor_out:
         t_sgd = timeit(lambda: fb.backward_fused("sgd", ws, grad, a.batch, nnz, hots=hots))
         print(json.dumps({"apply_variant": variant, "k2_plan_us": t_plan * 1e6, "k2_adagrad_us": t_ada * 1e6,
                           "k2_sgd_us": t_sgd * 1e6}))
+    L.lib().krs_embed_set_option(C.c_int(1), C.c_int(0))
+
+# ---- does the plan hide under the apply kernel?  (two streams; KRS_EMBED_OPT_APPLY 0 / 1) ----
+if not a.fmajor_out:
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    for variant in (0, 1):
+        L.lib().krs_embed_set_option(C.c_int(1), C.c_int(variant))
+        for order in ("apply_first", "plan_first"):
+            ts = []
+            for rep in range(6):
+                torch.cuda.synchronize()
+                e0, eA, eB = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+                sA.wait_stream(torch.cuda.current_stream()); sB.wait_stream(torch.cuda.current_stream())
+                def run_apply():
+                    with torch.cuda.stream(sA):
+                        fb.backward_fused("adagrad", ws, grad, a.batch, nnz, hots=hots)
+                        eA.record()
+                def run_plan():
+                    with torch.cuda.stream(sB):
+                        fb.plan_backward(ids, a.batch, hots=hots)
+                        eB.record()
+                (run_apply(), run_plan()) if order == "apply_first" else (run_plan(), run_apply())
+                torch.cuda.synchronize()
+                ts.append((e0.elapsed_time(eA), e0.elapsed_time(eB)))
+            ts = np.array(ts[2:])
+            print(json.dumps({"overlap": order, "apply_variant": variant, "apply_done_us": float(np.median(ts[:, 0]) * 1e3),
+                              "plan_done_us": float(np.median(ts[:, 1]) * 1e3)}))
     L.lib().krs_embed_set_option(C.c_int(1), C.c_int(0))

@@ -383,3 +383,54 @@ def test_thousands_of_out_of_range_ids_are_dropped(csr):
     ko.apply_optimizer(exp_t, acc, dense, touched, 0.05, "adagrad")
     np.testing.assert_allclose(table.cpu().numpy(), exp_t, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(slot.cpu().numpy(), acc, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("vocabs,dim", [([37, 900, 5, 70000], 64),        # 17 key bits: two passes
+                                        ([200, 31], 32),                   # 8 bits: one pass (first = last)
+                                        ([1_200_000, 3, 2_100_000], 8)])   # 22 bits: three passes
+@pytest.mark.parametrize("with_bad", [False, True])
+def test_table_segmented_plan_equals_global_plan(vocabs, dim, with_bad):
+    """krs_embed_bag_bwd_plan_tables (per-table sort on the id, 8-byte intermediate pairs, final pass rebuilds the
+    64-bit values) against the global sort (KRS_EMBED_OPT_PLAN = 1): the fused Adagrad update and the dense gradient
+    they lead to must be bit-identical -- problems that end in partial tiles, two features on one table (neighbours),
+    1 / 2 / 3 passes, out-of-range ids (which end their table's run instead of the array)."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    batch = 1031
+    tix = [0, 0] + list(range(1, len(vocabs)))             # table 0 has two neighbouring features
+    hots = [3, 1] + [7, 2, 5][: len(vocabs) - 1]
+    ids_np = np.concatenate([rng.integers(0, vocabs[tix[f]], batch * hots[f]) for f in range(len(tix))]).astype(np.int32)
+    if with_bad:
+        bad = rng.permutation(len(ids_np))[:300]
+        ids_np[bad] = np.where(bad % 2 == 0, -5, 2_000_000_000)
+    ids = torch.from_numpy(ids_np).to(dev)
+    cols = len(tix) * dim
+    grad = torch.from_numpy(rng.uniform(-1, 1, (batch, cols)).astype(np.float32)).to(dev)
+    w = torch.from_numpy(rng.uniform(0.1, 1, len(ids_np)).astype(np.float32)).to(dev)
+    res = []
+    try:
+        for variant in (0, 1):
+            L.check(L.lib().krs_embed_set_option(C.c_int(2), C.c_int(variant)), "krs_embed_set_option")
+            g = np.random.default_rng(9)
+            tables = [torch.from_numpy(g.uniform(-1, 1, (v, dim)).astype(np.float32)).to(dev) for v in vocabs]
+            slots = [torch.full((v, dim), 0.1, device=dev) for v in vocabs]
+            fb = FusedBags(tables, [(tix[f], "sum", f * dim) for f in range(len(tix))], slots=slots,
+                           lrs=[0.01 * (t + 1) for t in range(len(vocabs))])
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            ws = fb.plan_backward(ids, batch, hots=hots, err_flag=err)
+            assert bool(int(err.item()) & 1) == with_bad
+            dense = fb.backward_dense(ws, grad, batch, ids.numel(), hots=hots, weights=w)
+            fb.backward_fused("adagrad", ws, grad, batch, ids.numel(), hots=hots, weights=w)
+            torch.cuda.synchronize()
+            res.append((tables, slots, dense))
+    finally:
+        L.lib().krs_embed_set_option(C.c_int(2), C.c_int(0))
+    for part in range(3):
+        for a, b in zip(res[0][part], res[1][part]):
+            assert torch.equal(a, b)
+    assert not torch.equal(res[0][0][0], torch.from_numpy(np.random.default_rng(9).uniform(-1, 1, (vocabs[0], dim)).astype(np.float32)).to(dev))

@@ -59,7 +59,7 @@ def test_gradient_checksum_and_sgd_round_trip_at_full_size(c3):
     hots = [1] * T
     ids = torch.randint(0, V, (T * B,), device=DEV, generator=g, dtype=torch.int32)
     grad = (torch.rand(B, T * D, device=DEV, generator=g) - 0.5).to(torch.bfloat16)
-    ws = fb.plan_backward(ids, B, hots=hots)
+    ws = fb.plan_backward(ids, B, hots=hots, global_order=True)   # the compact form is indexed by segment
     # sparse form: every lookup's gradient lands in exactly one unique row; column sums are preserved
     rows, vals = fb.backward_sparse(ws, grad, B, ids.numel(), hots=hots)
     assert torch.all(rows[1:] > rows[:-1])
