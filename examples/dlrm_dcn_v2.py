@@ -7,7 +7,8 @@
 
 The only edits against the reference model code: `layers.concat_features` instead of
 `ops.concatenate` (the embeddings land directly in the interaction input, no copy) with
-`slab_lead_cols` reserving the bottom-MLP slot, and torch for the loss / dense optimizer.
+`slab_lead_cols` reserving the bottom-MLP slot, `kl.binary_crossentropy` for keras.losses.BinaryCrossentropy() and
+`keras_rs_amd.optim.Adagrad` for the dense optimizer.
 """
 
 from __future__ import annotations
@@ -121,7 +122,7 @@ def build_model(batch, vocab, hots, embedding_dim=128, projection=512, cross_lay
 def train_step(model, opt_box, inputs, labels):
     """One step: forward, BCE, backward (table optimizers run inside it), dense optimizer step."""
     pred = model(inputs)
-    loss = torch.nn.functional.binary_cross_entropy(pred.float().clamp(1e-7, 1 - 1e-7), labels)
+    loss = kl.binary_crossentropy(labels, pred)     # main.py:201-210, forward + backward in one pass (krs_bce_fwd_bwd)
     loss.backward()
     if opt_box[0] is None:  # the first step has built the layers
         dense_params = [p for p in model.parameters() if p.requires_grad]

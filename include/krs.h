@@ -300,8 +300,12 @@ int krs_gemm_set_option(int key, int value);
  *   KRS_EMBED_OPT_APPLY: the per-segment kernel of the backward -- 0 = bag_apply_fast_kernel (batched metadata,
  *   software-pipelined row / gradient loads; default), 1 = the round-1 kernel (kept for A/B).
  *   KRS_EMBED_OPT_PLAN: krs_embed_bag_bwd_plan_tables -- 0 = table-segmented sort where the layout allows it
- *   (default), 1 = always the global sort (A/B). */
-enum { KRS_EMBED_OPT_HOT1 = 0, KRS_EMBED_OPT_APPLY = 1, KRS_EMBED_OPT_PLAN = 2 };
+ *   (default), 1 = always the global sort (A/B).
+ *   KRS_EMBED_OPT_HOTROWS: LDS staging of hot embedding rows in the pooled gather -- 0 = off (default), 64 / 128 =
+ *   rows 0 .. n-1 of a workgroup's table are copied to LDS and lookups of them are served from there (one flat
+ *   16-byte load per lookup, routed to LDS or memory by its address); pays only when ids are relabelled
+ *   hot-first and those rows are NOT already cache hits (profiles/r3_k1_hot_rows_lds.txt: they are). */
+enum { KRS_EMBED_OPT_HOT1 = 0, KRS_EMBED_OPT_APPLY = 1, KRS_EMBED_OPT_PLAN = 2, KRS_EMBED_OPT_HOTROWS = 3 };
 int krs_embed_set_option(int key, int value);
 
 /* Elementwise halves of FeatureCross for the host-composed path (arbitrary
@@ -362,7 +366,9 @@ int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
  *   out [batch, out_cols], out_cols = F*F (skip_gather) | F(F+1)/2 | F(F-1)/2
  * Backward: dX[b,i,:] = sum_j (G[b,i,j] + G[b,j,i]) X[b,j,:], G = the gradient
  * scattered back to [F,F] (zero above / on the masked part).
- * F <= 64 (KRS_ERR_UNSUPPORTED above; the MFMA path covers F <= 32, 16-B aligned rows).
+ * Any F (the reference has no limit): the MFMA path covers F <= 32 with 16-B aligned rows, one plain launch
+ * F <= 64, beyond that one launch per (32 features i, 128 features j) block pair.  accumulate_mask addresses the
+ * first 64 features.
  * ------------------------------------------------------------------------- */
 int krs_dot_interaction_fwd(const void* const* feats, const int64_t* ld, int n_feats,
                             int64_t batch, int dim, int dtype,
@@ -400,6 +406,19 @@ size_t krs_mod_bucketize_workspace_bytes(int64_t nnz, int n_shards);
 int krs_mod_bucketize(const void* ids, int id_type, int64_t nnz, int n_shards,
                       void* local_ids, int32_t* perm, int64_t* bucket_counts,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * K7  Binary cross-entropy of the DLRM head, forward + backward in one pass
+ *
+ * keras.losses.BinaryCrossentropy() as examples/ml_perf/main.py:201-210 compiles it (from_logits=False,
+ * mean reduction) on the sigmoid output of the top MLP (examples/ml_perf/model.py:105-163):
+ *   p = clip(pred, epsilon, 1 - epsilon);  loss = mean_i -(y_i log p_i + (1 - y_i) log(1 - p_i))
+ *   dpred_i = grad_scale / n * ((1 - y_i) / (1 - p_i) - y_i / p_i), 0 where the clip is active
+ * pred [n] fp32 / bf16 (contiguous), labels [n] fp32, loss = device scalar, dpred [n] in pred's dtype
+ * (may be NULL: forward only).  fp32 arithmetic, fixed summation order (deterministic).
+ * ------------------------------------------------------------------------- */
+int krs_bce_fwd_bwd(const void* pred, int pred_dtype, const float* labels, int64_t n, float epsilon,
+                    float grad_scale, float* loss, void* dpred, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * K6  Row-sharded lookup: route / unpack / combine (the id side of the exchange)

@@ -93,6 +93,7 @@ SYMBOLS = [
     "krs_shard_route_static",
     "krs_shard_unpack_static",
     "krs_publish_i64",
+    "krs_bce_fwd_bwd",
 ]
 
 _lib = None

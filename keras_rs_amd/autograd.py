@@ -215,6 +215,23 @@ class DenseFn(torch.autograd.Function):
         return dx, dk.to(k_dt), db, None, None
 
 
+class BinaryCrossentropyFn(torch.autograd.Function):
+    """loss = mean(-(y log p + (1 - y) log(1 - p))), p = clip(pred, eps, 1 - eps): keras.losses.BinaryCrossentropy()
+    as examples/ml_perf/main.py:201-210 compiles it.  The gradient is produced by the forward's single pass over the
+    predictions (krs_bce_fwd_bwd) and scaled by the incoming scalar in the backward."""
+
+    @staticmethod
+    def forward(ctx, pred, labels, epsilon):
+        loss, dp = D.bce_fwd_bwd(pred, labels, epsilon, want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(dp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return (dp if dp is None else dp * g.to(dp.dtype)), None, None
+
+
 class CrossEpilogueFn(torch.autograd.Function):
     """y = x0 * (u + diag*x) + x for a host-composed u (arbitrary pre_activation callables)."""
 

@@ -589,6 +589,101 @@ __global__ __launch_bounds__(256) void dot_bwd_generic_kernel(const DotGenericPa
   }
 }
 
+// ---- more than 64 features: the plain kernels over BLOCKS of features ----------------------------------------
+// The reference has no limit on the number of features (dot_interaction.py:134-205); pointer tables of any length do
+// not fit kernel arguments, so F > 64 runs one launch per (block of 32 features i, chunk of 128 features j): the
+// forward fills the pairs (i, j) of the output; the backward adds the chunk's share of dX_i = sum_j (G_ij + G_ji) X_j
+// to the gradients of the block -- the first chunk stores (or adds to the existing value of an accumulated feature),
+// later chunks add to what the buffer holds; launches of one stream run in order, so j ascends as in the one-launch
+// kernel.  Up to 128 features that is ONE chunk: fp32 sum, one rounding, exactly the plain kernel's arithmetic;
+// beyond, a bf16 gradient is rounded once per chunk of 128 (fp32 gradients are exact sums either way).
+constexpr int kBlockI = 32, kBlockJ = 128;
+struct DotBlockParams {
+  const void* fi[kBlockI];
+  int64_t ldi[kBlockI];
+  void* gi[kBlockI];
+  int64_t gldi[kBlockI];
+  const void* fj[kBlockJ];
+  int64_t ldj[kBlockJ];
+  int i0, ni, j0, nj, n_feats;
+  int64_t batch;
+  int dim, self_inter, skip_gather, dtype;
+  void* out;
+  int64_t out_ld;
+  uint32_t acc_bits;     // backward: features of the i block whose gradient buffer already holds a value to add to
+  int first_j;           // backward: the first chunk of the row of launches
+};
+
+__global__ __launch_bounds__(256) void dot_fwd_block_kernel(const DotBlockParams p) {
+  const int64_t per = (int64_t)p.ni * p.nj;
+  const int64_t total = p.batch * per;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t b = idx / per;
+    const int e = (int)(idx - b * per);
+    const int ii = e / p.nj, jj = e - ii * p.nj;
+    const int i = p.i0 + ii, j = p.j0 + jj;
+    const bool keep = pair_kept(i, j, p.self_inter);
+    if (!keep && !p.skip_gather) continue;
+    float acc = 0.0f;
+    if (keep)
+      for (int c = 0; c < p.dim; ++c)
+        acc = fmaf(ld_elem(p.fi[ii], p.dtype, b * p.ldi[ii] + c), ld_elem(p.fj[jj], p.dtype, b * p.ldj[jj] + c), acc);
+    st_elem(p.out, p.dtype, b * p.out_ld + pair_col(i, j, p.n_feats, p.self_inter, p.skip_gather), acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void dot_bwd_block_kernel(const DotBlockParams p) {
+  const int64_t per = (int64_t)p.ni * p.dim;
+  const int64_t total = p.batch * per;
+  const int F = p.n_feats;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t b = idx / per;
+    const int e = (int)(idx - b * per);
+    const int ii = e / p.dim, c = e - ii * p.dim;
+    const int i = p.i0 + ii;
+    float acc = 0.0f;
+    for (int jj = 0; jj < p.nj; ++jj) {
+      const int j = p.j0 + jj;
+      float gs = 0.0f;
+      if (pair_kept(i, j, p.self_inter))
+        gs += ld_elem(p.out, p.dtype, b * p.out_ld + pair_col(i, j, F, p.self_inter, p.skip_gather));
+      if (pair_kept(j, i, p.self_inter))
+        gs += ld_elem(p.out, p.dtype, b * p.out_ld + pair_col(j, i, F, p.self_inter, p.skip_gather));
+      acc = fmaf(gs, ld_elem(p.fj[jj], p.dtype, b * p.ldj[jj] + c), acc);
+    }
+    if (!p.first_j || ((p.acc_bits >> ii) & 1u)) acc += ld_elem(p.gi[ii], p.dtype, b * p.gldi[ii] + c);
+    st_elem(p.gi[ii], p.dtype, b * p.gldi[ii] + c, acc);
+  }
+}
+
+// host side of the two: the launches of one call
+int run_dot_blocks(bool backward, const void* const* feats, const int64_t* ld, int n_feats, int64_t batch, int dim,
+                   int dtype, int self_interaction, int skip_gather, void* out, int64_t out_ld, void* const* grad_feats,
+                   const int64_t* grad_feat_ld, uint64_t accumulate_mask, hipStream_t st) {
+  for (int i0 = 0; i0 < n_feats; i0 += kBlockI) {
+    DotBlockParams p{};
+    p.i0 = i0; p.ni = std::min(kBlockI, n_feats - i0); p.n_feats = n_feats; p.batch = batch; p.dim = dim;
+    p.self_inter = self_interaction != 0; p.skip_gather = skip_gather != 0; p.dtype = dtype; p.out = out; p.out_ld = out_ld;
+    for (int k = 0; k < p.ni; ++k) {
+      p.fi[k] = feats[i0 + k]; p.ldi[k] = ld[i0 + k];
+      if (backward) { p.gi[k] = grad_feats[i0 + k]; p.gldi[k] = grad_feat_ld[i0 + k]; }
+      if (i0 + k < 64 && ((accumulate_mask >> (i0 + k)) & 1ull)) p.acc_bits |= 1u << k;
+    }
+    // forward without skip_gather: pairs with j > i are not part of the output
+    const int j_end = (!backward && !skip_gather) ? std::min(n_feats, i0 + p.ni) : n_feats;
+    for (int j0 = 0; j0 < j_end; j0 += kBlockJ) {
+      p.j0 = j0; p.nj = std::min(kBlockJ, j_end - j0); p.first_j = j0 == 0;
+      for (int k = 0; k < p.nj; ++k) { p.fj[k] = feats[j0 + k]; p.ldj[k] = ld[j0 + k]; }
+      const int64_t work = backward ? batch * p.ni * dim : batch * p.ni * p.nj;
+      const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(work, 256), 65536);
+      if (backward) hipLaunchKernelGGL(dot_bwd_block_kernel, dim3(blocks), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL(dot_fwd_block_kernel, dim3(blocks), dim3(256), 0, st, p);
+    }
+  }
+  KRS_CHECK_LAUNCH("dot_interaction block kernels");
+  return KRS_OK;
+}
+
 bool fast_ok(const void* const* feats, const int64_t* ld, int n_feats, int dim, int es) {
   if (n_feats > kMaxFast) return false;
   const int ve = 16 / es;
@@ -635,7 +730,8 @@ extern "C" int krs_dot_interaction_fwd(const void* const* feats, const int64_t* 
     return KRS_OK;
   }
   if (n_feats > kMaxGeneric)
-    return fail(KRS_ERR_UNSUPPORTED, "dot_interaction: at most %d features (got %d)", kMaxGeneric, n_feats);
+    return run_dot_blocks(false, feats, ld, n_feats, batch, dim, dtype, self_interaction, skip_gather, out, out_ld,
+                          nullptr, nullptr, 0, st);
   DotGenericParams g{};
   for (int f = 0; f < n_feats; ++f) { g.feat[f] = feats[f]; g.ld[f] = ld[f]; }
   g.n_feats = n_feats; g.batch = batch; g.dim = dim; g.self_inter = self_interaction != 0;
@@ -737,7 +833,8 @@ extern "C" int krs_dot_interaction_bwd_accumulate(const void* const* feats, cons
     return KRS_OK;
   }
   if (n_feats > kMaxGeneric)
-    return fail(KRS_ERR_UNSUPPORTED, "dot_interaction: at most %d features (got %d)", kMaxGeneric, n_feats);
+    return run_dot_blocks(true, feats, ld, n_feats, batch, dim, dtype, self_interaction, skip_gather,
+                          const_cast<void*>(grad_out), grad_ld, grad_feats, grad_feat_ld, accumulate_mask, st);
   DotGenericParams g{};
   for (int f = 0; f < n_feats; ++f) {
     g.feat[f] = feats[f]; g.ld[f] = ld[f]; g.gfeat[f] = grad_feats[f]; g.gld[f] = grad_feat_ld[f];

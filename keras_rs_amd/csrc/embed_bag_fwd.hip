@@ -115,7 +115,13 @@ __device__ __forceinline__ void store_row_piece(OT* dst, const float (&v)[N], bo
 //      unconditionally (row 0 stands in for invalid and padding slots and is masked after the
 //      load) and consumed in order; a set flag flushes the finished bag.
 // STREAM: bags of ~1 lookup -> no row reuse to protect: 8 row loads in flight, non-temporal.
-template <typename TT, typename OT, int LPR, bool HAS_W, bool STREAM>
+// HR > 0 (krs_embed_set_option(KRS_EMBED_OPT_HOTROWS, HR); "LDS staging of hot embedding rows"): when the four waves of
+// the workgroup work on ONE feature, rows 0 .. HR-1 of its table are copied to LDS first (ids relabelled hot-first put
+// the most frequent rows there), and a lookup of such a row is served from LDS.  No branch and no second access form:
+// the row address is SELECTED between the LDS copy and the table and read with one generic (flat) 16-byte load, which
+// the hardware routes to LDS or to memory by the address -- so the loop keeps its unconditional loads.  What it costs:
+// flat loads count on both the memory and the LDS counter, and HR x row bytes of LDS per workgroup lower the occupancy.
+template <typename TT, typename OT, int LPR, bool HAS_W, bool STREAM, int HR = 0>
 __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p) {
   constexpr int G = 64 / LPR;
   constexpr int N = Vec16<TT>::N;
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p)
   __shared__ int s_flag[4 * G * WIN];
   __shared__ float s_w[HAS_W ? 4 * G * WIN : 1];
   __shared__ int s_end[4 * G * (MAXB + 1)];
+  __shared__ __attribute__((aligned(16))) char s_hot[HR > 0 ? HR * LPR * 16 : 16];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -134,6 +141,21 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p)
 
   const int bags_per_wave = G * p.bpg;
   const int waves_per_feat = (p.batch + bags_per_wave - 1) / bags_per_wave;
+  int hot_rows = 0;   // rows of this workgroup's table that sit in s_hot (workgroup-uniform)
+  if constexpr (HR > 0) {
+    const int64_t total = (int64_t)waves_per_feat * p.n_feats;
+    const int64_t first = (int64_t)blockIdx.x * 4, last = min(first + 3, total - 1);
+    if (first < total && first / waves_per_feat == last / waves_per_feat) {
+      const krs_feature ft0 = p.feats[first / waves_per_feat];
+      const krs_table tb0 = p.tables[ft0.table];
+      hot_rows = min(HR, tb0.vocab);
+      const int pieces = hot_rows * LPR;      // 16-byte pieces (the host takes this path for row bytes == LPR * 16)
+      typedef const __attribute__((address_space(1))) u32x4* gsrc_ptr;
+      for (int i = threadIdx.x; i < pieces; i += 256)
+        reinterpret_cast<u32x4*>(s_hot)[i] = ((gsrc_ptr)tb0.weights)[i];
+    }
+    __syncthreads();
+  }
   const int64_t wave_unit = (int64_t)blockIdx.x * 4 + wave;
   if (wave_unit >= (int64_t)waves_per_feat * p.n_feats) return;
   const int f = __builtin_amdgcn_readfirstlane((int)(wave_unit / waves_per_feat));
@@ -273,8 +295,14 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_vec(const EmbedFwdParams p)
         const int row = idc[k] < 0 ? 0 : idc[k];
         // global address space made explicit: a generic pointer would become flat_load (+ lgkmcnt waits)
         typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
-        gvec_ptr src = (gvec_ptr)(table + (int64_t)row * row_bytes);
-        if constexpr (STREAM) raw[k] = __builtin_nontemporal_load(src); else raw[k] = *src;
+        if constexpr (HR > 0) {
+          const char* from_lds = s_hot + row * (LPR * 16) + sub * 16;      // generic pointer into the LDS aperture
+          const char* from_mem = table + (int64_t)row * row_bytes;
+          raw[k] = *reinterpret_cast<const u32x4*>(row < hot_rows ? from_lds : from_mem);   // one flat load
+        } else {
+          gvec_ptr src = (gvec_ptr)(table + (int64_t)row * row_bytes);
+          if constexpr (STREAM) raw[k] = __builtin_nontemporal_load(src); else raw[k] = *src;
+        }
       }
 #pragma unroll
       for (int k = 0; k < kUnroll; ++k) {
@@ -548,6 +576,7 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_generic(const EmbedFwdParam
 
 // One-hot gather variant (krs_embed_set_option(KRS_EMBED_OPT_HOT1, v) / environment KRS_EMBED_HOT1, read once):
 // bit 0: 16 instead of 8 row loads in flight per lane; bit 1: sample-major walk (embed_gather_hot1_rows).
+int g_hot_rows = 0;   // krs_embed_set_option(KRS_EMBED_OPT_HOTROWS, rows): 0 = no LDS staging (default), 64, 128
 int g_hot1 = -1;
 int hot1_variant() {
   if (g_hot1 < 0) {
@@ -587,6 +616,20 @@ int launch_vec(const EmbedFwdParams& p, bool one_hot, bool stream, hipStream_t s
   if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_fwd: grid too large");
 #define KRS_K1_LAUNCH(W, S) \
   hipLaunchKernelGGL((embed_bag_fwd_vec<TT, OT, LPR, W, S>), dim3((unsigned)blocks), dim3(256), 0, st, p)
+  if constexpr (sizeof(TT) == 2 && sizeof(OT) == 2 && LPR == 16) {
+    // LDS staging of hot rows (opt-in: krs_embed_set_option(KRS_EMBED_OPT_HOTROWS, 64 | 128)): bf16 rows of 256 bytes
+    if (g_hot_rows > 0 && !p.weights && (int64_t)p.dim * 2 == LPR * 16) {
+      if (g_hot_rows >= 128) {
+        if (stream) hipLaunchKernelGGL((embed_bag_fwd_vec<TT, OT, LPR, false, true, 128>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((embed_bag_fwd_vec<TT, OT, LPR, false, false, 128>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+      } else {
+        if (stream) hipLaunchKernelGGL((embed_bag_fwd_vec<TT, OT, LPR, false, true, 64>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((embed_bag_fwd_vec<TT, OT, LPR, false, false, 64>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+      }
+      KRS_CHECK_LAUNCH("embed_bag_fwd_vec (hot rows in LDS)");
+      return KRS_OK;
+    }
+  }
   if (p.weights) { if (stream) KRS_K1_LAUNCH(true, true); else KRS_K1_LAUNCH(true, false); }
   else { if (stream) KRS_K1_LAUNCH(false, true); else KRS_K1_LAUNCH(false, false); }
 #undef KRS_K1_LAUNCH
@@ -616,6 +659,11 @@ extern "C" int krs_embed_set_option(int key, int value) {
   if (key == KRS_EMBED_OPT_PLAN) {
     KRS_REQUIRE(value == 0 || value == 1, "krs_embed_set_option: plan variant must be 0 or 1");
     krs::g_plan_variant = value;
+    return KRS_OK;
+  }
+  if (key == KRS_EMBED_OPT_HOTROWS) {
+    KRS_REQUIRE(value == 0 || value == 64 || value == 128, "krs_embed_set_option: hot rows must be 0, 64 or 128");
+    krs::g_hot_rows = value;
     return KRS_OK;
   }
   if (key == KRS_EMBED_OPT_HOT1) {

@@ -246,3 +246,24 @@ def mod_bucketize(ids: torch.Tensor, n_shards: int):
                                    L.stream_ptr())
     L.check(rc, "krs_mod_bucketize")
     return local, perm, counts
+
+
+def bce_fwd_bwd(pred: torch.Tensor, labels: torch.Tensor, epsilon: float = 1e-7, grad_scale: float = 1.0,
+                want_grad: bool = True):
+    """(loss [] fp32, dL/dpred | None): binary cross-entropy of probabilities, mean reduction, forward and backward in
+    one pass (krs_bce_fwd_bwd; keras.losses.BinaryCrossentropy() of examples/ml_perf/main.py:201-210)."""
+    L.require_device(pred, "bce pred")
+    p = pred.reshape(-1)
+    if not p.is_contiguous():
+        p = p.contiguous()
+    y = labels.reshape(-1).to(torch.float32)
+    if not y.is_contiguous():
+        y = y.contiguous()
+    if y.numel() != p.numel():
+        raise L.KrsError(f"bce: {p.numel()} predictions but {y.numel()} labels")
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    dp = torch.empty_like(p) if want_grad else None
+    rc = L.lib().krs_bce_fwd_bwd(L.ptr(p), C.c_int(L.fdtype(p)), L.ptr(y), C.c_int64(p.numel()), C.c_float(epsilon),
+                                 C.c_float(grad_scale), L.ptr(loss), L.ptr(dp), L.stream_ptr())
+    L.check(rc, "krs_bce_fwd_bwd")
+    return loss, (None if dp is None else dp.reshape(pred.shape))

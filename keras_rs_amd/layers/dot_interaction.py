@@ -48,7 +48,8 @@ class DotInteraction(base.Layer):
             from keras_rs_amd.layers.distributed_embedding import slab_grad_relay, slab_views_run
 
             slab, k = slab_views_run(inputs)
-            if slab is not None and slab.dtype == cd and all(tuple(h.shape) == shape for h in inputs[:k]):
+            if slab is not None and slab.dtype == cd and len(inputs) <= 64 and \
+                    all(tuple(h.shape) == shape for h in inputs[:k]):   # (the kernel's accumulate mask has 64 bits)
                 relay, n_heads = slab_grad_relay(slab), k
         return DotInteractionFn.apply(self.self_interaction, self.skip_gather, relay, n_heads, *feats)
 

@@ -290,6 +290,25 @@ def dense_act_bwd(g, y, act):
     return (f32_to_bf16_bits(dz) if bf else dz), dz.astype(np.float64).sum(0).astype(np.float32)
 
 
+def bce_fwd_bwd(pred, labels, epsilon=1e-7, grad_scale=1.0):
+    """include/krs.h krs_bce_fwd_bwd: keras.losses.BinaryCrossentropy() as examples/ml_perf/main.py:201-210 compiles it
+    (probabilities in, mean reduction): p = clip(pred, eps, 1 - eps) in fp32, loss = mean(-(y log p + (1-y) log(1-p)))
+    summed in float64, dpred = grad_scale / n * ((1-y)/(1-p) - y/p) where the clip is inactive, else 0.
+    pred: fp32 array or bf16 bit patterns; returns (loss float32, dpred in the input format)."""
+    bf = pred.dtype == np.uint16
+    x = (bf16_bits_to_f32(pred) if bf else np.asarray(pred, np.float32)).reshape(-1)
+    y = np.asarray(labels, np.float32).reshape(-1)
+    eps, hi = np.float32(epsilon), np.float32(1.0) - np.float32(epsilon)
+    p = np.minimum(np.maximum(x, eps), hi)
+    one = np.float32(1.0)
+    li = -(y * np.log(p) + (one - y) * np.log(one - p))
+    loss = np.float32(li.astype(np.float64).sum() / len(x))
+    inside = (x >= eps) & (x <= hi)
+    g = np.where(inside, np.float32(grad_scale) * (one / np.float32(len(x))) * ((one - y) / (one - p) - y / p),
+                 np.float32(0)).astype(np.float32)
+    return loss, (f32_to_bf16_bits(g) if bf else g)
+
+
 def dense_adagrad(p, g, acc, lr, eps):
     """include/krs.h krs_dense_adagrad (keras / torch Adagrad on a dense fp32 weight, epsilon outside the root):
     returns (new p, new acc); fp32 arithmetic with the fused multiply-add of acc + g*g done in float64 and

@@ -25,6 +25,7 @@ ap.add_argument("--copyref", action="store_true")
 ap.add_argument("--idmode", default="rand")
 ap.add_argument("--fmajor_out", action="store_true")
 ap.add_argument("--scale", action="store_true")
+ap.add_argument("--hotrows", default="", help="comma list of KRS_EMBED_OPT_HOTROWS values to A/B (0,64,128)")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -65,9 +66,14 @@ if a.copyref:
     for _ in range(10): dst.copy_(src)
     e1.record(); torch.cuda.synchronize()
     print(json.dumps({"copy_GBps": 2 * 10 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9}))
-for bpg in (a.bpgs.split(",") if a.bpgs else [""]):
+import ctypes as _C
+from keras_rs_amd import _lib as _L
+_variants = [(b, h) for b in (a.bpgs.split(",") if a.bpgs else [""]) for h in (a.hotrows.split(",") if a.hotrows else [""])]
+for bpg, hr in _variants:
     if bpg:
         os.environ["KRS_BPG"] = bpg
+    if hr != "":
+        _L.check(_L.lib().krs_embed_set_option(_C.c_int(3), _C.c_int(int(hr))), "set_option")
     for _ in range(3):
         fb.forward(ids, a.batch, hots=hots, out=out)
     torch.cuda.synchronize()
@@ -81,10 +87,11 @@ for bpg in (a.bpgs.split(",") if a.bpgs else [""]):
     nnz = ids.numel()
     es = 2 if a.dtype == "bf16" else 4
     bytes_ = nnz * (a.dim * es + 4) + a.batch * a.tables * (a.dim * es)
-    print(json.dumps({"lib": os.path.basename(os.environ.get("KRS_LIB", "default")), "bpg": bpg, "stacked": a.stacked, "fmajor_out": a.fmajor_out, "vocab": a.vocab, "idmode": a.idmode, "nnz": nnz, "median_us": float(np.median(ts) * 1e6),
+    print(json.dumps({"lib": os.path.basename(os.environ.get("KRS_LIB", "default")), "bpg": bpg, "hotrows": hr, "stacked": a.stacked, "fmajor_out": a.fmajor_out, "vocab": a.vocab, "idmode": a.idmode, "nnz": nnz, "median_us": float(np.median(ts) * 1e6),
                       "min_us": float(ts.min() * 1e6), "lookups_per_s": nnz / float(np.median(ts)),
                       "GBps": bytes_ / float(np.median(ts)) / 1e9, "frac_of_8TBps": bytes_ / float(np.median(ts)) / 8e12}))
     
+_L.lib().krs_embed_set_option(_C.c_int(3), _C.c_int(0))
 # ---- K2 timings (plan = sort; apply = fused Adagrad) ----
 def timeit(fn, iters=10):
     for _ in range(2):

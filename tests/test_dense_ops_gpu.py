@@ -303,15 +303,6 @@ def test_dense_adagrad_one_launch_matches_torch_and_the_oracle():
         Adagrad([bad]).step()
 
 
-def test_dot_interaction_feature_limit_is_loud():
-    from keras_rs_amd import dense_ops as D
-    from keras_rs_amd._lib import KrsError
-
-    feats = [_t(np.ones((2, 4), np.float32)) for _ in range(65)]
-    with pytest.raises(KrsError, match="at most 64 features"):
-        D.dot_interaction_fwd(feats, False, False)
-
-
 @pytest.mark.parametrize("n_shards", [1, 2, 4, 8, 5])
 @pytest.mark.parametrize("idt", [np.int32, np.int64])
 @pytest.mark.parametrize("nnz", [0, 1, 255, 2048, 100_003])
@@ -325,3 +316,75 @@ def test_mod_bucketize_bit_exact(n_shards, idt, nnz):
     np.testing.assert_array_equal(counts.cpu().numpy(), ec)
     np.testing.assert_array_equal(perm.cpu().numpy(), ep)
     np.testing.assert_array_equal(local.cpu().numpy(), el)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+@pytest.mark.parametrize("n", [1, 1000, 65536])
+def test_binary_crossentropy_fwd_bwd_matches_oracle(dtype, n):
+    """krs_bce_fwd_bwd (keras.losses.BinaryCrossentropy() of examples/ml_perf/main.py:201-210) against the oracle:
+    loss to 2e-6 (fp32 tree sum vs float64 sum), gradient element-wise, predictions beyond the clip (gradient 0),
+    exact 0 / 1 predictions (finite loss), through autograd with an upstream scale."""
+    import keras_rs_amd.layers as kl
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(n)
+    pred = rng.uniform(0, 1, n).astype(np.float32)
+    pred[:: 97] = 0.0
+    pred[1:: 89] = 1.0
+    pred[2:: 83] = 5e-8
+    y = (rng.uniform(0, 1, n) < 0.3).astype(np.float32)
+    t = torch.from_numpy(pred).to(DEV).to(getattr(torch, dtype))
+    labels = torch.from_numpy(y).to(DEV)
+    loss, dp = D.bce_fwd_bwd(t, labels, grad_scale=1.0)
+    e_loss, e_dp = ko.bce_fwd_bwd(to_np(t), y)
+    assert np.isfinite(float(loss))
+    np.testing.assert_allclose(float(loss), float(e_loss), rtol=2e-6)
+    if dtype == "float32":
+        np.testing.assert_allclose(to_np(dp), e_dp, rtol=1e-6, atol=1e-12)
+    else:
+        np.testing.assert_allclose(ko.bf16_bits_to_f32(to_np(dp)), ko.bf16_bits_to_f32(e_dp), rtol=2 ** -7, atol=1e-12)
+    # through autograd: d(3 * loss)/dpred = 3 * dpred
+    tp = t.clone().reshape(n, 1).requires_grad_()
+    (3.0 * kl.BinaryCrossentropy()(labels.reshape(n, 1), tp)).backward()
+    np.testing.assert_allclose(tp.grad.float().cpu().numpy().reshape(-1), 3.0 * dp.float().cpu().numpy(), rtol=2 ** -6, atol=1e-12)
+
+
+@pytest.mark.parametrize("n_feats,dim", [(65, 16), (100, 8), (130, 4)])
+@pytest.mark.parametrize("self_interaction,skip_gather", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_dot_interaction_beyond_64_features(n_feats, dim, self_interaction, skip_gather, dtype):
+    """The reference puts no limit on the number of features (dot_interaction.py:134-205): F = 65, 100 (one chunk of j)
+    and 130 (two chunks) through the block launches, forward and backward against the oracle in the four modes."""
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(n_feats)
+    B = 37
+    tdt = getattr(torch, dtype)
+    feats = [_t(rng.uniform(-1, 1, (B, dim)), tdt) for _ in range(n_feats)]
+    fnp = [to_np(f) for f in feats]
+    out = D.dot_interaction_fwd(feats, self_interaction, skip_gather)
+    exp = ko.dot_interaction_fwd(fnp, self_interaction, skip_gather)
+    tol = _tol(tdt, dim)
+    np.testing.assert_allclose(to_f32(to_np(out)), to_f32(exp), **tol)
+    g = _t(rng.uniform(-1, 1, tuple(out.shape)), tdt)
+    grads = D.dot_interaction_bwd(feats, g, self_interaction, skip_gather)
+    e_grads = ko.dot_interaction_bwd(fnp, to_np(g), self_interaction, skip_gather)
+    btol = _tol(tdt, 2 * n_feats)
+    if dtype == "bfloat16" and n_feats > 128:
+        btol = dict(rtol=2 ** -5, atol=btol["atol"] * 2)      # one more rounding per chunk of 128 features
+    for a, b in zip(grads, e_grads):
+        np.testing.assert_allclose(to_f32(to_np(a)), to_f32(b), **btol)
+
+
+def test_dot_interaction_layer_with_100_features_trains():
+    import keras_rs_amd.layers as kl
+
+    rng = np.random.default_rng(0)
+    feats = [_t(rng.uniform(-1, 1, (8, 4))).requires_grad_() for _ in range(100)]
+    out = kl.DotInteraction()(feats)
+    assert tuple(out.shape) == (8, 100 * 99 // 2)
+    out.sum().backward()
+    x = torch.stack([f.detach() for f in feats], 1)                      # dX_i = sum_{j != i} X_j for an all-ones gradient
+    exp = x.sum(1, keepdim=True) - x
+    for i, f in enumerate(feats):
+        np.testing.assert_allclose(f.grad.cpu().numpy(), exp[:, i].cpu().numpy(), rtol=1e-5, atol=1e-5)

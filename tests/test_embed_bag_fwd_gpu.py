@@ -159,3 +159,34 @@ def test_bags_longer_than_one_staging_window(dt, dim):
     bags = dict(ids=ids, offsets=offsets, hots=None, weights=w, nnz=len(ids))
     exp, _, _ = oracle_embed_fwd([to_np(t) for t in tables], specs, bags, batch, dim, 3 * dim, NP_DT[dt], True)
     np.testing.assert_allclose(to_f32(to_np(out)), to_f32(exp), **tol)
+
+
+@pytest.mark.parametrize("rows", [64, 128])
+@pytest.mark.parametrize("hots", [[1, 3, 9], [2, 2, 2]])
+def test_hot_rows_staged_in_lds_give_identical_outputs(rows, hots):
+    """KRS_EMBED_OPT_HOTROWS: lookups of rows 0 .. n-1 are served from an LDS copy through flat loads -- the pooled
+    outputs must be bit-identical to the plain kernel's (same fp32 accumulation order), with ids concentrated on the
+    staged rows, a table smaller than the staged window, and workgroups that straddle two features (no staging there)."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    rng = np.random.default_rng(rows)
+    dev = torch.device("cuda:0")
+    B, D = 1999, 128
+    vocabs = [5000, 40, 700]
+    tables = [torch.from_numpy(rng.uniform(-1, 1, (v, D)).astype(np.float32)).to(torch.bfloat16).to(dev) for v in vocabs]
+    ids = torch.from_numpy(np.concatenate([
+        np.minimum((rng.uniform(0, 1, B * h) ** 4 * vocabs[t]).astype(np.int64), vocabs[t] - 1) for t, h in enumerate(hots)
+    ]).astype(np.int32)).to(dev)
+    fb = FusedBags(tables, [(t, "sum", t * D) for t in range(3)])
+    try:
+        L.check(L.lib().krs_embed_set_option(C.c_int(3), C.c_int(0)), "set_option")
+        ref, _ = fb.forward(ids, B, hots=hots)
+        L.check(L.lib().krs_embed_set_option(C.c_int(3), C.c_int(rows)), "set_option")
+        got, _ = fb.forward(ids, B, hots=hots)
+        torch.cuda.synchronize()
+    finally:
+        L.lib().krs_embed_set_option(C.c_int(3), C.c_int(0))
+    assert torch.equal(ref, got)

@@ -78,7 +78,8 @@ def test_assembled_model_matches_reference_composition():
     np.testing.assert_allclose(_np(pred), exp, rtol=1e-5, atol=1e-5)
 
     # ---- backward: float64 torch composition of the same formulas on the CPU ----
-    loss = torch.nn.functional.binary_cross_entropy(pred.float().clamp(1e-7, 1 - 1e-7), labels)
+    loss = kl.binary_crossentropy(labels, pred)      # krs_bce_fwd_bwd: no torch arithmetic left in the step
+    np.testing.assert_allclose(float(loss.detach()), float(ko.bce_fwd_bwd(_np(pred), _np(labels))[0]), rtol=2e-6)
     loss.backward()
     d64 = lambda a: torch.from_numpy(np.asarray(a, np.float64)).requires_grad_()  # noqa: E731
     P = {n: d64(_np(p)) for n, p in model.named_parameters() if p.requires_grad}

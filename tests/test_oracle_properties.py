@@ -195,3 +195,25 @@ def test_sgd_and_adagrad_touch_only_the_flagged_rows(seed):
     np.testing.assert_allclose(acc[touched != 0], a_ref[touched != 0], rtol=1e-6)
     np.testing.assert_array_equal(acc[touched == 0], np.full((int((touched == 0).sum()), d), 0.1, np.float32))
     np.testing.assert_array_equal(t2[touched == 0], table[touched == 0])
+
+
+def test_bce_oracle_matches_a_float64_composition_with_autograd():
+    """oracle bce_fwd_bwd against an independent float64 torch composition of keras.losses.BinaryCrossentropy()
+    (clip to [eps, 1 - eps], mean of -(y log p + (1 - y) log(1 - p))) and its autograd gradient."""
+    import torch
+
+    rng = np.random.default_rng(4)
+    n = 4097
+    pred = rng.uniform(0, 1, n).astype(np.float32)
+    pred[::50] = 0.0
+    pred[1::50] = 1.0
+    y = (rng.uniform(0, 1, n) < 0.4).astype(np.float32)
+    loss, dp = ko.bce_fwd_bwd(pred, y, grad_scale=2.0)
+    p64 = torch.from_numpy(pred.astype(np.float64)).requires_grad_()
+    y64 = torch.from_numpy(y.astype(np.float64))
+    eps = float(np.float32(1e-7))
+    pc = p64.clamp(eps, float(np.float32(1.0) - np.float32(1e-7)))
+    ref = -(y64 * torch.log(pc) + (1 - y64) * torch.log(1 - pc)).mean()
+    (2.0 * ref).backward()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=1e-6)
+    np.testing.assert_allclose(dp, p64.grad.numpy(), rtol=2e-5, atol=1e-12)
