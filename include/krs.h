@@ -415,10 +415,12 @@ int krs_mod_bucketize(const void* ids, int id_type, int64_t nnz, int n_shards,
  *   p = clip(pred, epsilon, 1 - epsilon);  loss = mean_i -(y_i log p_i + (1 - y_i) log(1 - p_i))
  *   dpred_i = grad_scale / n * ((1 - y_i) / (1 - p_i) - y_i / p_i), 0 where the clip is active
  * pred [n] fp32 / bf16 (contiguous), labels [n] fp32, loss = device scalar, dpred [n] in pred's dtype
- * (may be NULL: forward only).  fp32 arithmetic, fixed summation order (deterministic).
+ * (may be NULL: forward only).  partials: KRS_BCE_MAX_BLOCKS floats of scratch (device), or NULL = one workgroup
+ * does all of it.  fp32 arithmetic, fixed summation order either way (deterministic for a given scratch choice).
  * ------------------------------------------------------------------------- */
+#define KRS_BCE_MAX_BLOCKS 64
 int krs_bce_fwd_bwd(const void* pred, int pred_dtype, const float* labels, int64_t n, float epsilon,
-                    float grad_scale, float* loss, void* dpred, void* stream);
+                    float grad_scale, float* loss, void* dpred, float* partials, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * K6  Row-sharded lookup: route / unpack / combine (the id side of the exchange)

@@ -295,8 +295,8 @@ class EmbedBagFn(torch.autograd.Function):
         # later: DistributedEmbedding.check_ids); False / None = no report.
         lazy = isinstance(check_ids, torch.Tensor)
         err = check_ids if lazy else (torch.zeros(1, dtype=torch.int32, device=ids.device) if check_ids else None)
-        out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
-                                  out_dtype=out_dtype, want_scale=True, err_flag=err)
+        out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights, out_dtype=out_dtype,
+                                  want_scale=any(comb != L.SUM for _, comb, _ in bags.features), err_flag=err)
         if check_ids is True and int(err.item()) & L.FLAG_ID_OUT_OF_RANGE:
             raise IndexError("embedding id out of range for its table (ids are never clamped)")
         ctx.bags, ctx.batch, ctx.hots = bags, batch, hots
@@ -340,9 +340,12 @@ class EmbedBagFusedFn(torch.autograd.Function):
         # (queued behind the gather it ran under the first FeatureCross GEMMs and slowed them by 0.4 ms).
         ctx.plan = None
         plan_first = not _PLAN_AFTER_GATHER
+        # the per-bag combiner scale (1 / sum w, 1 / sqrt(sum w^2)) is what the backward multiplies by: all ones for
+        # "sum" bags, which then neither write it here nor gather it per lookup there
+        want_scale = any(comb != L.SUM for _, comb, _ in bags.features)
         if not plan_first:
             out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
-                                      out=slab[:, lead:], want_scale=True, err_flag=err_flag)
+                                      out=slab[:, lead:], want_scale=want_scale, err_flag=err_flag)
         if ctx.needs_input_grad[8]:  # a backward will follow (not under torch.no_grad())
             main = torch.cuda.current_stream()
             side = _side_stream(ids.device)
@@ -365,7 +368,7 @@ class EmbedBagFusedFn(torch.autograd.Function):
         # never clamped); read later by the layer, so the step keeps running without a host sync
         if plan_first:
             out, scale = bags.forward(ids, batch, hots=hots, offsets=offsets, weights=weights,
-                                      out=slab[:, lead:], want_scale=True, err_flag=err_flag)
+                                      out=slab[:, lead:], want_scale=want_scale, err_flag=err_flag)
         ctx.bags, ctx.batch, ctx.hots, ctx.optimizer, ctx.lead = bags, batch, hots, optimizer, lead
         ctx.save_for_backward(ids, offsets, weights, scale)
         ctx.out_meta = (out.dtype, out.device)

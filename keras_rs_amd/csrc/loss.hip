@@ -7,8 +7,11 @@
 //     loss = mean( -(y log p + (1 - y) log(1 - p)) )
 // Forward and backward are ONE pass here (the prediction is read once): the loss scalar and
 //     dL/dpred_i = scale / n * ((1 - y_i) / (1 - p_i) - y_i / p_i)    (0 where the clip is active)
-// One workgroup walks the n predictions (n = the batch: 65,536 at C3, 128 KB of input): per-thread sums over a fixed
-// stride, then a fixed-order tree in LDS, so the loss is run-to-run bit-identical (no atomics).
+// Per-thread sums over a fixed stride, a fixed-order tree in LDS per workgroup, and -- with the caller's `partials`
+// scratch (KRS_BCE_MAX_BLOCKS floats) -- one partial per workgroup added in workgroup order by a second tiny launch:
+// the loss is run-to-run bit-identical (no atomics).  Without scratch ONE workgroup walks all n predictions.
+#include <algorithm>
+
 #include "krs_common.h"
 
 namespace krs {
@@ -18,11 +21,11 @@ constexpr int kBceThreads = 1024;
 
 template <typename T>
 __global__ __launch_bounds__(kBceThreads) void bce_kernel(const T* pred, const float* labels, int64_t n, float eps,
-                                                          float scale, float* loss, T* dpred) {
+                                                          float scale, float* loss, T* dpred, float* partials) {
   __shared__ float part[kBceThreads];
   const float hi = 1.0f - eps, inv_n = 1.0f / (float)n;
   float acc = 0.0f;
-  for (int64_t i = threadIdx.x; i < n; i += kBceThreads) {
+  for (int64_t i = (int64_t)blockIdx.x * kBceThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBceThreads) {
     float x;
     if constexpr (sizeof(T) == 2) x = bf16_to_f32(pred[i]);
     else x = pred[i];
@@ -42,26 +45,38 @@ __global__ __launch_bounds__(kBceThreads) void bce_kernel(const T* pred, const f
     if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *loss = part[0] * inv_n;
+  if (threadIdx.x == 0) {
+    if (partials) partials[blockIdx.x] = part[0];
+    else *loss = part[0] * inv_n;
+  }
+}
+
+__global__ void bce_finish_kernel(const float* partials, int n_blocks, int64_t n, float* loss) {
+  float s = 0.0f;
+  for (int b = 0; b < n_blocks; ++b) s += partials[b];     // workgroup order
+  *loss = s / (float)n;
 }
 
 }  // namespace
 }  // namespace krs
 
 extern "C" int krs_bce_fwd_bwd(const void* pred, int pred_dtype, const float* labels, int64_t n, float epsilon,
-                               float grad_scale, float* loss, void* dpred, void* stream) {
+                               float grad_scale, float* loss, void* dpred, float* partials, void* stream) {
   using namespace krs;
   KRS_REQUIRE(pred && labels && loss, "bce: null argument");
   KRS_REQUIRE(n > 0, "bce: empty batch");
   KRS_REQUIRE(pred_dtype == KRS_F32 || pred_dtype == KRS_BF16, "bce: bad dtype");
   KRS_REQUIRE(epsilon > 0.0f && epsilon < 0.5f, "bce: epsilon must be in (0, 0.5)");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = partials ? (int)std::min<int64_t>(KRS_BCE_MAX_BLOCKS, ceil_div(n, kBceThreads)) : 1;
+  if (blocks == 1) partials = nullptr;
   if (pred_dtype == KRS_BF16)
-    hipLaunchKernelGGL(bce_kernel<uint16_t>, dim3(1), dim3(kBceThreads), 0, st, reinterpret_cast<const uint16_t*>(pred),
-                       labels, n, epsilon, grad_scale, loss, reinterpret_cast<uint16_t*>(dpred));
+    hipLaunchKernelGGL(bce_kernel<uint16_t>, dim3(blocks), dim3(kBceThreads), 0, st, reinterpret_cast<const uint16_t*>(pred),
+                       labels, n, epsilon, grad_scale, loss, reinterpret_cast<uint16_t*>(dpred), partials);
   else
-    hipLaunchKernelGGL(bce_kernel<float>, dim3(1), dim3(kBceThreads), 0, st, reinterpret_cast<const float*>(pred), labels,
-                       n, epsilon, grad_scale, loss, reinterpret_cast<float*>(dpred));
+    hipLaunchKernelGGL(bce_kernel<float>, dim3(blocks), dim3(kBceThreads), 0, st, reinterpret_cast<const float*>(pred), labels,
+                       n, epsilon, grad_scale, loss, reinterpret_cast<float*>(dpred), partials);
+  if (partials) hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(1), 0, st, partials, blocks, n, loss);
   KRS_CHECK_LAUNCH("krs_bce_fwd_bwd");
   return KRS_OK;
 }

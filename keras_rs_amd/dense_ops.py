@@ -263,7 +263,8 @@ def bce_fwd_bwd(pred: torch.Tensor, labels: torch.Tensor, epsilon: float = 1e-7,
         raise L.KrsError(f"bce: {p.numel()} predictions but {y.numel()} labels")
     loss = torch.empty((), dtype=torch.float32, device=pred.device)
     dp = torch.empty_like(p) if want_grad else None
+    scratch = torch.empty(64, dtype=torch.float32, device=pred.device)     # KRS_BCE_MAX_BLOCKS partial sums
     rc = L.lib().krs_bce_fwd_bwd(L.ptr(p), C.c_int(L.fdtype(p)), L.ptr(y), C.c_int64(p.numel()), C.c_float(epsilon),
-                                 C.c_float(grad_scale), L.ptr(loss), L.ptr(dp), L.stream_ptr())
+                                 C.c_float(grad_scale), L.ptr(loss), L.ptr(dp), L.ptr(scratch), L.stream_ptr())
     L.check(rc, "krs_bce_fwd_bwd")
     return loss, (None if dp is None else dp.reshape(pred.shape))
