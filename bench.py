@@ -648,6 +648,13 @@ def main():
         torch.distributed.destroy_process_group()
     if rank != 0:
         return
+    # (RCCL writes its version banner through C stdio: push it out now, so that the JSON line is the LAST line)
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
 
     def describe(hots):
         return "multi-hot ml_perf lengths (sum L = %d)" % sum(hots) if sum(hots) > len(hots) else "hotness L = 1"

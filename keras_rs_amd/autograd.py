@@ -90,13 +90,19 @@ class SlabGradRelay:
     (krs_dot_interaction_bwd_accumulate) and returns no gradient for them.  The leading inputs (the bottom-MLP
     output) keep their ordinary gradient tensors, so whatever else consumes them is unaffected.  Not used when
     the concat result is still referenced and retains its gradient or has hooks (its .grad would show the joined
-    value), nor when one of the slab's feature views does (it would see no gradient from the interaction)."""
+    value), nor when one of the slab's feature views does (it would see no gradient from the interaction), nor once
+    the slab has a second consumer (a second concat of the same features).  Known limit: a gradient of the concat
+    result CAPTURED by torch.autograd.grad(..., inputs=[concat_out]) is the very tensor the interaction adds into,
+    so it shows the joined value (the engine exposes no way to see a capture from inside a backward)."""
 
-    __slots__ = ("buf", "task", "out_ref")
+    __slots__ = ("buf", "task", "out_ref", "disabled")
     joined = 0   # times the in-kernel path was taken (read by the tests)
 
     def __init__(self):
         self.buf, self.task, self.out_ref = None, -1, None
+        # set when the slab got a second consumer (a second concat of the same features): autograd then sums the two
+        # gradients of the slab in a buffer of its own, and an in-place add into the first one could be lost
+        self.disabled = False
 
 
 class CrossLayerFn(torch.autograd.Function):
@@ -418,7 +424,7 @@ class SlabFillFn(torch.autograd.Function):
         if relay is not None:
             # (a concat result nobody holds any more cannot show its .grad to anyone)
             out = relay.out_ref() if relay.out_ref is not None else None
-            plain = out is None or (not out.retains_grad and not out._backward_hooks)
+            plain = (out is None or (not out.retains_grad and not out._backward_hooks)) and not relay.disabled
             task = torch._C._current_graph_task_id()
             relay.buf, relay.task = (g, task) if (plain and task != -1 and g.is_contiguous()) else (None, -1)
         return (g, None) + tuple(g[:, a:b] for a, b in ctx.cols)

@@ -164,8 +164,9 @@ def make_layers(keras) -> types.SimpleNamespace:
         by keras_rs_amd.layers.DistributedEmbedding: the hook set `_sparsecore_{init,build,preprocess,call,
         get_embedding_tables}` (base:990-1042) is that class's; this wrapper gives it the Keras layer protocol.
         'default_device' tables are exposed as trainable Keras weights (the model optimizer updates them, as in the
-        reference), 'sparsecore' tables and their optimizer slots as non-trainable ones (updated inside the
-        backward, jax/embedding_lookup.py:174-273), so checkpoints written through Keras contain all of them."""
+        reference), 'sparsecore' tables as non-trainable ones (updated inside the backward,
+        jax/embedding_lookup.py:174-273); the optimizer slots and step counts of the fused optimizers are written to /
+        read from Keras checkpoints by save_own_variables / load_own_variables below."""
 
         def __init__(self, feature_configs, *, table_stacking="auto", update_stats=False, **kwargs: Any):
             super().__init__(**kwargs)
@@ -186,6 +187,38 @@ def make_layers(keras) -> types.SimpleNamespace:
                 for name, p in self._impl.named_parameters():
                     track(keras.Variable(p, trainable=bool(p.requires_grad), name=name))
             self.built = True
+
+        # Keras checkpoints (.keras / .weights.h5, model.save_weights) call these two per layer.  The tables are
+        # tracked variables, but the fused optimizers' slot planes are module buffers and their step counts live in
+        # the module's extra state: written through the default path alone, a restore would silently reset the
+        # Adagrad / Adam / FTRL accumulators and Adam's bias-correction step.  So the layer writes its WHOLE state
+        # itself: every entry of the torch state_dict (tables or stacks, slot planes; bf16 as float32, which holds
+        # it exactly) plus the per-group iteration counts.  Counterpart of the slot variables the reference adds to
+        # the layer (jax/distributed_embedding.py:316-345) so that they are checkpointed with it.
+        def save_own_variables(self, store):
+            import numpy as np
+
+            sd = self._impl.state_dict()
+            extra = sd.pop("_extra_state", None)
+            for k, v in sd.items():
+                store[k] = (v.float() if v.dtype == torch.bfloat16 else v).detach().cpu().numpy()
+            its = (extra or {}).get("iterations", {})
+            for k, n in its.items():
+                store["iterations/" + k] = np.asarray(int(n), np.int64)
+
+        def load_own_variables(self, store):
+            if not self.built:
+                self.build(None)
+            sd = self._impl.state_dict()
+            extra = sd.pop("_extra_state", None)
+            missing = [k for k in sd if k not in store]
+            if missing:
+                raise ValueError(f"DistributedEmbedding.load_own_variables: the checkpoint lacks {missing}")
+            new = {k: torch.as_tensor(store[k][...]).to(v.dtype) for k, v in sd.items()}
+            its = {k: int(store["iterations/" + k][...]) for k in (extra or {}).get("iterations", {})
+                   if "iterations/" + k in store}
+            new["_extra_state"] = {"iterations": its}
+            self._impl.load_state_dict(new)
 
         def preprocess(self, inputs, weights=None, training=False):
             return self._impl.preprocess(inputs, weights, training)

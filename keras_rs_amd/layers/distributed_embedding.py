@@ -864,6 +864,7 @@ def concat_features(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
                 out = SlabFillFn.apply(slab, relay, *heads)
                 relay.out_ref = weakref.ref(out)
                 return out
+            slab_grad_relay(slab).disabled = True     # a second consumer of the slab: no in-place gradient join
             return torch.cat(heads + [slab[:, lead:]], dim=-1)
     return torch.cat(tensors, dim=-1)
 

@@ -7,7 +7,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.argv = [sys.argv[0], "--no-cpu-baseline", "--force-sharded", "--batch", sys.argv[1] if len(sys.argv) > 1 else "8192"]
+sys.argv = [sys.argv[0], "--no-cpu-baseline", "--force-sharded", "--batch", sys.argv[1] if len(sys.argv) > 1 else "8192",
+            "--exchange", sys.argv[2] if len(sys.argv) > 2 else "static"]
 import torch
 
 import bench
@@ -19,7 +20,7 @@ model = bench.Model(a, hots, 1, 0)
 model.embedding.build(None)
 box = [None]
 bench.measure(model, a, hots, 1, 0, dev, a.batch, 2, 3, box)
-el, _ = bench.measure(model, a, hots, 1, 0, dev, a.batch, 30, 3, box)
+el = bench.measure(model, a, hots, 1, 0, dev, a.batch, 30, 3, box)["elapsed"]
 print("synchronised ms_per_step %.3f" % (el / 30 * 1e3))
 # host-only: profile the python side of 20 steps
 pr = cProfile.Profile()

@@ -798,6 +798,9 @@ def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
         else:
             inter = kl.DotInteraction(dtype=policy)(feats)
             x0 = kl.concat_features(feats)
+        extra = None
+        if mode == "second_concat":      # the slab gets a second consumer: its gradients are summed by autograd,
+            extra = kl.concat_features(feats)       # so nothing may be added into one of them in place
         if mode == "retain":
             x0.retain_grad()
         if mode == "watch_view":
@@ -806,7 +809,10 @@ def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
         if mode == "dropped":     # a model's forward returns and the concat result is referenced by the graph only
             del x0, feats, emb
         before = SlabGradRelay.joined
-        ((y.float() ** 2).sum() + (inter.float() * w_dot).sum()).backward()
+        loss = (y.float() ** 2).sum() + (inter.float() * w_dot).sum()
+        if extra is not None:
+            loss = loss + 0.5 * (extra.float() ** 2).sum()
+        loss.backward()
         took = SlabGradRelay.joined - before
         gx0 = x0.grad.clone() if mode == "retain" else None
         return took, dense.grad.float().clone(), {k: v.float().clone() for k, v in layer.get_embedding_tables().items()}, gx0
@@ -824,3 +830,10 @@ def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
             torch.testing.assert_close(tabs[k], tabs_m[k], **tol)
         if gx0 is not None:   # the retained gradient of the concat is the cross layer's alone
             assert gx0.shape == (B, 4 * D_) and torch.isfinite(gx0.float()).all()
+    # a second concat of the same features: the join must step aside, and the gradients must hold the extra term
+    took_s, gd_s, tabs_s, _ = run("second_concat")
+    assert took_s == 0 and not torch.equal(gd_s, gd)
+    # ... the same numbers as a plain-torch composition of that loss on the joined run's inputs (dense gradient only:
+    # d(0.5 |extra|^2)/d(dense) = dense)
+    dense0 = torch.linspace(-1, 1, B * D_, device=DEV).reshape(B, D_).to(dt).float()
+    torch.testing.assert_close(gd_s, gd + dense0, **tol)
