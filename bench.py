@@ -471,6 +471,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     for i in range(steps):
         step()
         marks[i + 1].record()     # step boundaries on the launch stream: per-step GPU time, no host wait
+    enqueue_s = time.perf_counter() - t0     # the host has ENQUEUED every step; the device may still be running
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -480,7 +481,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    res = {"elapsed": elapsed, "k1_s": k1_s,
+    res = {"elapsed": elapsed, "k1_s": k1_s, "enqueue_s": enqueue_s,
            "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
     if probe_steps > 0:
         from keras_rs_amd import probe
@@ -493,7 +494,12 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         res["probe_steps"] = probe_steps
         if not sharded:
             # unique touched rows (K2's algorithmic bytes need them): measurement bookkeeping, outside every timed region
-            res["unique_rows"] = int(sum(torch.unique(v.reshape(-1)).numel() for v in ids.values()))
+            uniq = 0
+            for t, v in enumerate(ids.values()):      # a touched-row mask per table (no sort: keeps foreign kernels out of the traces)
+                mask = torch.zeros(a.vocabs[t], dtype=torch.bool, device=dev)
+                mask[v.reshape(-1).long()] = True
+                uniq += int(mask.sum())
+            res["unique_rows"] = uniq
     ex = getattr(model.embedding, "last_exchange", None)
     if ex:
         res["exchange"] = dict(ex)
@@ -523,9 +529,15 @@ def roofline_step(a, hots, b_local, res):
         slot = 8 if a.rowwise_adagrad else 2 * d * 4
         alg = bags * d * 2 + nnz * 12 + u * (2 * d * 2 + slot)
         sec = pr["k2_apply"]["ms_total"] / n * 1e-3
-        out.append({"kernel": "bag_apply_kernel<adagrad> (K2 apply, krs_embed_bag_bwd_fused_adagrad)", "bound": "hbm",
+        traffic = None
+        if not a.criteo_vocab and a.id_skew == 0 and not a.rowwise_adagrad and a.batch == 65536 and a.vocab == 1_000_000 \
+                and list(hots) == (ML_PERF_HOTS * 8)[: a.tables] and a.tables == 26:
+            traffic = pmc_traffic_key("bag_apply_fast_kernel<adagrad> multi-hot")
+        out.append({"kernel": "bag_apply_fast_kernel<adagrad> (K2 apply, krs_embed_bag_bwd_fused_adagrad)", "bound": "hbm",
                     "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK,
-                    "launch_us": sec * 1e6, "algorithmic_bytes": alg, "unique_rows": u, "traffic": None})
+                    "launch_us": sec * 1e6, "algorithmic_bytes": alg, "unique_rows": u, "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes of this kernel at this shape; Infinity-Cache hits are counted, not excluded)"})
     if "gemm" in pr:
         fl = pr["gemm"]["work_total"] / n
         sec = pr["gemm"]["ms_total"] / n * 1e-3
@@ -552,6 +564,14 @@ def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False):
                               "passes of this kernel at this shape (counters cannot be read inside this run)",
             "launch_us": k1_s * 1e6,
             "algorithmic_bytes": alg}
+
+
+def pmc_traffic_key(key):
+    try:
+        with open(os.path.join(ROOT, "profiles", "k1_pmc.json")) as f:
+            return json.load(f)[key]["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def pmc_traffic(kernel):
@@ -704,6 +724,9 @@ def main():
                             else f"tables MOD row-sharded over {world} GPUs, dense part DP"),
         },
         "step_stats": step_stats(r1["step_ms"]),
+        # host time to ENQUEUE one step (the loop returns before the device has finished): below ms_per_step = the host
+        # runs ahead of the GPU and the step is GPU-bound; equal to it = the host is the limit (e.g. a wait inside the step)
+        "host_enqueue_ms_per_step": r1["enqueue_s"] / a.steps * 1e3,
     }
     if sharded and "exchange" in r1:
         ex = r1["exchange"]
