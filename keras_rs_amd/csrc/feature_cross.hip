@@ -989,6 +989,13 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // products with heavy epilogues, 256 x 128 tiles on a three-stage ring at TWO workgroups per CU, so that one's
 // epilogue runs under the other's main loop (467 / 344 us against 450 / 323: 1.5x the operand bytes per flop cost
 // more than the overlap returns).
+// cache policy of the ring's LDS-DMA loads (development builds: scripts/exp/build_variants.sh): 0 = default, 2 = nt, 16 = sc1
+#ifndef KRS_PP_A_AUX
+#define KRS_PP_A_AUX 0
+#endif
+#ifndef KRS_PP_B_AUX
+#define KRS_PP_B_AUX 0
+#endif
 #ifndef KRS_PP_PROBE
 #define KRS_PP_PROBE 0  // development builds only (scripts/exp): 1 = DMA stream alone, 2 = LDS reads + MFMA alone, 3 = DMA + LDS reads, 4 = epilogue alone
 #endif
@@ -1112,7 +1119,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     if constexpr (KRS_PP_PROBE == 2) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr)ap[i], (lptr)(smem + stage * pp::STAGE + dma_off + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)ap[i], (lptr)(smem + stage * pp::STAGE + dma_off + i * 1024), 16, 0, KRS_PP_A_AUX);
       ap[i] += astep;
     }
   };
@@ -1121,7 +1128,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       __builtin_amdgcn_global_load_lds((gptr)bp[i], (lptr)(smem + stage * pp::STAGE + pp::PIECE + dma_off + i * 1024), 16,
-                                       0, 0);
+                                       0, KRS_PP_B_AUX);
       bp[i] += bstep;
     }
   };
