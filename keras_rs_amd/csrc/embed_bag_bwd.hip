@@ -78,9 +78,15 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // summation order in the apply kernels).  Dense bags: the first pass computes keys and values from the ids on the
 // fly (no key generation kernel, no round trip of 12 bytes per lookup through HBM).
 namespace rs {
-constexpr int kTile = 4096, kMaxBits = 10, kMaxBins = 1 << kMaxBits;
+#ifndef KRS_SORT_TILE
+#define KRS_SORT_TILE 4096       // (development builds vary the tile / workgroup shape: scripts/exp/build_variants.sh)
+#endif
+#ifndef KRS_SORT_THREADS
+#define KRS_SORT_THREADS 512
+#endif
+constexpr int kTile = KRS_SORT_TILE, kMaxBits = 10, kMaxBins = 1 << kMaxBits;
 constexpr int kHistThreads = 256, kHistItems = kTile / kHistThreads;
-constexpr int kThreads = 512, kWaves = kThreads / 64, kItems = kTile / kThreads;   // scatter: 8 waves x 512 lookups
+constexpr int kThreads = KRS_SORT_THREADS, kWaves = kThreads / 64, kItems = kTile / kThreads;   // scatter: 8 waves x 512 lookups
 constexpr int kGenFeats = 256;   // features whose descriptors the generating pass caches in LDS
 constexpr int kMaxProb = 128;    // tables (problems) of the table-segmented sort
 

@@ -4,9 +4,10 @@
 set -e
 R=$(cd $(dirname $0)/../.. && pwd)
 name=$1; shift
+src=${KRS_VARIANT_SRC:-feature_cross}      # which csrc/<src>.hip gets the -D settings
 mkdir -p $R/scripts/exp/libs/$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I $R/include "$@" \
-  -c $R/keras_rs_amd/csrc/feature_cross.hip -o $R/scripts/exp/libs/$name/feature_cross.o
-objs=$(ls $R/keras_rs_amd/build/*.o | grep -v feature_cross)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/scripts/exp/libs/$name/libkrs_hip.so $R/scripts/exp/libs/$name/feature_cross.o $objs
+  -c $R/keras_rs_amd/csrc/$src.hip -o $R/scripts/exp/libs/$name/$src.o
+objs=$(ls $R/keras_rs_amd/build/*.o | grep -v "/$src")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/scripts/exp/libs/$name/libkrs_hip.so $R/scripts/exp/libs/$name/$src.o $objs
 echo built $R/scripts/exp/libs/$name/libkrs_hip.so
