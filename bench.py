@@ -20,6 +20,9 @@ gather+POOL; examples/ml_perf/configs/v6e_8.py), the L = 1 variant is reported u
 (`--hotness 1` swaps them).
 With N > 1 the tables are MOD row-sharded over the ranks (C4), B_local = 65,536 / N.
 
+The K timed steps run with Python's cyclic garbage collector switched off (reference counting still frees every
+tensor): a full collection inside the region starves the GPU for a whole step on a fresh box.
+
 Prints ONE JSON line (rank 0) with `value` = whole-job embedding lookups/s, `ms_per_step` =
 the DCN fwd+bwd step time, a `roofline` object for K1 measured live with HIP events on the
 launch stream, and a `cpu_baseline` object (the oracle timed on this box's host cores on a
@@ -406,7 +409,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
             params = [p for layer in model.cross for p in layer.parameters()]
             from keras_rs_amd.optim import Adagrad   # torch.optim.Adagrad's arithmetic, one launch (krs_dense_adagrad)
 
-            opt_box[0] = Adagrad(params, lr=0.0034, initial_accumulator_value=0.1)
+            opt_box[0] = Adagrad(params, lr=0.0034, initial_accumulator_value=0.1, prepare_casts=True)
             if dp:
                 # dense weights are data-parallel: from the next backward on, each gradient's all-reduce starts
                 # the moment autograd has produced it and overlaps the rest of the backward pass
@@ -462,6 +465,14 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         torch.cuda.synchronize()
     k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # The timed region runs without the cyclic garbage collector: a full collection of a process that has imported
+    # torch walks ~10^6 objects (tens of milliseconds) and, when it lands inside the K steps, starves the GPU for a
+    # whole step -- the first run of this file on a fresh box did that once per run (one 55 ms step among 10.4 ms ones).
+    # Reference counting frees the step's tensors as before; the collector is switched back on behind the region.
+    import gc
+
+    gc.collect()
+    gc.disable()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -477,6 +488,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -128,7 +128,7 @@ def train_step(model, opt_box, inputs, labels):
         dense_params = [p for p in model.parameters() if p.requires_grad]
         from keras_rs_amd.optim import Adagrad
 
-        opt_box[0] = Adagrad(dense_params, lr=0.0034, initial_accumulator_value=0.1)
+        opt_box[0] = Adagrad(dense_params, lr=0.0034, initial_accumulator_value=0.1, prepare_casts=True)
     opt_box[0].step()
     opt_box[0].zero_grad(set_to_none=True)
     return loss.detach()

@@ -335,6 +335,11 @@ int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const v
 int krs_cast_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, int src_dtype,
                        void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int dst_dtype,
                        void* stream);
+/* The same for several contiguous weights in ONE launch (the bf16 copies of every dense kernel of a model, refreshed
+ * behind the optimizer step): srcs[i] is [rows[i], cols[i]] row-major, dsts[i] (same shape) and / or dst_ts[i]
+ * ([cols[i], rows[i]]) receive the cast copy / its transpose; either output pointer of a tensor may be NULL. */
+int krs_cast_transpose_many(int count, const void* const* srcs, const int64_t* rows, const int64_t* cols,
+                            int src_dtype, void* const* dsts, void* const* dst_ts, int dst_dtype, void* stream);
 
 /* Backward of the bias + activation epilogue of a Dense layer (keras.layers.Dense inside the DLRM MLP blocks,
  * examples/ml_perf/model.py:214-262): dz [m,n] = g * act'(y) with the derivative taken from the saved output y

@@ -77,6 +77,7 @@ SYMBOLS = [
     "krs_cross_epilogue_bwd",
     "krs_colsum",
     "krs_cast_transpose",
+    "krs_cast_transpose_many",
     "krs_dense_adagrad",
     "krs_dense_act_bwd",
     "krs_dot_interaction_fwd",

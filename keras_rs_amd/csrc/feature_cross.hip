@@ -2351,6 +2351,72 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const void* src, in
   }
 }
 
+// Several weights in ONE launch (the per-step bf16 copies of every dense kernel, refreshed right behind the optimizer
+// step: six launch-bound 15 us kernels per FeatureCross stack become one).  Contiguous sources and outputs.
+constexpr int kCastMax = 32;
+struct CastManyArgs {
+  const void* src[kCastMax];
+  void* dst[kCastMax];
+  void* dst_t[kCastMax];
+  int32_t rows[kCastMax], cols[kCastMax];
+  int32_t tile_end[kCastMax];    // inclusive prefix of the tensors' 64 x 64 tile counts
+  int count, src_dtype, dst_dtype;
+};
+__global__ __launch_bounds__(256) void cast_transpose_many_kernel(const CastManyArgs a) {
+  __shared__ float tile[64][65];
+  int t = 0;
+  while (t + 1 < a.count && (int)blockIdx.x >= a.tile_end[t]) ++t;
+  const void* src = nullptr; void* dst = nullptr; void* dst_t = nullptr; int64_t rows = 0, cols = 0; int first = 0;
+#pragma unroll
+  for (int i = 0; i < kCastMax; ++i)   // static kernarg indices
+    if (i == t) { src = a.src[i]; dst = a.dst[i]; dst_t = a.dst_t[i]; rows = a.rows[i]; cols = a.cols[i]; first = i ? a.tile_end[i - 1] : 0; }
+  const int tiles_x = (int)ceil_div(cols, 64);
+  const int tid = (int)blockIdx.x - first;
+  const int64_t r0 = (int64_t)(tid / tiles_x) * 64, c0 = (int64_t)(tid % tiles_x) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t r = r0 + ty * 16 + k, c = c0 + tx;
+    if (r < rows && c < cols) {
+      const float v = ld_elem(src, a.src_dtype, r * cols + c);
+      tile[ty * 16 + k][tx] = v;
+      if (dst) st_elem(dst, a.dst_dtype, r * cols + c, v);
+    }
+  }
+  if (!dst_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int64_t c = c0 + ty * 16 + k, r = r0 + tx;   // dst_t[c][r] = src[r][c]
+    if (r < rows && c < cols) st_elem(dst_t, a.dst_dtype, c * rows + r, tile[tx][ty * 16 + k]);
+  }
+}
+
+extern "C" int krs_cast_transpose_many(int count, const void* const* srcs, const int64_t* rows, const int64_t* cols,
+                                       int src_dtype, void* const* dsts, void* const* dst_ts, int dst_dtype, void* stream) {
+  KRS_REQUIRE(count >= 0 && (count == 0 || (srcs && rows && cols && dsts && dst_ts)), "cast_transpose_many: null list");
+  KRS_REQUIRE((src_dtype == KRS_F32 || src_dtype == KRS_BF16) && (dst_dtype == KRS_F32 || dst_dtype == KRS_BF16),
+              "cast_transpose_many: dtype must be f32 or bf16");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int lo = 0; lo < count; lo += kCastMax) {
+    CastManyArgs a{};
+    a.count = std::min(kCastMax, count - lo);
+    a.src_dtype = src_dtype; a.dst_dtype = dst_dtype;
+    int tiles = 0;
+    for (int i = 0; i < a.count; ++i) {
+      KRS_REQUIRE(srcs[lo + i] && (dsts[lo + i] || dst_ts[lo + i]) && rows[lo + i] > 0 && cols[lo + i] > 0 &&
+                      rows[lo + i] < 0x7fffffff && cols[lo + i] < 0x7fffffff, "cast_transpose_many: bad tensor %d", lo + i);
+      a.src[i] = srcs[lo + i]; a.dst[i] = dsts[lo + i]; a.dst_t[i] = dst_ts[lo + i];
+      a.rows[i] = (int32_t)rows[lo + i]; a.cols[i] = (int32_t)cols[lo + i];
+      tiles += (int)(ceil_div(rows[lo + i], 64) * ceil_div(cols[lo + i], 64));
+      a.tile_end[i] = tiles;
+    }
+    hipLaunchKernelGGL(cast_transpose_many_kernel, dim3((unsigned)tiles), dim3(256), 0, st, a);
+    KRS_CHECK_LAUNCH("cast_transpose_many_kernel");
+  }
+  return KRS_OK;
+}
+
 extern "C" int krs_cast_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, int src_dtype,
                                   void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int dst_dtype,
                                   void* stream) {

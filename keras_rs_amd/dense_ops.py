@@ -150,10 +150,26 @@ def dense_act_bwd(g: torch.Tensor, y: torch.Tensor | None, act: int, want_dbias:
     return (dz if need_dz else g), db
 
 
+def _cast_cache_key(w: torch.Tensor, dtype: torch.dtype):
+    return (w.data_ptr(), w._version, tuple(w.shape), w.dtype, dtype)
+
+
 def cast_transpose(w: torch.Tensor, dtype: torch.dtype, want_plain: bool = True, want_t: bool = True):
     """(w.to(dtype), w.to(dtype).t().contiguous()) of a 2-D weight in ONE launch (krs_cast_transpose); an output
-    that is not wanted is None; the plain one is `w` itself when it already has the dtype and is row-major."""
+    that is not wanted is None; the plain one is `w` itself when it already has the dtype and is row-major.
+
+    Parameters remember that they were asked for (`_krs_cast_want`): `refresh_casts` -- called by
+    keras_rs_amd.optim.Adagrad(prepare_casts=True) right behind its update -- then prepares the copies of ALL such
+    weights for the next step in one launch and leaves them on the parameter (`_krs_cast`), where this function finds
+    them ONCE (keyed by storage address, torch version, shape and dtypes)."""
     w = _rowmajor(w, "cast_transpose")
+    if isinstance(w, torch.nn.Parameter) and w.dtype != dtype and want_plain and want_t and w.is_contiguous():
+        hit = getattr(w, "_krs_cast", None)
+        if hit is not None:
+            w._krs_cast = None        # one use: the first forward behind the optimizer step that prepared it
+            if hit[0] == _cast_cache_key(w, dtype):
+                return hit[1], hit[2]
+        w._krs_cast_want = dtype
     rows, cols = w.shape
     plain = None
     if want_plain:
@@ -167,6 +183,29 @@ def cast_transpose(w: torch.Tensor, dtype: torch.dtype, want_plain: bool = True,
                                         C.c_int(L.fdtype(plain if plain is not None else wt)), L.stream_ptr())
         L.check(rc, "krs_cast_transpose")
     return plain, wt
+
+
+def refresh_casts(params) -> int:
+    """Cast + transposed copies of every parameter that a layer has asked `cast_transpose` for, in ONE launch
+    (krs_cast_transpose_many); to be called when the weights have just changed (behind the optimizer step: the C-ABI
+    update does not go through torch, so the copies are keyed by storage and version AFTER it).  Returns the count."""
+    todo = [p for p in params if getattr(p, "_krs_cast_want", None) is not None and p.is_cuda and p.dim() == 2
+            and p.is_contiguous()]
+    by_dtype: dict = {}
+    for p in todo:
+        by_dtype.setdefault((p.dtype, p._krs_cast_want), []).append(p)
+    for (sdt, ddt), ps in by_dtype.items():
+        n = len(ps)
+        plains = [torch.empty(tuple(p.shape), dtype=ddt, device=p.device) for p in ps]
+        trans = [torch.empty((p.shape[1], p.shape[0]), dtype=ddt, device=p.device) for p in ps]
+        ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+        rc = L.lib().krs_cast_transpose_many(
+            C.c_int(n), ptrs(ps), (C.c_int64 * n)(*[p.shape[0] for p in ps]), (C.c_int64 * n)(*[p.shape[1] for p in ps]),
+            C.c_int(L.fdtype(ps[0])), ptrs(plains), ptrs(trans), C.c_int(L.fdtype(plains[0])), L.stream_ptr())
+        L.check(rc, "krs_cast_transpose_many")
+        for p, a, b in zip(ps, plains, trans):
+            p._krs_cast = (_cast_cache_key(p, ddt), a, b)
+    return len(todo)
 
 
 def _ptr_table(ts: Sequence[torch.Tensor]):

@@ -12,10 +12,17 @@ from keras_rs_amd import _lib as L
 
 
 class Adagrad(torch.optim.Optimizer):
-    def __init__(self, params, lr: float = 0.01, initial_accumulator_value: float = 0.0, eps: float = 1e-10):
+    def __init__(self, params, lr: float = 0.01, initial_accumulator_value: float = 0.0, eps: float = 1e-10,
+                 prepare_casts: bool = False):
+        """prepare_casts: right behind the update, prepare the compute-dtype copies (plain + K-contiguous) that the
+        FeatureCross / Dense layers want of their kernels for the NEXT forward, for all weights in ONE launch instead
+        of one launch per weight inside the layers.  A copy is used once, by the first forward after this step, and
+        only if the weight's storage and torch version are what they were here -- so the loop must not modify the
+        weights behind torch's back (`p.data...` writes) between `step()` and that forward; off by default."""
         if lr < 0 or eps < 0 or initial_accumulator_value < 0:
             raise ValueError("Adagrad: lr, eps and initial_accumulator_value must be non-negative")
         super().__init__(params, dict(lr=lr, initial_accumulator_value=initial_accumulator_value, eps=eps))
+        self.prepare_casts = bool(prepare_casts)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -50,4 +57,10 @@ class Adagrad(torch.optim.Optimizer):
             rc = L.lib().krs_dense_adagrad(arr(ps), arr(gs), arr(accs), sizes, C.c_int(n), C.c_float(group["lr"]),
                                            C.c_float(group["eps"]), L.stream_ptr())
             L.check(rc, "krs_dense_adagrad")
+            # the bf16 copies (plain + K-contiguous) the GEMMs of the next step want, for every weight a layer has asked
+            # for, in one launch: the weights have just changed, and the C-ABI update is invisible to torch's versions
+            if self.prepare_casts:
+                from keras_rs_amd import dense_ops as D
+
+                D.refresh_casts(ps)
         return loss

@@ -837,3 +837,58 @@ def test_dot_interaction_gradient_joins_the_slab_gradient_in_the_kernel(policy):
     # d(0.5 |extra|^2)/d(dense) = dense)
     dense0 = torch.linspace(-1, 1, B * D_, device=DEV).reshape(B, D_).to(dt).float()
     torch.testing.assert_close(gd_s, gd + dense0, **tol)
+
+
+def test_prepared_casts_behind_the_optimizer_step():
+    """optim.Adagrad(prepare_casts=True) prepares the compute-dtype copies of every kernel a layer has asked for, for
+    the next forward, in one launch (krs_cast_transpose_many): the copies equal the casts of the UPDATED weights, are
+    handed out once, and are dropped when the weight changed through torch in between (version bump); training with and
+    without them agrees (to the last-bit noise of the atomically summed bias gradients)."""
+    from keras_rs_amd import dense_ops as D
+    from keras_rs_amd.layers import base as kl_base
+    from keras_rs_amd.optim import Adagrad
+
+    kl = _layers()
+
+    def make():
+        return [kl.FeatureCross(projection_dim=16, kernel_initializer=kl_base.GlorotUniform(seed=1), dtype="mixed_bfloat16"),
+                kl.FeatureCross(projection_dim=16, kernel_initializer=kl_base.GlorotUniform(seed=2), dtype="mixed_bfloat16"),
+                kl.Dense(8, activation="relu", kernel_initializer=kl_base.GlorotUniform(seed=3), dtype="mixed_bfloat16")]
+
+    g = torch.Generator(device=DEV).manual_seed(5)
+    xs = [torch.randn(96, 64, device=DEV, generator=g).to(torch.bfloat16) for _ in range(4)]
+
+    def run(prepare):
+        layers = make()
+        opt = None
+        outs = []
+        for x in xs:
+            y = layers[2](layers[1](x, layers[0](x, x)))
+            outs.append(y.detach().float().clone())
+            y.float().pow(2).sum().backward()
+            if opt is None:
+                opt = Adagrad([p for l in layers for p in l.parameters()], lr=0.05, initial_accumulator_value=0.1,
+                              prepare_casts=prepare)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        return layers, outs
+
+    layers, o1 = run(True)
+    _, o0 = run(False)
+    for a, b in zip(o0, o1):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=1e-3)
+    assert not torch.equal(o1[0], o1[3])
+    mats = [p for l in layers for p in l.parameters() if p.dim() == 2]
+    assert len(mats) == 5
+    for p in mats:
+        key, plain, trans = p._krs_cast                                  # prepared by the last step()
+        assert torch.equal(plain, p.detach().to(torch.bfloat16)) and torch.equal(trans, plain.t().contiguous())
+        a, b = D.cast_transpose(p, torch.bfloat16)
+        assert a is plain and b is trans and p._krs_cast is None          # handed out once
+        a2, b2 = D.cast_transpose(p, torch.bfloat16)                     # ... then the ordinary path
+        assert a2 is not plain and torch.equal(a2, plain) and torch.equal(b2, trans)
+    assert D.refresh_casts(mats) == 5
+    with torch.no_grad():
+        mats[0].mul_(0.5)                                                # through torch: version bump
+    a, _ = D.cast_transpose(mats[0], torch.bfloat16)
+    assert torch.equal(a, mats[0].detach().to(torch.bfloat16))
