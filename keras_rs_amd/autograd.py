@@ -24,6 +24,48 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+# Weight-gradient GEMMs of the cross layers on a second stream (see CrossLayerFn.backward): they are off the critical
+# path, and started behind a layer's dx product they run beside the HBM-bound dz / dx0 pass of the layer below (or the
+# DotInteraction gradient and the table update behind the bottom layer) -- an elementwise pass and a ring GEMM do overlap
+# a little on this part (scripts/exp/overlap_probe2.py: 563 + 271 us apart, 707 together), two GEMMs or a GEMM and the
+# table update do not.  Measured in the step: 10.31-10.48 -> 10.20-10.29 ms.  Deferring all six to the table update was
+# slower (10.49).  Environment KRS_WGRAD_SIDE=0 switches it off.
+WGRAD_SIDE_STREAM = bool(int(__import__("os").environ.get("KRS_WGRAD_SIDE", "1")))
+_WGRAD_STREAMS: dict = {}
+_WGRAD_SYNC_QUEUED: set = set()
+
+
+def _wgrad_stream(device) -> "torch.cuda.Stream":
+    key = str(device)
+    st = _WGRAD_STREAMS.get(key)
+    if st is None:
+        st = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def wgrad_stream_sync() -> None:
+    """The current stream waits for the weight-gradient stream(s): before anything reads those gradients (the end of
+    the backward pass does it by itself; dp.GradAllReduce calls it before it reduces a gradient)."""
+    for st in _WGRAD_STREAMS.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def _queue_wgrad_sync(task: int) -> None:
+    """Once per backward pass: rejoin the main stream when the graph task ends."""
+    if task in _WGRAD_SYNC_QUEUED:
+        return
+    if task == -1:          # not inside a backward pass (a direct call): rejoin at once
+        wgrad_stream_sync()
+        return
+    _WGRAD_SYNC_QUEUED.add(task)
+
+    def done():
+        _WGRAD_SYNC_QUEUED.discard(task)
+        wgrad_stream_sync()
+
+    torch.autograd.Variable._execution_engine.queue_callback(done)
+
+
 def _split_columns(out: torch.Tensor, n: int, dim: int, lead: int = 0):
     """Per-feature [B, dim] column views of the fused [B, lead + n*dim] lookup output."""
     return tuple(out[:, lead + i * dim:lead + (i + 1) * dim] for i in range(n))
@@ -165,7 +207,28 @@ class CrossLayerFn(torch.autograd.Function):
         if extra is not None:
             dx0 = dx0 + extra.to(dx0.dtype)
         direct = dx0 if same else (dxd if need_dxd else g)  # dL/dx through "+ x" and "diag * x"
-        if low_rank:
+        if low_rank and WGRAD_SIDE_STREAM and dz.is_cuda:
+            # Data-gradient path first; the two weight gradients (off the critical path: only the optimizer reads them)
+            # go to a second stream that starts when dx is done -- i.e. beside the HBM-bound kernel that follows on the
+            # main stream (the dz / dx0 pass of the layer below, or the DotInteraction gradient and the table update
+            # behind the bottom layer).  The main stream rejoins at the end of the backward pass (wgrad_stream_sync).
+            dh, _ = D.gemm(dz, kc, b_is_nk=True)                               # dh = dz K^T     [B, p]
+            dx, _ = D.gemm(dh, dc, b_is_nk=True, r=direct, beta=1.0)           # dx = dh U^T + direct
+            main = torch.cuda.current_stream()
+            side = _wgrad_stream(dz.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            dk = torch.empty((h.shape[1], dz.shape[1]), dtype=torch.float32, device=dz.device)
+            dd = torch.empty((xc.shape[1], dh.shape[1]), dtype=torch.float32, device=dz.device)
+
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32, out=dk)   # dK = h^T dz     [p, d]
+                D.gemm(xc, dh, a_is_km=True, out_dtype=torch.float32, out=dd)  # dU = x^T dh     [d, p]
+            for t in (h, dz, xc, dh, dk, dd):
+                t.record_stream(side)
+            _queue_wgrad_sync(task)
+        elif low_rank:
             dk, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)      # dK = h^T dz     [p, d]
             dh, _ = D.gemm(dz, kc, b_is_nk=True)                               # dh = dz K^T     [B, p]
             dd, _ = D.gemm(xc, dh, a_is_km=True, out_dtype=torch.float32)      # dU = x^T dh     [d, p]

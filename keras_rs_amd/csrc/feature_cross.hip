@@ -1744,7 +1744,9 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   // bf16 weight gradients: LDS-DMA + transposing reads (K extents in whole 64-row tiles, >= 8 columns)
   if (ES == 2 && p.a_km && !p.b_nk && p.k % 64 == 0 && p.k_per_split % 64 == 0 && p.m >= 8 && p.n >= 8 &&
       p.m % 8 == 0 && p.n % 8 == 0) {
-    if (p.m >= 256 && p.n >= 256) {
+    // development switch: the 128 x 128 twin (4 waves, <= 128 VGPRs, 64 KB of LDS: half a CU) for every shape
+    static const bool tn128 = getenv("KRS_GEMM_TN128") != nullptr;
+    if (p.m >= 256 && p.n >= 256 && !tn128) {
       const int mt_ = (int)ceil_div(p.m, 256), nt_ = (int)ceil_div(p.n, 256);
       const dim3 grid_tn((unsigned)(ceil_div((int64_t)p.splits * mt_ * nt_, 8) * 8));
       const int pipe = gemm_pipe();

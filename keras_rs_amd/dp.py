@@ -38,6 +38,11 @@ class GradAllReduce:
         were produced before the hooks existed)."""
         if not self._active or p.grad is None:
             return
+        if p.grad.is_cuda:
+            # a cross layer's weight gradients come off a second stream (autograd.WGRAD_SIDE_STREAM)
+            from keras_rs_amd.autograd import wgrad_stream_sync
+
+            wgrad_stream_sync()
         op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
         self._pending.append((dist.all_reduce(p.grad, op=op, group=self.group, async_op=True), p))
 

@@ -892,3 +892,40 @@ def test_prepared_casts_behind_the_optimizer_step():
         mats[0].mul_(0.5)                                                # through torch: version bump
     a, _ = D.cast_transpose(mats[0], torch.bfloat16)
     assert torch.equal(a, mats[0].detach().to(torch.bfloat16))
+
+
+def test_weight_gradients_on_the_second_stream_are_the_same_gradients():
+    """autograd.WGRAD_SIDE_STREAM: dK / dU of the cross layers are computed on a second stream that the main stream
+    rejoins at the end of the backward pass -- same kernels, same inputs: every gradient bit-identical to the
+    one-stream schedule, also when the optimizer step follows immediately (the rejoin must order it)."""
+    from keras_rs_amd import autograd as A
+    from keras_rs_amd.layers import base as kl_base
+    from keras_rs_amd.optim import Adagrad
+
+    kl = _layers()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x0 = torch.randn(4096, 512, device=DEV, generator=g).to(torch.bfloat16)
+
+    def run(side):
+        old = A.WGRAD_SIDE_STREAM
+        A.WGRAD_SIDE_STREAM = side
+        try:
+            layers = [kl.FeatureCross(projection_dim=64, kernel_initializer=kl_base.GlorotUniform(seed=i), dtype="mixed_bfloat16",
+                                      use_bias=False) for i in range(3)]
+            x = x0.clone().requires_grad_()
+            xl = x
+            for layer in layers:
+                xl = layer(x, xl)
+            xl.float().pow(2).mean().backward()
+            grads = [p.grad.clone() for layer in layers for p in layer.parameters()] + [x.grad.clone()]
+            opt = Adagrad([p for layer in layers for p in layer.parameters()], lr=0.01, initial_accumulator_value=0.1)
+            opt.step()                                       # right behind the backward: reads the side stream's results
+            torch.cuda.synchronize()
+            return grads + [p.detach().clone() for layer in layers for p in layer.parameters()]
+        finally:
+            A.WGRAD_SIDE_STREAM = old
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) == 13
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
