@@ -496,14 +496,19 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     res = {"elapsed": elapsed, "k1_s": k1_s, "enqueue_s": enqueue_s,
            "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
     if probe_steps > 0:
+        from keras_rs_amd import autograd as krs_autograd
         from keras_rs_amd import probe
 
+        # (the probe steps run the weight-gradient GEMMs on the main stream: beside the elementwise passes, as in the
+        #  timed steps, their event spans would measure the overlap, not the kernels)
+        side_was, krs_autograd.WGRAD_SIDE_STREAM = krs_autograd.WGRAD_SIDE_STREAM, False
         step()
         probe.start()
         for _ in range(probe_steps):
             step()
         res["probe"] = probe.stop()
         res["probe_steps"] = probe_steps
+        krs_autograd.WGRAD_SIDE_STREAM = side_was
         if not sharded:
             # unique touched rows (K2's algorithmic bytes need them): measurement bookkeeping, outside every timed region
             uniq = 0

@@ -31,6 +31,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # table update do not.  Measured in the step: 10.31-10.48 -> 10.20-10.29 ms.  Deferring all six to the table update was
 # slower (10.49).  Environment KRS_WGRAD_SIDE=0 switches it off.
 WGRAD_SIDE_STREAM = bool(int(__import__("os").environ.get("KRS_WGRAD_SIDE", "1")))
+WGRAD_SIDE_MIN_ROWS = 32768
 _WGRAD_STREAMS: dict = {}
 _WGRAD_SYNC_QUEUED: set = set()
 
@@ -41,6 +42,19 @@ def _wgrad_stream(device) -> "torch.cuda.Stream":
     if st is None:
         st = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
     return st
+
+
+def _wgrad_side_ok(w) -> bool:
+    """May this weight's gradient come off the second stream?  Only when nothing reads it before the end of the backward
+    pass: no gradient to accumulate into yet (the first accumulation is an assignment, a later one is an add kernel on
+    the main stream), no tensor hooks, and no post-accumulate hooks other than ones that rejoin the stream themselves
+    (dp.GradAllReduce marks its parameters)."""
+    if w is None:
+        return True
+    if w.grad is not None or w._backward_hooks:
+        return False
+    hooks = getattr(w, "_post_accumulate_grad_hooks", None)
+    return not hooks or bool(getattr(w, "_krs_hooks_rejoin_wgrad_stream", False))
 
 
 def wgrad_stream_sync() -> None:
@@ -179,6 +193,7 @@ class CrossLayerFn(torch.autograd.Function):
         ctx.meta = (diag_scale, act, same, down is not None, bias is not None,
                     x0.dtype, x.dtype, None if down is None else down.dtype, kernel.dtype)
         ctx.relay_in = relay_in
+        ctx.w_refs = tuple(weakref.ref(w) for w in (down, kernel) if w is not None)
         both = ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         ctx.relay_up = relay_up if (relay_up is not None and not same and both and relay_up.matches(x0)) else None
         return y
@@ -207,7 +222,10 @@ class CrossLayerFn(torch.autograd.Function):
         if extra is not None:
             dx0 = dx0 + extra.to(dx0.dtype)
         direct = dx0 if same else (dxd if need_dxd else g)  # dL/dx through "+ x" and "diag * x"
-        if low_rank and WGRAD_SIDE_STREAM and dz.is_cuda:
+        # (worth it when the kernels are long against a launch: at a per-rank batch of 8192 the step is bound by the
+        #  host's enqueue rate and the extra events cost more than the overlap returns: 2.42 -> 2.54 ms)
+        if low_rank and WGRAD_SIDE_STREAM and dz.is_cuda and dz.shape[0] >= WGRAD_SIDE_MIN_ROWS and \
+                all(_wgrad_side_ok(r()) for r in ctx.w_refs):
             # Data-gradient path first; the two weight gradients (off the critical path: only the optimizer reads them)
             # go to a second stream that starts when dx is done -- i.e. beside the HBM-bound kernel that follows on the
             # main stream (the dz / dx0 pass of the layer below, or the DotInteraction gradient and the table update

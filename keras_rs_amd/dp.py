@@ -32,6 +32,7 @@ class GradAllReduce:
             for p in params:
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self.launch))
+                    p._krs_hooks_rejoin_wgrad_stream = True     # launch() waits for autograd's weight-gradient stream
 
     def launch(self, p: torch.nn.Parameter) -> None:
         """Starts the reduction of `p.grad` (what the hook does; callable directly for gradients that

@@ -905,10 +905,11 @@ def test_weight_gradients_on_the_second_stream_are_the_same_gradients():
     kl = _layers()
     g = torch.Generator(device=DEV).manual_seed(3)
     x0 = torch.randn(4096, 512, device=DEV, generator=g).to(torch.bfloat16)
+    A_rows = 1024          # (the side stream is taken from this many rows on: lowered for the test)
 
     def run(side):
-        old = A.WGRAD_SIDE_STREAM
-        A.WGRAD_SIDE_STREAM = side
+        old, old_rows = A.WGRAD_SIDE_STREAM, A.WGRAD_SIDE_MIN_ROWS
+        A.WGRAD_SIDE_STREAM, A.WGRAD_SIDE_MIN_ROWS = side, A_rows
         try:
             layers = [kl.FeatureCross(projection_dim=64, kernel_initializer=kl_base.GlorotUniform(seed=i), dtype="mixed_bfloat16",
                                       use_bias=False) for i in range(3)]
@@ -923,9 +924,25 @@ def test_weight_gradients_on_the_second_stream_are_the_same_gradients():
             torch.cuda.synchronize()
             return grads + [p.detach().clone() for layer in layers for p in layer.parameters()]
         finally:
-            A.WGRAD_SIDE_STREAM = old
+            A.WGRAD_SIDE_STREAM, A.WGRAD_SIDE_MIN_ROWS = old, old_rows
 
     a, b = run(True), run(False)
     assert len(a) == len(b) == 13
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+    # gradient ACCUMULATION (a second backward into existing .grad: an add kernel on the main stream) and a user hook on
+    # a weight both read the gradient before the end of the pass: the layer must keep those on the main stream
+    layer = kl.FeatureCross(projection_dim=64, kernel_initializer=kl_base.GlorotUniform(seed=9), dtype="mixed_bfloat16")
+    xa = x0.clone().requires_grad_()
+    seen = []
+    A.WGRAD_SIDE_MIN_ROWS = A_rows
+    for rep in range(2):
+        layer(xa, xa).float().pow(2).mean().backward()
+        if rep == 0:
+            g1 = [p.grad.clone() for p in layer.parameters()]
+            layer.kernel.register_hook(lambda g: seen.append(g.clone()))
+    torch.cuda.synchronize()
+    for p, g in zip(layer.parameters(), g1):
+        torch.testing.assert_close(p.grad, 2 * g, rtol=1e-5, atol=1e-8)
+    A.WGRAD_SIDE_MIN_ROWS = 32768
+    assert len(seen) == 1 and torch.equal(seen[0], g1[[n for n, _ in layer.named_parameters()].index("kernel")])
