@@ -24,7 +24,9 @@ def _free_port():
     # static-capacity exchange (no size ever reaches the host): sized automatically, from the TableConfig limits, and
     # from a capacity the first steps overflow (ids dropped + flagged, limits learnt from the running statistics)
     ("adagrad", "w", 2, "static"), ("sgd", "now", 3, "static"), ("adam", "w", 2, "static_cfg"),
-    ("adagrad", "w", 2, "static_tiny"), ("sgd", "now", 3, "static_tiny"), ("adagrad", "wragged", 2, "static")])
+    ("adagrad", "w", 2, "static_tiny"), ("sgd", "now", 3, "static_tiny"), ("adagrad", "wragged", 2, "static"),
+    # the world the scaling run ends on (8 owners, every bag split over up to 8 partial sums)
+    ("adagrad", "w", 8, "static"), ("adagrad", "nowragged", 8, "exact")])
 def test_sharded_embedding_matches_unsharded_oracle(kind, weighted, world, exchange):
     # weighted: user weights on every feature; "now": none (mean / sqrtn scales are still folded in);
     # "...ragged": bags of varying length (some empty) given as Ragged values + row offsets
