@@ -318,7 +318,12 @@ int krs_embed_set_option(int key, int value);
  *              receives the sum of both lines and nothing else is written
  *        du  = dz = g*x0 * act'(z), act' written through u (relu: u>0,
  *              sigmoid: u(1-u), tanh: 1-u^2)
- *        dbias[n] = sum_m dz[m,n]         (optional) */
+ *        dbias[n] = sum_m dz[m,n]         (optional)
+ * Bias gradients (here, krs_dense_act_bwd, krs_colsum) are column sums over all m rows.  With a workspace of
+ * krs_colsum_workspace_bytes(m, n) bytes they are formed in two stages -- per row group, then over the groups in
+ * order -- and come out with the same bits on every run; with workspace == NULL the groups are added with fp32
+ * atomics, whose order (and so the last bits) varies from run to run. */
+size_t krs_colsum_workspace_bytes(int64_t m, int64_t n);
 int krs_cross_epilogue_fwd(const void* u, const void* x0, const void* x, void* y,
                            int64_t m, int64_t n, int64_t ld, float diag_scale,
                            int dtype, void* stream);
@@ -326,7 +331,7 @@ int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const v
                            void* du, void* dx0, int dx0_accumulate, void* dxd,
                            float* dbias,
                            int64_t m, int64_t n, int64_t ld, float diag_scale, int act,
-                           int dtype, void* stream);
+                           int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight preparation for the two GEMM layouts of a Dense / FeatureCross step: dst [rows, cols] = cast(src) and
  * dst_t [cols, rows] = cast(src)^T, either may be NULL.  What `ops.cast(kernel, compute_dtype)` +
@@ -346,7 +351,8 @@ int krs_cast_transpose_many(int count, const void* const* srcs, const int64_t* r
  * (relu: y > 0; sigmoid: y(1-y); tanh: 1-y^2; none: 1, y may be NULL) and dbias [n] = column sums of dz (fp32).
  * dz or dbias may be NULL. */
 int krs_dense_act_bwd(const void* g, int64_t ld_g, const void* y, int64_t ld_y, void* dz, int64_t ld_dz,
-                      float* dbias, int64_t m, int64_t n, int act, int dtype, void* stream);
+                      float* dbias, int64_t m, int64_t n, int act, int dtype, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* Adagrad step on a list of dense fp32 weights (the FeatureCross / Dense kernels and biases of one training step) in
  * one launch: acc += g*g; p -= lr * g / (sqrt(acc) + eps).  params / grads / accs / sizes: HOST arrays of `count`
@@ -358,7 +364,7 @@ int krs_dense_adagrad(float* const* params, const float* const* grads, float* co
 
 /* Column sum: out[n] = sum_m a[m,n] (fp32 out).  Dense bias gradient. */
 int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
-               float* out, void* stream);
+               float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * K4  DotInteraction

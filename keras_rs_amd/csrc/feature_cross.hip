@@ -1808,6 +1808,7 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
 struct CrossParams {
   const void* g; const void* u; const void* x0; const void* x;
   void* y; void* du; void* dx0; void* dxd; float* dbias;
+  float* partial;   // [row groups][n] partial column sums (workspace) -> colsum_finish_kernel; null: fp32 atomics on dbias
   int dx0_acc;
   int64_t m, n, ld;
   float diag;
@@ -1983,7 +1984,11 @@ __global__ __launch_bounds__(256) void cross_bwd_vec_kernel(const CrossParams p,
     __syncthreads();
     for (int c = threadIdx.x; c < 64 * V; c += 256) {
       const int64_t cc = (int64_t)blockIdx.x * 64 * V + c;
-      if (cc < p.n) atomicAdd(p.dbias + cc, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+      const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+      if (cc < p.n) {
+        if (p.partial) p.partial[(int64_t)blockIdx.y * p.n + cc] = s;
+        else atomicAdd(p.dbias + cc, s);
+      }
     }
   }
 }
@@ -2011,18 +2016,61 @@ __global__ __launch_bounds__(64) void cross_bwd_scalar_kernel(const CrossParams 
     }
     if (p.dxd && !fold) st_elem(p.dxd, p.dtype, o, g + p.diag * gx0);
   }
-  if (p.dbias) atomicAdd(p.dbias + col, db);
+  if (p.dbias) {
+    if (p.partial) p.partial[(int64_t)blockIdx.y * p.n + col] = db;
+    else atomicAdd(p.dbias + col, db);
+  }
 }
 
 __global__ __launch_bounds__(64) void colsum_kernel(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
-                                                    float* out, int rows_per_block) {
+                                                    float* out, float* partial, int rows_per_block) {
   const int64_t col = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (col >= n) return;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = min(m, r0 + rows_per_block);
   float s = 0.0f;
   for (int64_t i = r0; i < r1; ++i) s += ld_elem(a, dtype, i * lda + col);
-  atomicAdd(out + col, s);
+  if (partial) partial[(int64_t)blockIdx.y * n + col] = s;
+  else atomicAdd(out + col, s);
+}
+
+// Second half of the deterministic column sums (bias gradients): out[c] = partial[0][c] + partial[1][c] + ... in row-group
+// order -- the grouping depends on (m, n) alone, so the fp32 result is the same bits on every run (with the atomics
+// of the workspace-free form the order of the additions, and the last bits, varied from run to run).
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* partial, int64_t groups, int64_t n, float* out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.0f;
+  for (int64_t g = 0; g < groups; ++g) s += partial[g * n + c];
+  out[c] = s;
+}
+
+// row chunks of the column-sum walks: enough to fill the chip, few enough to keep the second stage cheap
+struct ColChunks {
+  int rows_per_block;
+  int64_t chunks;      // = grid.y of the scalar kernels
+  int64_t groups4;     // = grid.y of the vector kernels (four chunks, one per wave, per workgroup)
+};
+ColChunks col_chunks(int64_t m, int64_t cols) {
+  const int64_t strips = ceil_div(cols, 64);
+  int64_t chunks = ceil_div(4096, strips);
+  if (chunks > m) chunks = m;
+  ColChunks c;
+  c.rows_per_block = (int)ceil_div(m, chunks);
+  c.chunks = ceil_div(m, c.rows_per_block);
+  c.groups4 = ceil_div(c.chunks, 4);
+  return c;
+}
+// groups of partial sums the launch will write for an [m, n] operand walked V columns per thread
+int64_t colsum_groups(int64_t m, int64_t n, int v) {
+  if (m <= 0 || n <= 0) return 0;
+  const ColChunks c = col_chunks(m, v > 1 ? n / v : n);
+  return v > 1 ? c.groups4 : c.chunks;
+}
+int finish_colsum(float* partial, int64_t groups, int64_t n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, partial, groups, n, out);
+  KRS_CHECK_LAUNCH("colsum_finish_kernel");
+  return KRS_OK;
 }
 
 bool vec_ok(const CrossParams& p, int v, std::initializer_list<const void*> ptrs) {
@@ -2177,31 +2225,38 @@ extern "C" int krs_cross_epilogue_fwd(const void* u, const void* x0, const void*
   return KRS_OK;
 }
 
+extern "C" size_t krs_colsum_workspace_bytes(int64_t m, int64_t n) {
+  if (m <= 0 || n <= 0) return 0;
+  int64_t g = colsum_groups(m, n, 1);
+  if (n % 4 == 0) g = std::max(g, colsum_groups(m, n, 4));
+  if (n % 8 == 0) g = std::max(g, colsum_groups(m, n, 8));
+  return (size_t)g * (size_t)n * sizeof(float);
+}
+
 extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const void* x, void* du,
                                       void* dx0, int dx0_accumulate, void* dxd, float* dbias, int64_t m,
                                       int64_t n, int64_t ld, float diag_scale, int act, int dtype,
-                                      void* stream) {
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   KRS_REQUIRE(g && x0, "cross_epilogue_bwd: null g/x0");
   KRS_REQUIRE(act == KRS_ACT_NONE || u, "cross_epilogue_bwd: an activation needs the saved u");
   KRS_REQUIRE(!dx0 || (u && x), "cross_epilogue_bwd: dx0 needs u and x");
   KRS_REQUIRE(m >= 0 && n >= 0 && ld >= n, "cross_epilogue_bwd: bad sizes");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dbias) KRS_HIP(hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), st));
+  const bool two_stage = dbias && workspace && m > 0 && n > 0;
+  if (two_stage) KRS_REQUIRE(workspace_bytes >= krs_colsum_workspace_bytes(m, n), "cross_epilogue_bwd: workspace too small");
+  if (dbias && !two_stage) KRS_HIP(hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), st));
   if (m == 0 || n == 0) return KRS_OK;
   CrossParams p{};
   p.g = g; p.u = u; p.x0 = x0; p.x = x; p.du = du; p.dx0 = dx0; p.dxd = dxd; p.dbias = dbias;
+  p.partial = two_stage ? reinterpret_cast<float*>(workspace) : nullptr;
   p.dx0_acc = dx0_accumulate; p.m = m; p.n = n; p.ld = ld; p.diag = diag_scale; p.act = act; p.dtype = dtype;
   const int v = dtype == KRS_BF16 ? 8 : 4;
   const bool vec = vec_ok(p, v, {g, u, x0, x, du, dx0, dxd});
-  const int64_t cols = vec ? n / v : n;
-  const int64_t strips = ceil_div(cols, 64);
-  // enough row chunks to fill the chip, few enough to keep the atomics cheap
-  int64_t chunks = ceil_div(4096, strips);
-  if (chunks > m) chunks = m;
-  const int rows_per_block = (int)ceil_div(m, chunks);
-  const dim3 grid((unsigned)strips, (unsigned)ceil_div(m, rows_per_block));
+  const ColChunks cc = col_chunks(m, vec ? n / v : n);
+  const int64_t strips = ceil_div(vec ? n / v : n, 64);
+  const int rows_per_block = cc.rows_per_block;
   if (vec) {
-    const dim3 grid4((unsigned)strips, (unsigned)ceil_div(ceil_div(m, rows_per_block), 4));  // four chunks per workgroup
+    const dim3 grid4((unsigned)strips, (unsigned)cc.groups4);  // four chunks per workgroup
     const bool acc = p.dx0 && p.dx0_acc;
     if (dtype == KRS_BF16) {
       if (acc) hipLaunchKernelGGL((cross_bwd_vec_kernel<uint16_t, 8, true>), grid4, dim3(256), 0, st, p, rows_per_block);
@@ -2211,9 +2266,10 @@ extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* 
       else hipLaunchKernelGGL((cross_bwd_vec_kernel<float, 4, false>), grid4, dim3(256), 0, st, p, rows_per_block);
     }
   } else {
-    hipLaunchKernelGGL(cross_bwd_scalar_kernel, grid, dim3(64), 0, st, p, rows_per_block);
+    hipLaunchKernelGGL(cross_bwd_scalar_kernel, dim3((unsigned)strips, (unsigned)cc.chunks), dim3(64), 0, st, p, rows_per_block);
   }
   KRS_CHECK_LAUNCH("cross_bwd_kernel");
+  if (two_stage) return finish_colsum(p.partial, vec ? cc.groups4 : cc.chunks, n, dbias, st);
   return KRS_OK;
 }
 
@@ -2226,6 +2282,7 @@ struct DenseBwdParams {
   const void* y;
   void* dz;
   float* dbias;
+  float* partial;   // as CrossParams::partial
   int64_t m, n, ldg, ldy, ldz;
   int act, dtype;
 };
@@ -2276,7 +2333,11 @@ __global__ __launch_bounds__(256) void dense_act_bwd_vec_kernel(const DenseBwdPa
     __syncthreads();
     for (int c = threadIdx.x; c < 64 * V; c += 256) {
       const int64_t cc = (int64_t)blockIdx.x * 64 * V + c;
-      if (cc < p.n) atomicAdd(p.dbias + cc, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+      const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+      if (cc < p.n) {
+        if (p.partial) p.partial[(int64_t)blockIdx.y * p.n + cc] = s;
+        else atomicAdd(p.dbias + cc, s);
+      }
     }
   }
 }
@@ -2291,38 +2352,40 @@ __global__ __launch_bounds__(64) void dense_act_bwd_scalar_kernel(const DenseBwd
     db += dz;
     if (p.dz) st_elem(p.dz, p.dtype, i * p.ldz + col, dz);
   }
-  if (p.dbias) atomicAdd(p.dbias + col, db);
+  if (p.dbias) {
+    if (p.partial) p.partial[(int64_t)blockIdx.y * p.n + col] = db;
+    else atomicAdd(p.dbias + col, db);
+  }
 }
 
 extern "C" int krs_dense_act_bwd(const void* g, int64_t ld_g, const void* y, int64_t ld_y, void* dz, int64_t ld_dz,
-                                 float* dbias, int64_t m, int64_t n, int act, int dtype, void* stream) {
+                                 float* dbias, int64_t m, int64_t n, int act, int dtype, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
   KRS_REQUIRE(g && (dz || dbias), "dense_act_bwd: null operand");
   KRS_REQUIRE(act == KRS_ACT_NONE || y, "dense_act_bwd: an activation needs the saved output y");
   KRS_REQUIRE(m >= 0 && n >= 0 && ld_g >= n && (!y || ld_y >= n) && (!dz || ld_dz >= n), "dense_act_bwd: bad sizes");
   KRS_REQUIRE(dtype == KRS_F32 || dtype == KRS_BF16, "dense_act_bwd: dtype must be f32 or bf16");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dbias) KRS_HIP(hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), st));
+  const bool two_stage = dbias && workspace && m > 0 && n > 0;
+  if (two_stage) KRS_REQUIRE(workspace_bytes >= krs_colsum_workspace_bytes(m, n), "dense_act_bwd: workspace too small");
+  if (dbias && !two_stage) KRS_HIP(hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), st));
   if (m == 0 || n == 0) return KRS_OK;
-  DenseBwdParams p{g, y, dz, dbias, m, n, ld_g, ld_y, ld_dz, act, dtype};
+  DenseBwdParams p{g, y, dz, dbias, two_stage ? reinterpret_cast<float*>(workspace) : nullptr, m, n, ld_g, ld_y, ld_dz, act, dtype};
   const int v = dtype == KRS_BF16 ? 8 : 4;
-  const int es = dtype == KRS_BF16 ? 2 : 4;
   bool vec = n % v == 0 && ld_g % v == 0 && (!y || ld_y % v == 0) && (!dz || ld_dz % v == 0);
   for (const void* q : {g, y, (const void*)dz}) vec = vec && reinterpret_cast<uintptr_t>(q) % 16 == 0;
-  (void)es;
-  const int64_t cols = vec ? n / v : n;
-  const int64_t strips = ceil_div(cols, 64);
-  int64_t chunks = ceil_div(4096, strips);
-  if (chunks > m) chunks = m;
-  const int rows_per_block = (int)ceil_div(m, chunks);
+  const ColChunks cc = col_chunks(m, vec ? n / v : n);
+  const int64_t strips = ceil_div(vec ? n / v : n, 64);
   if (vec) {
-    const dim3 grid4((unsigned)strips, (unsigned)ceil_div(ceil_div(m, rows_per_block), 4));
-    if (dtype == KRS_BF16) hipLaunchKernelGGL((dense_act_bwd_vec_kernel<uint16_t, 8>), grid4, dim3(256), 0, st, p, rows_per_block);
-    else hipLaunchKernelGGL((dense_act_bwd_vec_kernel<float, 4>), grid4, dim3(256), 0, st, p, rows_per_block);
+    const dim3 grid4((unsigned)strips, (unsigned)cc.groups4);
+    if (dtype == KRS_BF16) hipLaunchKernelGGL((dense_act_bwd_vec_kernel<uint16_t, 8>), grid4, dim3(256), 0, st, p, cc.rows_per_block);
+    else hipLaunchKernelGGL((dense_act_bwd_vec_kernel<float, 4>), grid4, dim3(256), 0, st, p, cc.rows_per_block);
   } else {
-    hipLaunchKernelGGL(dense_act_bwd_scalar_kernel, dim3((unsigned)strips, (unsigned)ceil_div(m, rows_per_block)), dim3(64), 0,
-                       st, p, rows_per_block);
+    hipLaunchKernelGGL(dense_act_bwd_scalar_kernel, dim3((unsigned)strips, (unsigned)cc.chunks), dim3(64), 0, st, p,
+                       cc.rows_per_block);
   }
   KRS_CHECK_LAUNCH("dense_act_bwd_kernel");
+  if (two_stage) return finish_colsum(p.partial, vec ? cc.groups4 : cc.chunks, n, dbias, st);
   return KRS_OK;
 }
 
@@ -2503,19 +2566,20 @@ extern "C" int krs_dense_adagrad(float* const* params, const float* const* grads
 }
 
 extern "C" int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype, float* out,
-                          void* stream) {
+                          void* workspace, size_t workspace_bytes, void* stream) {
   KRS_REQUIRE(a && out, "colsum: null operand");
   KRS_REQUIRE(m >= 0 && n >= 0, "colsum: bad sizes");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n == 0) return KRS_OK;
-  KRS_HIP(hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st));
+  const bool two_stage = workspace && m > 0;
+  if (two_stage) KRS_REQUIRE(workspace_bytes >= krs_colsum_workspace_bytes(m, n), "colsum: workspace too small");
+  if (!two_stage) KRS_HIP(hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st));
   if (m == 0) return KRS_OK;
-  const int64_t strips = ceil_div(n, 64);
-  int64_t chunks = ceil_div(4096, strips);
-  if (chunks > m) chunks = m;
-  const int rows_per_block = (int)ceil_div(m, chunks);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)strips, (unsigned)ceil_div(m, rows_per_block)), dim3(64), 0,
-                     st, a, lda, m, n, dtype, out, rows_per_block);
+  const ColChunks cc = col_chunks(m, n);
+  float* partial = two_stage ? reinterpret_cast<float*>(workspace) : nullptr;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)cc.chunks), dim3(64), 0, st, a, lda, m, n, dtype,
+                     out, partial, cc.rows_per_block);
   KRS_CHECK_LAUNCH("colsum_kernel");
+  if (two_stage) return finish_colsum(partial, cc.chunks, n, out, st);
   return KRS_OK;
 }

@@ -98,6 +98,14 @@ def cross_epilogue_fwd(u, x0, x, diag_scale=0.0):
     return y
 
 
+def _colsum_ws(m: int, n: int, device):
+    """(pointer, byte count) arguments of the two-stage column sums (run-to-run identical bias gradients) + the
+    tensor that keeps the workspace alive until the call has been enqueued."""
+    nbytes = int(L.lib().krs_colsum_workspace_bytes(C.c_int64(m), C.c_int64(n)))
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+    return ws, L.ptr(ws), C.c_size_t(nbytes)
+
+
 def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
                        dx0_into: torch.Tensor | None = None,
                        want_du=True, want_dxd=True, want_dbias=True, fold_direct=False):
@@ -112,10 +120,11 @@ def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
         raise L.KrsError("cross_epilogue_bwd: dx0 buffer must be contiguous")
     dxd = dx0 if fold_direct else (torch.empty_like(x) if want_dxd else None)
     dbias = torch.empty(n, dtype=torch.float32, device=x.device) if want_dbias else None
+    ws, ws_ptr, ws_bytes = _colsum_ws(m, n, x.device) if want_dbias else (None, None, C.c_size_t(0))
     rc = L.lib().krs_cross_epilogue_bwd(
         L.ptr(g), L.ptr(u), L.ptr(x0), L.ptr(x), L.ptr(du), L.ptr(dx0), C.c_int(int(dx0_into is not None)),
         L.ptr(dxd), L.ptr(dbias), C.c_int64(m), C.c_int64(n), C.c_int64(n), C.c_float(diag_scale or 0.0),
-        C.c_int(act), C.c_int(L.fdtype(x)), L.stream_ptr())
+        C.c_int(act), C.c_int(L.fdtype(x)), ws_ptr, ws_bytes, L.stream_ptr())
     L.check(rc, "krs_cross_epilogue_bwd")
     return du, dx0, dxd, dbias
 
@@ -123,8 +132,9 @@ def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
 def colsum(a: torch.Tensor) -> torch.Tensor:
     a = _rowmajor(a, "colsum")
     out = torch.empty(a.shape[1], dtype=torch.float32, device=a.device)
+    ws, ws_ptr, ws_bytes = _colsum_ws(a.shape[0], a.shape[1], a.device)
     rc = L.lib().krs_colsum(L.ptr(a), C.c_int64(a.stride(0)), C.c_int64(a.shape[0]), C.c_int64(a.shape[1]),
-                            C.c_int(L.fdtype(a)), L.ptr(out), L.stream_ptr())
+                            C.c_int(L.fdtype(a)), L.ptr(out), ws_ptr, ws_bytes, L.stream_ptr())
     L.check(rc, "krs_colsum")
     return out
 
@@ -142,10 +152,11 @@ def dense_act_bwd(g: torch.Tensor, y: torch.Tensor | None, act: int, want_dbias:
     dz = torch.empty((m, n), dtype=g.dtype, device=g.device) if need_dz else None
     db = torch.empty(n, dtype=torch.float32, device=g.device) if want_dbias else None
     if need_dz or want_dbias:
+        ws, ws_ptr, ws_bytes = _colsum_ws(m, n, g.device) if want_dbias else (None, None, C.c_size_t(0))
         rc = L.lib().krs_dense_act_bwd(L.ptr(g), C.c_int64(g.stride(0)), L.ptr(y if need_dz else None),
                                        C.c_int64(y.stride(0) if (y is not None and need_dz) else n),
                                        L.ptr(dz), C.c_int64(n), L.ptr(db), C.c_int64(m), C.c_int64(n), C.c_int(act),
-                                       C.c_int(L.fdtype(g)), L.stream_ptr())
+                                       C.c_int(L.fdtype(g)), ws_ptr, ws_bytes, L.stream_ptr())
         L.check(rc, "krs_dense_act_bwd")
     return (dz if need_dz else g), db
 

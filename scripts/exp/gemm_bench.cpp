@@ -138,7 +138,7 @@ int main(int argc, char** argv) {
         break;
       case 2:
         KK(krs_cross_epilogue_bwd(g.p, u[i].p, x0.p, x.p, dz[i].p, dx0[i].p, getenv("KRS_EW_ACC") ? 1 : 0, nullptr, dbias, B, d, x.ld, 0.0f,
-                                  KRS_ACT_NONE, KRS_BF16, st));
+                                  KRS_ACT_NONE, KRS_BF16, nullptr, 0, st));
         break;
       case 3:
         KK(krs_gemm(h[i].p, h[i].ld, 1, dz[i].p, dz[i].ld, 0, dk[i].p, dk[i].ld, pj, d, B, KRS_BF16, KRS_F32, nullptr, ws,

@@ -92,6 +92,9 @@ def test_c2_eight_tables_three_full_rank_cross_layers_fp32():
     for layer, (k, b) in zip(layers, W):
         np.testing.assert_allclose(layer.weights[0].grad.cpu().numpy(), k.grad.numpy(), rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(layer.weights[1].grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4)
+        # ... and the north star's 1e-5 as a bound on the gradient as a whole (largest error against largest entry)
+        for got, ref in ((layer.weights[0].grad, k.grad), (layer.weights[1].grad, b.grad)):
+            assert np.abs(got.cpu().numpy() - ref.numpy()).max() <= 1e-5 * np.abs(ref.numpy()).max()
     # embedding-table gradient = scatter-add of the x0 gradient slices (index work: exact rows, 1e-5 values)
     dx0 = r0.grad.numpy()
     for t in (0, 5):

@@ -108,6 +108,10 @@ def test_assembled_model_matches_reference_composition():
     for n, p in model.named_parameters():
         if p.requires_grad:
             np.testing.assert_allclose(_np(p.grad), P[n].grad.numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+            # the north star's 1e-5, as a statement about the gradient as a whole: the largest error against the
+            # largest entry (element by element an fp32 sum with cancellation has no relative bound at all)
+            ref = P[n].grad.numpy()
+            assert np.abs(_np(p.grad) - ref).max() <= 1e-5 * np.abs(ref).max(), n
     # the large tables took their fused SGD step inside the backward: table - lr * dense gradient on the touched rows
     after = model.embedding_layer.get_embedding_tables()
     for t in large_keys:
