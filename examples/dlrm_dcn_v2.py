@@ -70,7 +70,7 @@ class DLRMDCNV2(torch.nn.Module):
             self.small_embedding_layers = torch.nn.ModuleDict({
                 f"{f['new_name']}_id": kl.EmbedReduce(f["vocabulary_size"], embedding_dim, combiner="sum",
                                                       embeddings_initializer=base.LecunNormal(seed=seed),
-                                                      dtype=embedding_dtype,
+                                                      dtype=dtype,   # (model.py:133-141: no dtype argument = the model's policy; fp32 variables)
                                                       name=f"small_embedding_layer_{f['new_name']}")
                 for f in small_emb_features})
         self.dcn_block = DCNBlock(num_dcn_layers, dcn_projection_dim, seed, dtype)

@@ -388,3 +388,40 @@ def test_dot_interaction_layer_with_100_features_trains():
     exp = x.sum(1, keepdim=True) - x
     for i, f in enumerate(feats):
         np.testing.assert_allclose(f.grad.cpu().numpy(), exp[:, i].cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,n", [(20000, 3456), (8192, 13), (4097, 250), (3, 8)])
+def test_bias_gradients_are_two_stage_sums_identical_from_run_to_run(dt, m, n):
+    """krs_colsum_workspace_bytes: with the workspace the three column sums of the path (cross bias, Dense bias, colsum)
+    are formed per row group and then over the groups IN ORDER -- the same bits on every run -- and agree with the
+    workspace-free form of the C ABI (fp32 atomics over the same groups) to rounding; a short workspace is refused."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd import dense_ops as D
+
+    rng = np.random.default_rng(5)
+    g, u, x0, x = (_t(rng.uniform(-1, 1, (m, n)), dt) for _ in range(4))
+    runs = [(D.cross_epilogue_bwd(g, u, x0, x, 0.0, act=D.ACTS["relu"])[3], D.dense_act_bwd(g, u, D.ACTS["tanh"])[1],
+             D.colsum(g)) for _ in range(3)]
+    for later in runs[1:]:
+        for a, b in zip(runs[0], later):
+            assert torch.equal(a, b)
+    exp = (to_f32(to_np(g)).astype(np.float64) * to_f32(to_np(x0)) * (to_f32(to_np(u)) > 0)).sum(0)
+    scale = np.abs(exp).max() + 1.0
+    np.testing.assert_allclose(runs[0][0].cpu().numpy(), exp, rtol=0, atol=2e-6 * scale * np.sqrt(m))
+    np.testing.assert_allclose(runs[0][2].cpu().numpy(), to_f32(to_np(g)).astype(np.float64).sum(0), rtol=0,
+                               atol=2e-6 * scale * np.sqrt(m))
+    # workspace-free form of the ABI (atomics): same groups, other order
+    nbytes = L.lib().krs_colsum_workspace_bytes(C.c_int64(m), C.c_int64(n))
+    assert nbytes >= 4 * n
+    out = torch.empty(n, dtype=torch.float32, device=DEV)
+    rc = L.lib().krs_colsum(L.ptr(g), C.c_int64(n), C.c_int64(m), C.c_int64(n), C.c_int(L.fdtype(g)), L.ptr(out), None,
+                            C.c_size_t(0), L.stream_ptr())
+    assert rc == 0
+    np.testing.assert_allclose(out.cpu().numpy(), runs[0][2].cpu().numpy(), rtol=0, atol=1e-6 * scale * np.sqrt(m))
+    ws = torch.empty(max(nbytes // 2, 4), dtype=torch.uint8, device=DEV)
+    rc = L.lib().krs_colsum(L.ptr(g), C.c_int64(n), C.c_int64(m), C.c_int64(n), C.c_int(L.fdtype(g)), L.ptr(out), L.ptr(ws),
+                            C.c_size_t(nbytes // 2), L.stream_ptr())
+    assert rc != 0 and b"workspace too small" in L.lib().krs_last_error()

@@ -121,3 +121,48 @@ def test_assembled_model_matches_reference_composition():
         touched[ids[t].reshape(-1)] = 1
         ko.apply_optimizer(exp_t, None, T64[name].grad.numpy().astype(np.float32), touched, lr, "sgd")
         np.testing.assert_allclose(_np(after[name]), exp_t, rtol=1e-5, atol=1e-6)
+
+
+def test_two_runs_of_the_step_are_bit_identical():
+    """Run-to-run reproducibility of the whole training step (mixed_bfloat16, the bench's policy): two models built from
+    the same seeds and stepped three times on the same batches end with the same bits in every dense weight, bias,
+    optimizer slot and table row -- no fp32 atomics left anywhere in the step (the bias gradients were the last:
+    krs_colsum_workspace_bytes), K2 has one owner per row and sums in position order, split-K slabs are reduced in order."""
+    import keras_rs_amd.layers as kl
+
+    ex = _example()
+    B, E = 4096, 32
+    hots = [3, 1, 2, 5, 1, 2, 1, 7]
+    vocabs = [5000, 70, 3000, 9000, 30, 400, 20000, 1000]
+    rng = np.random.default_rng(11)
+    batches = []
+    for _ in range(3):
+        ids = {t: torch.from_numpy(rng.integers(0, vocabs[t], (B, hots[t])).astype(np.int32)).to(DEV) for t in range(8)}
+        dense = torch.from_numpy(rng.uniform(0, 0.9, (B, 13)).astype(np.float32)).to(DEV)
+        labels = torch.from_numpy((rng.uniform(0, 1, (B, 1)) < 0.3).astype(np.float32)).to(DEV)
+        batches.append((ids, dense, labels))
+
+    def run():
+        model = ex.build_model(B, vocabs, hots, embedding_dim=E, projection=64, cross_layers=3, bottom=(64, 32, E),
+                               top=(128, 64, 1), table_optimizer=kl.Adagrad(learning_rate=0.05, initial_accumulator_value=0.1),
+                               embedding_threshold=100)
+        small = {f"cat_{t:02d}_id" for t in range(8) if vocabs[t] < 100}
+        box, losses = [None], []
+        for ids, dense, labels in batches:
+            inputs = {"dense_input": dense,
+                      "large_emb_inputs": {f"cat_{t:02d}_id": ids[t] for t in range(8) if f"cat_{t:02d}_id" not in small},
+                      "small_emb_inputs": {f"cat_{t:02d}_id": ids[t] for t in range(8) if f"cat_{t:02d}_id" in small}}
+            losses.append(ex.train_step(model, box, inputs, labels))
+        torch.cuda.synchronize()
+        state = {k: v.detach().clone() for k, v in model.state_dict().items() if isinstance(v, torch.Tensor)}
+        state.update({f"table.{k}": v.detach().clone() for k, v in model.embedding_layer.get_embedding_tables().items()})
+        state.update({f"opt.{i}.{k}": v.clone() for i, st in enumerate(box[0].state.values()) for k, v in st.items()
+                      if isinstance(v, torch.Tensor)})
+        return losses, state
+
+    la, sa = run()
+    lb, sb = run()
+    assert [float(x) for x in la] == [float(x) for x in lb]
+    assert sa.keys() == sb.keys() and len(sa) > 20
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
