@@ -8,8 +8,8 @@
 // Plan (once per batch of ids, independent of the gradient values):
 //   keys[p] = tables[t(f)].row_base + ids[p]   (u32; invalid ids -> 0xffffffff)
 //   vals[p] = (bag(p) << 32) | p               (u64)
-//   stable LSD radix sort of (keys, vals) over ceil(log2(total_rows)) bits
-//   (rocPRIM device radix sort, compiled into this library).
+//   stable LSD radix sort of (keys, vals) over ceil(log2(total_rows)) bits (namespace rs below: own kernels;
+//   dense bags whose tables form contiguous runs of positions are sorted per table, over the id bits alone).
 //   head flags -> exclusive scan -> segment list (first sorted position of every run of equal
 //   keys), and the work items of the segments longer than kLongSeg lookups.
 // Apply: a group of LPR lanes (one 16-byte piece of the gradient row per lane, as in K1) per
