@@ -325,7 +325,8 @@ class ShardedDistributedEmbedding(base.Layer):
         self._capacity_spec = capacity
         self.capacity_headroom = float(capacity_headroom)
         self._caps: dict = {}            # (group, batch, hots) -> [cap_lookups, cap_segments]
-        self._stats_q: dict = {}         # group -> list of (step, event, pinned stats, caps key)
+        self._stats_q: dict = {}           # group -> list of (step, event, pinned stats, caps key)
+        self._stat_bufs: dict = {}         # group -> ring of four page-locked buffers the statistics land in
         self._stat_step: dict = {}
         self.overflow_steps = 0
         self.slab_lead_cols = int(slab_lead_cols)  # as DistributedEmbedding: room for layers.concat_features
@@ -670,7 +671,10 @@ class ShardedDistributedEmbedding(base.Layer):
         self._stat_step[gi] = step + 1
         q = self._stats_q.setdefault(gi, [])
         if stats.is_cuda:
-            host = torch.empty(4, dtype=torch.int64).pin_memory()
+            ring = self._stat_bufs.setdefault(gi, [])
+            if len(ring) < 4:     # (a buffer is read two steps after it was filled: four never collide)
+                ring.append(torch.empty(4, dtype=torch.int64).pin_memory())
+            host = ring[step % 4] if len(ring) == 4 else ring[-1]
             host.copy_(stats, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
