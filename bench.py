@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--probe-steps", type=int, default=3,
                     help="extra steps after each timed region with event spans around the C-ABI calls (K2 apply, GEMMs): "
                          "the `roofline_step` entries; 0 = off")
+    ap.add_argument("--graph", action="store_true",
+                    help="one rank only: capture the step in a HIP graph (keras_rs_amd.graphs.GraphedStep) and time its "
+                         "replays -- for the host-bound per-rank step of a strongly-scaled job (--force-sharded --batch 8192)")
     ap.add_argument("--rccl-self", action="store_true",
                     help="with --force-sharded at N = 1: route the layer's collectives through a ONE-rank RCCL communicator "
                          "instead of device copies (proves the RCCL call path on a one-GPU box)")
@@ -428,6 +431,14 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
 
     for _ in range(warmup):
         step()
+    eager_step = step
+    if getattr(a, "graph", False) and not getattr(a, "_graph_used", False):
+        a._graph_used = True      # (the primary leg only: see keras_rs_amd/graphs.py on a second capture in one process)
+        if world > 1 or loader is not None or dp:
+            raise SystemExit("--graph: one rank, device-resident inputs, no collectives")
+        from keras_rs_amd.graphs import GraphedStep
+
+        step = GraphedStep(eager_step, warmup=2)
     # K1 launch duration, measured live with events on the launch stream, between the warm-up and the
     # timed steps (one krs_embed_bag_fwd launch per event pair).
     k1_s = None
@@ -502,6 +513,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         # (the probe steps run the weight-gradient GEMMs on the main stream: beside the elementwise passes, as in the
         #  timed steps, their event spans would measure the overlap, not the kernels)
         side_was, krs_autograd.WGRAD_SIDE_STREAM = krs_autograd.WGRAD_SIDE_STREAM, False
+        step = eager_step     # (spans are host-side event pairs: eager steps)
         step()
         probe.start()
         for _ in range(probe_steps):
@@ -745,6 +757,8 @@ def main():
         # runs ahead of the GPU and the step is GPU-bound; equal to it = the host is the limit (e.g. a wait inside the step)
         "host_enqueue_ms_per_step": r1["enqueue_s"] / a.steps * 1e3,
     }
+    if a.graph:
+        out["launch"] = "every timed step is one replay of a HIP graph captured from the eager step (keras_rs_amd.graphs)"
     if sharded and "exchange" in r1:
         ex = r1["exchange"]
         out["a2a_bytes_per_step"] = ex.get("bytes_per_step")

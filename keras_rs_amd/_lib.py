@@ -161,10 +161,36 @@ def itype(t: torch.Tensor) -> int:
     raise KrsError(f"unsupported index dtype {t.dtype} (int32 / int64 only)")
 
 
+# page-locked staging blocks set aside for descriptor uploads issued while a stream is CAPTURING (hipHostMalloc is not
+# allowed then, and the memcpy node of the graph reads its source at every replay: a block handed out there is never
+# reused)
+_CAPTURE_PIN_BYTES = 4096
+_capture_pins: list = []
+_capture_pins_held: list = []
+
+
+def _reserve_capture_pins(count: int = 64) -> None:
+    if not _capture_pins and not _capture_pins_held:
+        block = torch.empty(count * _CAPTURE_PIN_BYTES, dtype=torch.uint8).pin_memory()
+        _capture_pins.extend(block[i * _CAPTURE_PIN_BYTES:(i + 1) * _CAPTURE_PIN_BYTES] for i in range(count))
+
+
 def struct_to_device(arr: np.ndarray, device) -> torch.Tensor:
     """Uploads a numpy structured array (krs_table / krs_feature) as raw bytes."""
     host = torch.from_numpy(arr.view(np.uint8).reshape(-1).copy())
     if torch.device(device).type == "cuda":
+        if torch.cuda.is_current_stream_capturing():
+            n = host.numel()
+            if n > _CAPTURE_PIN_BYTES or not _capture_pins:
+                raise KrsError("descriptor upload during graph capture: run the step eagerly first (descriptors are "
+                               "cached; the few that change per step use a reserved page-locked block of 4 KB)")
+            pin = _capture_pins.pop()
+            _capture_pins_held.append(pin)
+            pin[:n].copy_(host)
+            dev = torch.empty(n, dtype=torch.uint8, device=device)
+            dev.copy_(pin[:n], non_blocking=True)
+            return dev
+        _reserve_capture_pins()
         # page-locked staging + asynchronous copy: a pageable upload makes the host wait for everything
         # queued on the stream (a pipeline drain per descriptor; the host allocator keeps the staging
         # block alive until the copy has run)

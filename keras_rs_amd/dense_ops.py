@@ -207,8 +207,17 @@ def refresh_casts(params) -> int:
         by_dtype.setdefault((p.dtype, p._krs_cast_want), []).append(p)
     for (sdt, ddt), ps in by_dtype.items():
         n = len(ps)
-        plains = [torch.empty(tuple(p.shape), dtype=ddt, device=p.device) for p in ps]
-        trans = [torch.empty((p.shape[1], p.shape[0]), dtype=ddt, device=p.device) for p in ps]
+        # the copies live in buffers that belong to the parameter and are rewritten in place, step after step (stream
+        # order puts the rewrite behind the last reader: the backward pass of the step whose update precedes it) --
+        # fixed addresses, so a step captured in a graph (torch.cuda.graph) keeps reading what its replays write
+        plains, trans = [], []
+        for p in ps:
+            buf = getattr(p, "_krs_cast_buf", None)
+            if buf is None or buf[0].dtype != ddt or buf[0].device != p.device or tuple(buf[0].shape) != tuple(p.shape):
+                buf = p._krs_cast_buf = (torch.empty(tuple(p.shape), dtype=ddt, device=p.device),
+                                         torch.empty((p.shape[1], p.shape[0]), dtype=ddt, device=p.device))
+            plains.append(buf[0])
+            trans.append(buf[1])
         ptrs = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
         rc = L.lib().krs_cast_transpose_many(
             C.c_int(n), ptrs(ps), (C.c_int64 * n)(*[p.shape[0] for p in ps]), (C.c_int64 * n)(*[p.shape[1] for p in ps]),

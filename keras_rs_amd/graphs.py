@@ -1,0 +1,46 @@
+"""A training step replayed from a HIP graph (torch.cuda.CUDAGraph on ROCm = hipGraph): for steps that are bound by the
+host's enqueue rate -- the per-rank step of a strongly-scaled job (batch 8192 per GPU: ~250 launches in 2.4 ms) -- one
+`hipGraphLaunch` replaces the Python / ctypes work of the whole step.
+
+What makes the path capturable: the C ABI only ever enqueues kernels and memsets on the stream it is given (no copies to
+the host, no allocation, no synchronisation: include/krs.h), the static-capacity exchange has no size that reaches the
+host (keras_rs_amd/sharded.py), out-of-range-id flags and exchange statistics are copied to page-locked memory by nodes
+of the graph and looked at BETWEEN replays (`check_ids(wait=True)`, `poll_exchange_stats()`), and the compute-dtype
+copies of the dense weights live at fixed addresses (dense_ops.refresh_casts).
+
+Limits, all of the capture mechanism: shapes and ids buffers are fixed (new ids are copied into the captured input
+tensors), scalars the host computes per step are frozen into the kernel arguments -- constant learning rates only
+(SGD / Adagrad / FTRL; Adam's bias correction changes per step: not under a graph) --, and a capacity that grows means a
+new capture.
+
+Validated (tests/test_graph_step_gpu.py, `bench.py --graph`): replays leave the same bits as eager steps, for the
+single-GPU layer and for the sharded layer at world 1; the sharded per-rank step (batch 8192) was captured twice in one
+process.  Known problem, ROCm 7.2: a SECOND capture of the large-batch single-GPU step (batch 65536, which forks into the
+plan and weight-gradient streams) in the same process crashed inside hipStreamEndCapture -- with new side streams and with
+the first graph kept alive alike; `bench.py --graph` therefore graphs its primary leg only.  Collectives were not
+captured here (one GPU per box): RCCL inside a capture is untested."""
+
+from __future__ import annotations
+
+import torch
+
+
+class GraphedStep:
+    """`step` (a callable without arguments that runs forward, backward and the optimizer on fixed tensors) captured once
+    and replayed.  `warmup` eager calls run first on a side stream, as torch.cuda.graph asks: they build the layers, the
+    optimizer state and every cached descriptor."""
+
+    def __init__(self, step, warmup: int = 3):
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph):
+            step()
+
+    def __call__(self) -> None:
+        self.graph.replay()

@@ -31,6 +31,13 @@ def default_device() -> torch.device:
 
 
 # --------------------------------------------------------------------------- #
+def stream_capturing() -> bool:
+    """True while the current HIP stream records into a graph (torch.cuda.graph): host-side polling of events and of
+    page-locked mirrors is then left out of the step -- a replay cannot run it -- and done by the caller between
+    replays (`check_ids(wait=True)`, `poll_exchange_stats()`)."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 # dtype policy (keras.DTypePolicy subset: float32 | bfloat16 | mixed_bfloat16)
 # --------------------------------------------------------------------------- #
 class DTypePolicy:

@@ -568,6 +568,11 @@ class DistributedEmbedding(base.Layer):
         """Queues a copy of the error word into page-locked memory behind the lookups just launched."""
         if self._err_dev is not None:
             self._err_host.copy_(self._err_dev, non_blocking=True)
+            if base.stream_capturing():
+                # inside a graph the copy is a node of every replay; there is no event to poll: check_ids(wait=True)
+                # between replays waits for the device instead
+                self._err_event, self._err_in_graph = None, True
+                return
             self._err_event = torch.cuda.Event()
             self._err_event.record()
 
@@ -576,10 +581,14 @@ class DistributedEmbedding(base.Layer):
         (such ids contribute nothing; they are never clamped).  Called at the start of every `call` without
         waiting for the GPU (only snapshots that have already arrived are looked at), with wait=True from
         get_embedding_tables() and by callers that want the verdict on the last step now."""
+        if base.stream_capturing():
+            return
         ev = self._err_event
         if ev is None:
-            return
-        if wait:
+            if not (wait and getattr(self, "_err_in_graph", False)):
+                return
+            torch.cuda.current_stream(self._err_dev.device).synchronize()   # replays of a captured step
+        elif wait:
             ev.synchronize()
         elif not ev.query():
             return

@@ -327,6 +327,7 @@ class ShardedDistributedEmbedding(base.Layer):
         self._caps: dict = {}            # (group, batch, hots) -> [cap_lookups, cap_segments]
         self._stats_q: dict = {}           # group -> list of (step, event, pinned stats, caps key)
         self._stat_bufs: dict = {}         # group -> ring of four page-locked buffers the statistics land in
+        self._graph_stats: dict = {}       # group -> (page-locked statistics of a CAPTURED step, caps key)
         self._stat_step: dict = {}
         self.overflow_steps = 0
         self.slab_lead_cols = int(slab_lead_cols)  # as DistributedEmbedding: room for layers.concat_features
@@ -495,10 +496,14 @@ class ShardedDistributedEmbedding(base.Layer):
         dropped before the exchange: they reach no row of any table on any rank)."""
         if self._replicated is not None:
             self._replicated.check_ids(wait)
+        if base.stream_capturing():
+            return
         ev = self._err_event
         if ev is None:
-            return
-        if wait:
+            if not (wait and getattr(self, "_err_in_graph", False)):
+                return
+            torch.cuda.current_stream(self._err_dev.device).synchronize()   # replays of a captured step
+        elif wait:
             ev.synchronize()
         elif not ev.query():
             return
@@ -584,8 +589,11 @@ class ShardedDistributedEmbedding(base.Layer):
             out.update(self._replicated(pre["replicated"]))
         if self._err_dev is not None:
             self._err_host.copy_(self._err_dev, non_blocking=True)
-            self._err_event = torch.cuda.Event()
-            self._err_event.record()
+            if base.stream_capturing():
+                self._err_event, self._err_in_graph = None, True
+            else:
+                self._err_event = torch.cuda.Event()
+                self._err_event.record()
         return {p: out[p] for p in self._paths}
 
     def _a2a(self, send: torch.Tensor, send_counts: list | None = None, recv_counts: list | None = None) -> torch.Tensor:
@@ -667,6 +675,17 @@ class ShardedDistributedEmbedding(base.Layer):
         this step's unpack (max need_l / need_s over ALL ranks' blocks: identical on every rank).  They are copied to
         page-locked memory behind an event and looked at two steps later -- long complete, so no wait -- on every
         rank at the same step: a need above the capacity grows it (x 1.125) for the steps that follow."""
+        if stats.is_cuda and base.stream_capturing():
+            # a captured step: the copy is a node of every replay, nothing is polled from inside the step;
+            # poll_exchange_stats() between replays looks at the latest figures (a capacity that grows changes buffer
+            # shapes: the step must then be captured again)
+            ring = self._stat_bufs.get(gi)
+            if not ring:
+                raise L.KrsError("ShardedDistributedEmbedding: run the step eagerly once before capturing it "
+                                 "(page-locked memory cannot be allocated while a stream is capturing)")
+            self._graph_stats[gi] = (ring[0], key)
+            ring[0].copy_(stats, non_blocking=True)
+            return
         step = self._stat_step.get(gi, 0)
         self._stat_step[gi] = step + 1
         q = self._stats_q.setdefault(gi, [])
@@ -685,16 +704,34 @@ class ShardedDistributedEmbedding(base.Layer):
             _, ev0, h0, key0 = q.pop(0)
             if ev0 is not None:
                 ev0.synchronize()
-            need_l, need_s = int(h0[0]), int(h0[1])
-            cap = self._caps.get(key0)
-            self.last_exchange.update(need=(need_l, need_s), received=(int(h0[2]), int(h0[3])))
-            if cap is not None and (need_l > cap[0] or need_s > cap[1]):
-                self.overflow_steps += 1
-                up64 = lambda v: int(-(-int(v) // 64) * 64)   # noqa: E731
-                if need_l > cap[0]:
-                    cap[0] = up64(need_l * 1.125)
-                if need_s > cap[1]:
-                    cap[1] = up64(need_s * 1.125)
+            self._apply_stats(h0, key0)
+
+    def _apply_stats(self, h0, key0) -> bool:
+        """One step's statistics (host copy) against the capacity they ran with; True when the capacity grew."""
+        need_l, need_s = int(h0[0]), int(h0[1])
+        cap = self._caps.get(key0)
+        self.last_exchange.update(need=(need_l, need_s), received=(int(h0[2]), int(h0[3])))
+        if cap is None or (need_l <= cap[0] and need_s <= cap[1]):
+            return False
+        self.overflow_steps += 1
+        up64 = lambda v: int(-(-int(v) // 64) * 64)   # noqa: E731
+        if need_l > cap[0]:
+            cap[0] = up64(need_l * 1.125)
+        if need_s > cap[1]:
+            cap[1] = up64(need_s * 1.125)
+        return True
+
+    def poll_exchange_stats(self) -> bool:
+        """For steps replayed from a graph (torch.cuda.graph around the step): waits for the device, looks at the
+        statistics of the last replay and grows the capacities they exceed.  True = a capacity grew -- lookups of that
+        replay were dropped (`overflow_steps`), and the step has to be captured again, its buffers changed size."""
+        if not self._graph_stats:
+            return False
+        torch.cuda.current_stream(self._device).synchronize()
+        grew = False
+        for host, key in self._graph_stats.values():
+            grew = self._apply_stats(host, key) or grew
+        return grew
 
     def _forward_static(self, gi, g, cap, key, ids, batch, hots, offsets, weights, lead, emit_w):
         k, n = self.kernels, self.world
