@@ -2034,15 +2034,36 @@ __global__ __launch_bounds__(64) void colsum_kernel(const void* a, int64_t lda, 
   else atomicAdd(out + col, s);
 }
 
-// Second half of the deterministic column sums (bias gradients): out[c] = partial[0][c] + partial[1][c] + ... in row-group
-// order -- the grouping depends on (m, n) alone, so the fp32 result is the same bits on every run (with the atomics
-// of the workspace-free form the order of the additions, and the last bits, varied from run to run).
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* partial, int64_t groups, int64_t n, float* out) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= n) return;
-  float s = 0.0f;
-  for (int64_t g = 0; g < groups; ++g) s += partial[g * n + c];
-  out[c] = s;
+// Second half of the deterministic column sums (bias gradients): out[c] = sum over the row groups of partial[g][c] in a
+// FIXED order -- the grouping depends on (m, n) alone, so the fp32 result is the same bits on every run (with the atomics
+// of the workspace-free form the order of the additions, and the last bits, varied from run to run).  A workgroup owns 32
+// columns; its 32 slices (one half wave each) sum contiguous runs of groups in ascending order, four independent loads
+// in flight, and the slice sums are added in slice order.  (One thread per column walking all groups -- the first
+// version -- took 40-500 us: up to 1024 dependent loads per thread and a handful of workgroups.)
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* partial, int64_t groups, int64_t n, float* out) {
+  __shared__ float red[32][33];
+  const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
+  const int64_t col = (int64_t)blockIdx.x * 32 + c;
+  float acc = 0.0f;
+  if (col < n) {
+    const int64_t per = (groups + 31) / 32;
+    const int64_t g0 = (int64_t)s * per, g1 = min(groups, g0 + per);
+    int64_t g = g0;
+    for (; g + 4 <= g1; g += 4) {
+      const float a0 = partial[g * n + col], a1 = partial[(g + 1) * n + col];
+      const float a2 = partial[(g + 2) * n + col], a3 = partial[(g + 3) * n + col];
+      acc += a0; acc += a1; acc += a2; acc += a3;
+    }
+    for (; g < g1; ++g) acc += partial[g * n + col];
+  }
+  red[s][c] = acc;
+  __syncthreads();
+  if (s == 0 && col < n) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += red[i][c];
+    out[col] = t;
+  }
 }
 
 // row chunks of the column-sum walks: enough to fill the chip, few enough to keep the second stage cheap
@@ -2068,7 +2089,7 @@ int64_t colsum_groups(int64_t m, int64_t n, int v) {
   return v > 1 ? c.groups4 : c.chunks;
 }
 int finish_colsum(float* partial, int64_t groups, int64_t n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, partial, groups, n, out);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)ceil_div(n, 32)), dim3(1024), 0, st, partial, groups, n, out);
   KRS_CHECK_LAUNCH("colsum_finish_kernel");
   return KRS_OK;
 }
