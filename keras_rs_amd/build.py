@@ -36,10 +36,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s[:-4] + ".o")
-        objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+        # (embed_bag_bwd.hip: ~1000 kernel instantiations -- three objects compiled side by side, see KRS_BWD_PART there)
+        parts = [(f"_p{i}", [f"-DKRS_BWD_PART={i}"]) for i in range(3)] if s == "embed_bag_bwd.hip" else [("", [])]
+        for suffix, defs in parts:
+            obj = os.path.join(OBJ, s[:-4] + suffix + ".o")
+            objs.append(obj)
+            if force or _newer(obj, [src] + hdrs):
+                jobs.append([HIPCC] + FLAGS + defs + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

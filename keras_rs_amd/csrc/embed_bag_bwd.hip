@@ -28,11 +28,24 @@
 #include "krs_common.h"
 #include "krs_scan.h"
 
+// The apply kernels are instantiated per (gradient type, table type, lanes per row, optimizer, weights, scale): ~1000
+// kernels, 160 s of hipcc in one translation unit.  keras_rs_amd/build.py compiles this file three times instead, in
+// parallel: KRS_BWD_PART 0 = the plan + the dense / sparse / SGD forms, 1 = Adagrad and row-wise Adagrad, 2 = Adam and
+// FTRL (entry points outside a part are left out of it).  Undefined = the whole file in one object.
+#ifndef KRS_BWD_PART
+#define KRS_BWD_PART -1
+#endif
+#define KRS_BWD_HAS(part) (KRS_BWD_PART < 0 || KRS_BWD_PART == (part))
+
 namespace krs {
+#if KRS_BWD_HAS(0)
 // krs_embed_set_option(KRS_EMBED_OPT_APPLY, v): 0 = bag_apply_fast_kernel (default), 1 = bag_apply_kernel (A/B, fallback)
 int g_apply_variant = 0;
 // krs_embed_set_option(KRS_EMBED_OPT_PLAN, v): 0 = table-segmented sort where the layout allows it (default), 1 = always the global sort
 int g_plan_variant = 0;
+#else
+extern int g_apply_variant, g_plan_variant;
+#endif
 namespace {
 
 constexpr uint32_t kInvalidKey = 0xffffffffu;
@@ -1700,10 +1713,12 @@ ApplyParams make_apply(const krs_table* tables, int n_tables, const krs_feature*
 
 using namespace krs;
 
+#if KRS_BWD_HAS(0)
 extern "C" size_t krs_embed_bag_bwd_workspace_bytes(int64_t nnz) {
   if (nnz < 0) return 0;
   return plan_layout(nullptr, nnz, true).total_bytes;
 }
+#endif
 
 // Table-segmented sort (rs::scatter_seg_kernel) when the host descriptors are given and the lookups are laid out for
 // it: dense bags, the features of a table neighbours, tables (and their row bases) ascending with the features.
@@ -1872,6 +1887,7 @@ static int plan_impl(const krs_table* tables, const krs_table* tables_host, int 
   return KRS_OK;
 }
 
+#if KRS_BWD_HAS(0)
 extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature* feats, int n_feats,
                                       const void* ids, int id_type, const void* offsets, int off_type,
                                       int batch, int64_t nnz, int64_t total_rows, void* workspace,
@@ -1879,7 +1895,9 @@ extern "C" int krs_embed_bag_bwd_plan(const krs_table* tables, const krs_feature
   return plan_impl(tables, nullptr, 0, feats, nullptr, n_feats, ids, id_type, offsets, off_type, batch, nnz, total_rows,
                    workspace, workspace_bytes, err_flag, stream);
 }
+#endif
 
+#if KRS_BWD_HAS(0)
 extern "C" int krs_embed_bag_bwd_plan_tables(const krs_table* tables, const krs_table* tables_host, int n_tables,
                                              const krs_feature* feats, const krs_feature* feats_host, int n_feats,
                                              const void* ids, int id_type, int batch, int64_t nnz, int64_t total_rows,
@@ -1888,7 +1906,9 @@ extern "C" int krs_embed_bag_bwd_plan_tables(const krs_table* tables, const krs_
   return plan_impl(tables, tables_host, n_tables, feats, feats_host, n_feats, ids, id_type, nullptr, KRS_I32, batch, nnz,
                    total_rows, workspace, workspace_bytes, err_flag, stream);
 }
+#endif
 
+#if KRS_BWD_HAS(0)
 extern "C" int krs_embed_bag_bwd_dense(const krs_table* grad_tables, int n_tables, const krs_feature* feats,
                                        int n_feats, const float* weights, const float* bag_scale,
                                        const void* grad, int grad_dtype, int64_t grad_ld, int batch, int dim,
@@ -1897,7 +1917,9 @@ extern "C" int krs_embed_bag_bwd_dense(const krs_table* grad_tables, int n_table
   ApplyParams p = make_apply(grad_tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kDense>(p, grad_dtype, KRS_F32, reinterpret_cast<hipStream_t>(stream));
 }
+#endif
 
+#if KRS_BWD_HAS(0)
 extern "C" int krs_embed_bag_bwd_fused_sgd(const krs_table* tables, int n_tables, const krs_feature* feats,
                                            int n_feats, const float* weights, const float* bag_scale,
                                            const void* grad, int grad_dtype, int64_t grad_ld, int batch, int dim,
@@ -1906,7 +1928,9 @@ extern "C" int krs_embed_bag_bwd_fused_sgd(const krs_table* tables, int n_tables
   ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kSgd>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
+#endif
 
+#if KRS_BWD_HAS(1)
 extern "C" int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_tables, const krs_feature* feats,
                                                int n_feats, const float* weights, const float* bag_scale,
                                                const void* grad, int grad_dtype, int64_t grad_ld, int batch,
@@ -1916,7 +1940,9 @@ extern "C" int krs_embed_bag_bwd_fused_adagrad(const krs_table* tables, int n_ta
   ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kAdagrad>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
+#endif
 
+#if KRS_BWD_HAS(1)
 extern "C" int krs_embed_bag_bwd_fused_adagrad_rowwise(const krs_table* tables, int n_tables,
                                                        const krs_feature* feats, int n_feats, const float* weights,
                                                        const float* bag_scale, const void* grad, int grad_dtype,
@@ -1926,7 +1952,9 @@ extern "C" int krs_embed_bag_bwd_fused_adagrad_rowwise(const krs_table* tables, 
   ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   return run_apply<kAdagradRow>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
+#endif
 
+#if KRS_BWD_HAS(2)
 extern "C" int krs_embed_bag_bwd_fused_adam(const krs_table* tables, int n_tables, const krs_feature* feats,
                                             int n_feats, const float* weights, const float* bag_scale,
                                             const void* grad, int grad_dtype, int64_t grad_ld, int batch,
@@ -1938,7 +1966,9 @@ extern "C" int krs_embed_bag_bwd_fused_adam(const krs_table* tables, int n_table
   p.hyper = Hyper{beta_1, beta_2, epsilon, bias_correction};
   return run_apply<kAdam>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
+#endif
 
+#if KRS_BWD_HAS(2)
 extern "C" int krs_embed_bag_bwd_fused_ftrl(const krs_table* tables, int n_tables, const krs_feature* feats,
                                             int n_feats, const float* weights, const float* bag_scale,
                                             const void* grad, int grad_dtype, int64_t grad_ld, int batch,
@@ -1949,7 +1979,9 @@ extern "C" int krs_embed_bag_bwd_fused_ftrl(const krs_table* tables, int n_table
   p.hyper = Hyper{learning_rate_power, l1, l2, beta};
   return run_apply<kFtrl>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
+#endif
 
+#if KRS_BWD_HAS(0)
 extern "C" int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats, const float* weights,
                                         const float* bag_scale, const void* grad, int grad_dtype,
                                         int64_t grad_ld, int batch, int dim, int64_t nnz, const void* workspace,
@@ -1969,3 +2001,4 @@ extern "C" int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats, c
   p.row_grads = row_grads;
   return run_apply<kSparse>(p, grad_dtype, KRS_F32, st);
 }
+#endif
