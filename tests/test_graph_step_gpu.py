@@ -2,96 +2,20 @@
 optimizer slot and dense weight as the same number of eager steps: the C ABI only enqueues kernels and memsets on the
 stream it is given, the compute-dtype copies of the weights live at fixed addresses, and flags / exchange statistics are
 read between replays.  Both embedding layers: the single-GPU DistributedEmbedding and the sharded layer at world 1
-(static-capacity exchange: no size reaches the host)."""
+(static-capacity exchange: no size reaches the host).  Each case runs in its own process (tests/_graph_worker.py)."""
 
-import numpy as np
+import os
+import subprocess
+import sys
+
 import pytest
-import torch
 
 pytestmark = pytest.mark.gpu
-DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(sharded: bool):
-    import keras_rs_amd.layers as kl
-    from keras_rs_amd.layers import base
-
-    B, D, hots, vocabs = 33024, 32, [3, 1, 7, 2], [5000, 300, 20000, 1000]   # (above autograd.WGRAD_SIDE_MIN_ROWS)
-    opt = kl.Adagrad(learning_rate=0.05, initial_accumulator_value=0.1)
-    feats = {}
-    for t in range(4):
-        tc = kl.TableConfig(name=f"t{t}", vocabulary_size=vocabs[t], embedding_dim=D,
-                            initializer=base.RandomUniform(-0.05, 0.05, seed=7 + t), optimizer=opt, combiner="sum",
-                            placement="sparsecore")
-        feats[f"f{t}"] = kl.FeatureConfig(f"f{t}", tc, (B, hots[t]), (B, D))
-    if sharded:
-        from keras_rs_amd.sharded import ShardedDistributedEmbedding
-
-        emb = ShardedDistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=D, exchange="static")
-    else:
-        emb = kl.DistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=D)
-    dot = kl.DotInteraction(dtype="bfloat16")
-    cross = torch.nn.ModuleList(kl.FeatureCross(projection_dim=64, kernel_initializer=base.GlorotUniform(seed=3 + i),
-                                                dtype="mixed_bfloat16") for i in range(2))
-    g = torch.Generator(device=DEV).manual_seed(5)
-    ids = {f"f{t}": torch.randint(0, vocabs[t], (B, hots[t]), device=DEV, generator=g, dtype=torch.int32) for t in range(4)}
-    dense = (torch.rand(B, D, device=DEV, generator=g) * 0.9).to(torch.bfloat16)
-    pre = emb.preprocess(ids)
-    g_xl = torch.full((B, 5 * D), 1.0 / B, dtype=torch.bfloat16, device=DEV)
-    g_in = torch.full((B, 10), 0.1 / B, dtype=torch.bfloat16, device=DEV)
-    box = [None]
-
-    def step():
-        out = emb(pre)
-        fs = [dense] + [out[k] for k in out]
-        inter = dot(fs)
-        x0 = kl.concat_features(fs)
-        xl = x0
-        for layer in cross:
-            xl = layer(x0, xl)
-        torch.autograd.backward([xl, inter], [g_xl, g_in])
-        if box[0] is None:
-            from keras_rs_amd.optim import Adagrad
-
-            box[0] = Adagrad([p for layer in cross for p in layer.parameters()], lr=0.01, initial_accumulator_value=0.1,
-                             prepare_casts=True)
-        box[0].step()
-        box[0].zero_grad(set_to_none=True)
-
-    def state():
-        torch.cuda.synchronize()
-        s = {f"table.{k}": v.clone() for k, v in emb.get_embedding_tables().items()}
-        s.update({f"cross.{k}": v.detach().clone() for k, v in cross.state_dict().items()})
-        s.update({f"emb.{k}": v.detach().clone() for k, v in emb.state_dict().items() if isinstance(v, torch.Tensor)})
-        s.update({f"opt.{i}": st["sum"].clone() for i, st in enumerate(box[0].state.values())})
-        return s
-
-    return emb, step, state
-
-
-@pytest.mark.parametrize("sharded", [False, True])
-def test_replayed_steps_equal_eager_steps(sharded):
-    from keras_rs_amd.graphs import GraphedStep
-
-    _, step_a, state_a = _build(sharded)
-    for _ in range(5):
-        step_a()
-    ref = state_a()
-
-    emb, step_b, state_b = _build(sharded)
-    graphed = GraphedStep(step_b, warmup=2)      # two eager steps, then the capture (which runs nothing)
-    for _ in range(3):
-        graphed()
-    emb.check_ids(wait=True)                     # the flag word of the replays: no id was out of range
-    if sharded:
-        assert emb.poll_exchange_stats() is False and emb.overflow_steps == 0
-        assert emb.last_exchange["need"][0] <= emb.last_exchange["capacity"][0]
-    got = state_b()
-    assert ref.keys() == got.keys() and len(ref) >= 10
-    for k in ref:
-        assert torch.equal(ref[k], got[k]), k
-    # ... and the steps did move the tables (the comparison is not between two untouched states)
-    emb0, step0, state0 = _build(sharded)
-    step0()
-    first = state0()
-    assert not torch.equal(first["table.t0"], ref["table.t0"])
+@pytest.mark.parametrize("which", ["single", "sharded"])
+def test_replayed_steps_equal_eager_steps(which):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_graph_worker.py"), which], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and f"GRAPH_OK {which}" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
