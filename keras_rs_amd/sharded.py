@@ -306,8 +306,11 @@ class ShardedDistributedEmbedding(base.Layer):
     def __init__(self, feature_configs: dict[str, FeatureConfig], *, process_group=None, kernels=None,
                  slab_lead_cols: int = 0, replicate_below: int = 0, grad_average: bool = False,
                  partial_dtype=None, exchange: str = "exact", capacity="auto", capacity_headroom: float = 1.25,
-                 **kwargs: Any):
+                 update_stats: bool = True, **kwargs: Any):
         super().__init__(**kwargs)
+        # (base_distributed_embedding.py:461-464: whether the per-partition limits follow the running statistics; here
+        #  the capacities of the static exchange.  False = they stay what they were sized to, overflows are only counted)
+        self.update_stats = bool(update_stats)
         if exchange not in ("exact", "static"):
             raise ValueError(f"exchange must be 'exact' or 'static', got {exchange!r}")
         # "exact": the all-to-alls carry exactly the lookups of the step; their sizes reach the host through ONE
@@ -714,6 +717,8 @@ class ShardedDistributedEmbedding(base.Layer):
         if cap is None or (need_l <= cap[0] and need_s <= cap[1]):
             return False
         self.overflow_steps += 1
+        if not self.update_stats:
+            return False
         up64 = lambda v: int(-(-int(v) // 64) * 64)   # noqa: E731
         if need_l > cap[0]:
             cap[0] = up64(need_l * 1.125)

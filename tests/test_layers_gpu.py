@@ -946,3 +946,25 @@ def test_weight_gradients_on_the_second_stream_are_the_same_gradients():
         torch.testing.assert_close(p.grad, 2 * g, rtol=1e-5, atol=1e-8)
     A.WGRAD_SIDE_MIN_ROWS = 32768
     assert len(seen) == 1 and torch.equal(seen[0], g1[[n for n, _ in layer.named_parameters()].index("kernel")])
+
+
+def test_distributed_embedding_mixed_placement_and_update_stats_argument():
+    """distributed_embedding_test.py:654-723 (placements intermixed: every feature must come back from ITS table -- the
+    widths differ, and here the values are checked too) and :760-771 (`update_stats=True` is accepted at construction)."""
+    kl = _layers()
+    B = 16
+    t1 = kl.TableConfig("table1", 50, 16, placement="default_device")
+    t2 = kl.TableConfig("table2", 50, 32, placement="sparsecore")
+    t3 = kl.TableConfig("table3", 50, 64, placement="default_device")
+    cfg = {"feature1": kl.FeatureConfig("feature1", t1, (B, 1), (B, 16)),
+           "feature2": kl.FeatureConfig("feature2", t2, (B, 1), (B, 32)),
+           "feature3": kl.FeatureConfig("feature3", t3, (B, 1), (B, 64))}
+    layer = kl.DistributedEmbedding(cfg, update_stats=True)
+    assert layer.update_stats is True
+    rng = np.random.default_rng(2)
+    ids = {k: rng.integers(0, 50, (B, 1)).astype(np.int32) for k in cfg}
+    res = layer(ids)
+    tables = {k: v.cpu().numpy() for k, v in layer.get_embedding_tables().items()}
+    for k, t, d in (("feature1", "table1", 16), ("feature2", "table2", 32), ("feature3", "table3", 64)):
+        assert tuple(res[k].shape) == (B, d)
+        np.testing.assert_array_equal(res[k].detach().cpu().numpy(), tables[t][ids[k][:, 0]])   # one id per bag: its row
