@@ -37,7 +37,7 @@ from keras_rs_amd import _lib as L
 from keras_rs_amd.autograd import EmbedBagFn, EmbedBagFusedFn
 from keras_rs_amd.embedding_ops import FusedBags
 from keras_rs_amd.layers import base
-from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig, TableConfig
+from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig
 from keras_rs_amd.layers.embed_reduce import Ragged, check_shapes_compatible
 
 SUPPORTED_PLACEMENTS = ("auto", "default_device", "sparsecore")

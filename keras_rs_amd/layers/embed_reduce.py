@@ -10,7 +10,6 @@ from typing import Any
 import numpy as np
 import torch
 
-from keras_rs_amd import _lib as L
 from keras_rs_amd.autograd import EmbedBagFn
 from keras_rs_amd.embedding_ops import FusedBags
 from keras_rs_amd.layers import base
