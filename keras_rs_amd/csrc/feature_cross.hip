@@ -996,6 +996,9 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 #ifndef KRS_PP_B_AUX
 #define KRS_PP_B_AUX 0
 #endif
+#ifndef KRS_PP_LAYOUT_EXP
+#define KRS_PP_LAYOUT_EXP 0
+#endif
 #ifndef KRS_PP_PROBE
 #define KRS_PP_PROBE 0  // development builds only (scripts/exp): 1 = DMA stream alone, 2 = LDS reads + MFMA alone, 3 = DMA + LDS reads, 4 = epilogue alone
 #endif
@@ -1100,6 +1103,16 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
       bp[i] = p.b + min(n0 + r, p.n - 1) * p.ldb * 2 + c * 16;
     }
     astep = bstep = 64;
+#if KRS_PP_LAYOUT_EXP  // development builds (timing only, results are garbage): operands read as if pre-tiled [K/32][rows][32]
+    if (KRS_PP_LAYOUT_EXP & 1) {
+      for (int i = 0; i < 2; ++i) bp[i] = p.b + (min(n0 + (wave * 2 + i) * 16 + (lane >> 2), p.n - 1)) * 64 + (lane & 3) * 16;
+      bstep = p.n * 64;
+    }
+    if (KRS_PP_LAYOUT_EXP & 2) {
+      for (int i = 0; i < 2; ++i) ap[i] = p.a + (min(m0 + (wave * 2 + i) * 16 + (lane >> 2), p.m - 1)) * 64 + (lane & 3) * 16;
+      astep = p.m * 64;
+    }
+#endif
   } else {
     // instruction q fills the 1 KB block (128-column half q >> 3, k-rows (q & 7)*4 .. +3) with the image of
     // gemm_tn_glds_kernel: lane = (quarter*4 + k-row)*4 + chunk
@@ -1113,6 +1126,16 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     }
     astep = p.lda * 64;
     bstep = p.ldb * 64;
+#if KRS_PP_LAYOUT_EXP  // (timing only) K-strided operands read as if pre-tiled [cols/256][K][256]
+    if (KRS_PP_LAYOUT_EXP & 4) {
+      for (int i = 0; i < 2; ++i) bp[i] = p.b + ((min(n0 >> 8, (p.n >> 8) - 1) * p.k + kbeg + ((wave & 3) * 2 + i) * 4 + kr) * 256 + (col & 255)) * 2;
+      bstep = 32 * 512;
+    }
+    if (KRS_PP_LAYOUT_EXP & 8) {
+      for (int i = 0; i < 2; ++i) ap[i] = p.a + ((min(m0 >> 8, (p.m >> 8) - 1) * p.k + kbeg + ((wave & 3) * 2 + i) * 4 + kr) * 256 + (col & 255)) * 2;
+      astep = 32 * 512;
+    }
+#endif
   }
   const int dma_off = wave * 2048;  // + i*1024: where instruction q = wave*2 + i lands inside a piece
   auto issue_a = [&](int stage) {
