@@ -529,6 +529,8 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
                 mask[v.reshape(-1).long()] = True
                 uniq += int(mask.sum())
             res["unique_rows"] = uniq
+    flush = getattr(model.embedding, "flush_exchange_stats", None)
+    res["overflow_steps"] = int(flush()) if flush is not None else 0
     ex = getattr(model.embedding, "last_exchange", None)
     if ex:
         res["exchange"] = dict(ex)
@@ -637,6 +639,12 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
+    # The step below owns every reader of the cross layers' weight gradients (one consumer per weight, gradients set to
+    # None after every step, the all-reduce hooks rejoin the stream): the second stream for dK / dU is safe here, and it
+    # is opt-in since round 4 (keras_rs_amd/autograd.py; KRS_WGRAD_SIDE=0 keeps it off for an A/B)
+    from keras_rs_amd import autograd as krs_autograd
+
+    krs_autograd.set_wgrad_side_stream(bool(int(os.environ.get("KRS_WGRAD_SIDE", "1"))))
     model = Model(a, primary, world, rank)
     model.embedding.build(None)
     opt_box = [None]
@@ -762,7 +770,13 @@ def main():
     if sharded and "exchange" in r1:
         ex = r1["exchange"]
         out["a2a_bytes_per_step"] = ex.get("bytes_per_step")
-        out["exchange"] = {k: v for k, v in ex.items() if k in ("mode", "bytes", "capacity", "overflowed")}
+        out["exchange"] = {k: v for k, v in ex.items() if k in ("mode", "bytes", "capacity", "need", "received")}
+        # static exchange: lookups beyond a block's capacity are DROPPED (the reference's id dropping) -- `value` would
+        # then count dropped lookups as work, so the line says so at the top level
+        out["overflow_steps"] = int(r1.get("overflow_steps", 0)) + int(r2.get("overflow_steps", 0))
+        if out["overflow_steps"]:
+            out["invalid"] = ("the static exchange dropped lookups in %d step(s) (capacity %s, largest per-owner need %s): "
+                              "`value` counts dropped lookups as work" % (out["overflow_steps"], ex.get("capacity"), ex.get("need")))
     second = {"workload": "same tables / model, " + describe(secondary),
               "value": a.batch * sum(secondary) / (elapsed2 / sec_steps), "unit": "lookups/s",
               "ms_per_step": elapsed2 / sec_steps * 1e3, "steps": sec_steps, "warmup": max(5, a.warmup),

@@ -233,7 +233,11 @@ int krs_embed_bag_bwd_fused_ftrl(const krs_table* tables, int n_tables,
 
 /* Sparse form: unique global rows and their summed gradients.
  *   unique_rows [nnz] int64 (first *n_unique valid), row_grads [nnz, dim] fp32,
- *   n_unique device int64. */
+ *   n_unique device int64.
+ * Needs the plan of krs_embed_bag_bwd_plan (global sort).  A workspace last written by
+ * krs_embed_bag_bwd_plan_tables is refused with KRS_ERR_UNSUPPORTED (the library remembers which call
+ * planned into a workspace address; the workspace also carries the fact, so a plan that was moved to
+ * another address yields *n_unique = -1 instead of a miscounted list). */
 int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats,
                              const float* weights, const float* bag_scale,
                              const void* grad, int grad_dtype, int64_t grad_ld,

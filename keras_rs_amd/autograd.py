@@ -29,11 +29,26 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # DotInteraction gradient and the table update behind the bottom layer) -- an elementwise pass and a ring GEMM do overlap
 # a little on this part (scripts/exp/overlap_probe2.py: 563 + 271 us apart, 707 together), two GEMMs or a GEMM and the
 # table update do not.  Measured in the step: 10.31-10.48 -> 10.20-10.29 ms.  Deferring all six to the table update was
-# slower (10.49).  Environment KRS_WGRAD_SIDE=0 switches it off.
-WGRAD_SIDE_STREAM = bool(int(__import__("os").environ.get("KRS_WGRAD_SIDE", "1")))
+# slower (10.49).
+# OPT-IN since round 4 (`set_wgrad_side_stream(True)` or KRS_WGRAD_SIDE=1; bench.py and the example's training step
+# switch it on): a gradient produced on a private stream is only safe when NOTHING but the end-of-backward rejoin reads
+# it, and a backward function cannot see every reader -- a second gradient contribution to the same weight (a manual
+# L2 term, a weight shared by two layers) is summed by autograd's input buffer on the main stream with nothing ordering
+# it behind this stream.  The owner of the training step can promise that; a library default cannot.  What the
+# function can see it still checks (`_wgrad_side_ok`): an accumulated .grad, tensor hooks, foreign post-accumulate
+# hooks, a regulariser on the weight (layers.base marks it: its penalty is a second contribution), the weight used by
+# more than one pending CrossLayerFn.
+WGRAD_SIDE_STREAM = bool(int(__import__("os").environ.get("KRS_WGRAD_SIDE", "0")))
 WGRAD_SIDE_MIN_ROWS = 32768
 _WGRAD_STREAMS: dict = {}
 _WGRAD_SYNC_QUEUED: set = set()
+
+
+def set_wgrad_side_stream(on: bool) -> bool:
+    """Switch the second stream for the cross layers' weight gradients on or off (see above); returns the old value."""
+    global WGRAD_SIDE_STREAM
+    old, WGRAD_SIDE_STREAM = WGRAD_SIDE_STREAM, bool(on)
+    return old
 
 
 def _wgrad_stream(device) -> "torch.cuda.Stream":
@@ -47,11 +62,14 @@ def _wgrad_stream(device) -> "torch.cuda.Stream":
 def _wgrad_side_ok(w) -> bool:
     """May this weight's gradient come off the second stream?  Only when nothing reads it before the end of the backward
     pass: no gradient to accumulate into yet (the first accumulation is an assignment, a later one is an add kernel on
-    the main stream), no tensor hooks, and no post-accumulate hooks other than ones that rejoin the stream themselves
-    (dp.GradAllReduce marks its parameters)."""
+    the main stream), no tensor hooks, no post-accumulate hooks other than ones that rejoin the stream themselves
+    (dp.GradAllReduce marks its parameters), no second consumer this function knows of (a regulariser attached by
+    `Layer.add_weight`, a second CrossLayerFn whose backward is still pending)."""
     if w is None:
         return True
     if w.grad is not None or w._backward_hooks:
+        return False
+    if getattr(w, "_krs_has_regularizer", False) or getattr(w, "_krs_pending_cross", 1) != 1:
         return False
     hooks = getattr(w, "_post_accumulate_grad_hooks", None)
     return not hooks or bool(getattr(w, "_krs_hooks_rejoin_wgrad_stream", False))
@@ -194,6 +212,12 @@ class CrossLayerFn(torch.autograd.Function):
                     x0.dtype, x.dtype, None if down is None else down.dtype, kernel.dtype)
         ctx.relay_in = relay_in
         ctx.w_refs = tuple(weakref.ref(w) for w in (down, kernel) if w is not None)
+        # pending uses of each weight (a weight shared by two layer calls gets two gradient contributions)
+        ctx.counted = any(ctx.needs_input_grad[i] for i in (2, 3))
+        if ctx.counted:
+            for w in (down, kernel):
+                if w is not None:
+                    w._krs_pending_cross = getattr(w, "_krs_pending_cross", 0) + 1
         both = ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         ctx.relay_up = relay_up if (relay_up is not None and not same and both and relay_up.matches(x0)) else None
         return y
@@ -224,8 +248,15 @@ class CrossLayerFn(torch.autograd.Function):
         direct = dx0 if same else (dxd if need_dxd else g)  # dL/dx through "+ x" and "diag * x"
         # (worth it when the kernels are long against a launch: at a per-rank batch of 8192 the step is bound by the
         #  host's enqueue rate and the extra events cost more than the overlap returns: 2.42 -> 2.54 ms)
-        if low_rank and WGRAD_SIDE_STREAM and dz.is_cuda and dz.shape[0] >= WGRAD_SIDE_MIN_ROWS and \
-                all(_wgrad_side_ok(r()) for r in ctx.w_refs):
+        side_ok = low_rank and WGRAD_SIDE_STREAM and dz.is_cuda and dz.shape[0] >= WGRAD_SIDE_MIN_ROWS and \
+            all(_wgrad_side_ok(r()) for r in ctx.w_refs)
+        if ctx.counted:
+            ctx.counted = False
+            for r in ctx.w_refs:
+                w = r()
+                if w is not None:
+                    w._krs_pending_cross = max(0, getattr(w, "_krs_pending_cross", 1) - 1)
+        if side_ok:
             # Data-gradient path first; the two weight gradients (off the critical path: only the optimizer reads them)
             # go to a second stream that starts when dx is done -- i.e. beside the HBM-bound kernel that follows on the
             # main stream (the dz / dx0 pass of the layer below, or the DotInteraction gradient and the table update
@@ -243,8 +274,12 @@ class CrossLayerFn(torch.autograd.Function):
             with torch.cuda.stream(side):
                 D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32, out=dk)   # dK = h^T dz     [p, d]
                 D.gemm(xc, dh, a_is_km=True, out_dtype=torch.float32, out=dd)  # dU = x^T dh     [d, p]
-            for t in (h, dz, xc, dh, dk, dd):
+                # the casts to the weights' dtype (bf16 variables) belong to this stream too: on the main stream they
+                # would read dk / dd with nothing ordering them behind the two products
+                dk_out, dd_out = dk.to(k_dt), dd.to(down_dt)
+            for t in (h, dz, xc, dh, dk, dd, dk_out, dd_out):
                 t.record_stream(side)
+            dk, dd = dk_out, dd_out
             _queue_wgrad_sync(task)
         elif low_rank:
             dk, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)      # dK = h^T dz     [p, d]
@@ -397,7 +432,7 @@ class EmbedBagFn(torch.autograd.Function):
         ids, offsets, weights, scale = ctx.saved_tensors
         bags = ctx.bags
         g = _gather_feature_grads(gs, ctx.batch, bags.dim, *ctx.out_meta)
-        ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
+        ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets, global_order=False)
         grads = bags.backward_dense(ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                                     bag_scale=scale)
         grads = [gr.to(dt) for gr, dt in zip(grads, ctx.table_dtypes)]
@@ -444,7 +479,7 @@ class EmbedBagFusedFn(torch.autograd.Function):
             bags.feature_desc(batch, hots, ids.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                ws = bags.plan_backward(ids, batch, hots=hots, offsets=offsets)
+                ws = bags.plan_backward(ids, batch, hots=hots, offsets=offsets, global_order=False)
                 done = torch.cuda.Event()
                 done.record(side)
             for t in (ws, ids, offsets):
@@ -472,7 +507,7 @@ class EmbedBagFusedFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_event(done)
             ws.record_stream(torch.cuda.current_stream())
         else:
-            ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets)
+            ws = bags.plan_backward(ids, ctx.batch, hots=ctx.hots, offsets=offsets, global_order=False)
         opt = ctx.optimizer  # a kind string, or an object with .fused_kind / .next_hyper() (the layer's group)
         kind = opt if isinstance(opt, str) else opt.fused_kind
         hyper = None if isinstance(opt, str) else opt.next_hyper()   # also refreshes scheduled learning rates

@@ -24,6 +24,8 @@
 // Algorithmic bytes: bags*D*s_g + nnz*(4+8) + U*(2*D*s_t [+ 2*D*4 per slot plane]).
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "krs_common.h"
 #include "krs_scan.h"
@@ -72,6 +74,7 @@ struct PlanLayout {
   uint32_t* seg_start;    // = vals_in, next n words: first sorted position of every segment
   uint32_t* n_seg;        // number of segments (a trailing run of invalid keys counts as one)
   uint32_t* n_long;       // number of LongItems (device scalar); [1] partial rows handed out; [2] MultiSegs
+  uint32_t* sort_mode;    // 0 = global sort (out-of-range lookups form ONE trailing run), != 0 = table-segmented sort
   LongItem* long_list;    // work items of the segments longer than kLongSeg (any order)
   MultiSeg* multi_list;   // segments longer than kChunk
   float* partials;        // [<= 2 * nnz / kChunk + 2] fp32 partial rows, kPartialBytes apart
@@ -586,7 +589,8 @@ PlanLayout plan_layout(void* ws, int64_t nnz, bool need_temp = false) {
   l.vals_in = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8 + 8, 256);
   l.vals_sorted = reinterpret_cast<uint64_t*>(p + o); o += align_up(n * 8, 256);
   l.n_seg = reinterpret_cast<uint32_t*>(p + o);
-  l.n_long = l.n_seg + 1; o += 256;
+  l.n_long = l.n_seg + 1;
+  l.sort_mode = l.n_seg + 8; o += 256;
   // every long segment has <= len / kChunk + 1 items; there are <= n / kLongSeg long segments
   l.long_list = reinterpret_cast<LongItem*>(p + o); o += align_up((n / kLongSeg + n / kChunk + 2) * sizeof(LongItem), 256);
   l.multi_list = reinterpret_cast<MultiSeg*>(p + o); o += align_up((n / kChunk + 2) * sizeof(MultiSeg), 256);
@@ -1602,8 +1606,12 @@ __global__ void long_list_kernel(const uint32_t* seg_start, const uint32_t* n_se
   }
   for (uint32_t c = 0; c < nch; ++c) items[base + c] = LongItem{(uint32_t)u, c, nch > 1 ? pb + c : 0xffffffffu};
 }
-__global__ void count_unique_kernel(const uint32_t* keys, const uint32_t* n_seg, int64_t nnz, int64_t* n_unique) {
-  // segments minus the trailing run of invalid keys, if any
+__global__ void count_unique_kernel(const uint32_t* keys, const uint32_t* n_seg, const uint32_t* sort_mode, int64_t nnz,
+                                    int64_t* n_unique) {
+  // segments minus the trailing run of invalid keys, if any.  A table-segmented plan leaves the out-of-range lookups at
+  // the end of every TABLE's run: the compact form cannot be built from it (-1; the host entry refuses such a plan
+  // when it has seen the plan call, this covers a workspace that was moved)
+  if (*sort_mode != 0) { *n_unique = -1; return; }
   *n_unique = (int64_t)*n_seg - (nnz > 0 && keys[nnz - 1] == kInvalidKey ? 1 : 0);
 }
 
@@ -1719,6 +1727,21 @@ extern "C" size_t krs_embed_bag_bwd_workspace_bytes(int64_t nnz) {
   return plan_layout(nullptr, nnz, true).total_bytes;
 }
 #endif
+
+// Which sort produced the plan in a workspace (host side, keyed by the workspace address): krs_embed_bag_bwd_sparse
+// refuses a table-segmented plan.  The same fact is kept in the workspace itself (PlanLayout::sort_mode).
+static std::mutex g_plan_mode_mutex;
+static std::unordered_map<const void*, int> g_plan_modes;
+static void remember_plan_mode(const void* workspace, int by_table) {
+  std::lock_guard<std::mutex> lock(g_plan_mode_mutex);
+  if (g_plan_modes.size() > (1u << 16)) g_plan_modes.clear();
+  g_plan_modes[workspace] = by_table;
+}
+static int recall_plan_mode(const void* workspace) {   // -1 = never seen
+  std::lock_guard<std::mutex> lock(g_plan_mode_mutex);
+  auto it = g_plan_modes.find(workspace);
+  return it == g_plan_modes.end() ? -1 : it->second;
+}
 
 // Table-segmented sort (rs::scatter_seg_kernel) when the host descriptors are given and the lookups are laid out for
 // it: dense bags, the features of a table neighbours, tables (and their row bases) ascending with the features.
@@ -1881,6 +1904,8 @@ static int plan_impl(const krs_table* tables, const krs_table* tables_host, int 
   KRS_CHECK_LAUNCH("seg_emit_kernel");
   // segments too long for one lane group (at most nnz / kLongSeg of them)
   KRS_HIP(hipMemsetAsync(l.n_long, 0, 3 * sizeof(uint32_t), st));
+  KRS_HIP(hipMemsetAsync(l.sort_mode, by_table ? 1 : 0, sizeof(uint32_t), st));
+  remember_plan_mode(workspace, by_table ? 1 : 0);
   hipLaunchKernelGGL(long_list_kernel, dim3(nb), dim3(256), 0, st, l.seg_start, l.n_seg, nnz, l.n_long, l.long_list,
                      l.multi_list);
   KRS_CHECK_LAUNCH("long_list_kernel");
@@ -1993,8 +2018,11 @@ extern "C" int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats, c
     KRS_HIP(hipMemsetAsync(n_unique, 0, sizeof(int64_t), st));
     return KRS_OK;
   }
+  if (recall_plan_mode(workspace) == 1)
+    return fail(KRS_ERR_UNSUPPORTED, "embed_bag_bwd_sparse: the workspace holds a table-segmented plan "
+                "(krs_embed_bag_bwd_plan_tables): the compact form needs the global sort of krs_embed_bag_bwd_plan");
   const PlanLayout l = plan_layout(const_cast<void*>(workspace), nnz);
-  hipLaunchKernelGGL(count_unique_kernel, dim3(1), dim3(1), 0, st, l.keys_sorted, l.n_seg, nnz, n_unique);
+  hipLaunchKernelGGL(count_unique_kernel, dim3(1), dim3(1), 0, st, l.keys_sorted, l.n_seg, l.sort_mode, nnz, n_unique);
   KRS_CHECK_LAUNCH("count_unique_kernel");
   ApplyParams p = make_apply(nullptr, 0, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   p.unique_rows = unique_rows;

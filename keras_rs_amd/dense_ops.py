@@ -224,6 +224,12 @@ def refresh_casts(params) -> int:
             C.c_int(L.fdtype(ps[0])), ptrs(plains), ptrs(trans), C.c_int(L.fdtype(plains[0])), L.stream_ptr())
         L.check(rc, "krs_cast_transpose_many")
         for p, a, b in zip(ps, plains, trans):
+            # the C ABI rewrote these buffers behind torch's back: bump their version counters (host-side bookkeeping,
+            # no kernel), so that a backward pass that still holds them from an EARLIER forward -- a retained graph,
+            # two forwards before one backward across an optimizer step, a teacher / EMA forward -- fails autograd's
+            # saved-tensor check loudly instead of differentiating against the new weights' copies
+            torch.autograd.graph.increment_version(a)
+            torch.autograd.graph.increment_version(b)
             p._krs_cast = (_cast_cache_key(p, ddt), a, b)
     return len(todo)
 

@@ -126,11 +126,13 @@ class FusedBags:
     # ---- K2 ---------------------------------------------------------------
     def plan_backward(self, ids: torch.Tensor, batch: int, hots: Sequence[int] | None = None,
                       offsets: torch.Tensor | None = None, err_flag: torch.Tensor | None = None,
-                      global_order: bool = False):
+                      global_order: bool = True):
         """Sorts the lookups by global row (krs_embed_bag_bwd_plan / _plan_tables).  Returns the opaque
         workspace tensor the apply calls consume; depends only on the ids, not on gradients.
-        global_order: out-of-range ids must form ONE trailing run (what backward_sparse needs); otherwise dense
-        bags take the table-segmented sort, which leaves them at the end of their table's run."""
+        global_order (default): the global sort -- out-of-range ids form ONE trailing run, every apply form accepts
+        the plan.  global_order=False: dense bags take the faster table-segmented sort, which leaves them at the end
+        of their table's run; backward_dense / backward_fused skip them wherever they are (the autograd functions
+        ask for this form), backward_sparse refuses such a plan (KRS_ERR_UNSUPPORTED)."""
         L.require_device(ids, "ids")
         nnz = ids.numel()
         nbytes = L.lib().krs_embed_bag_bwd_workspace_bytes(C.c_int64(nnz))
@@ -218,4 +220,7 @@ class FusedBags:
             C.c_int64(nnz), L.ptr(ws), L.ptr(rows), L.ptr(vals), L.ptr(n_u), L.stream_ptr())
         L.check(rc, "krs_embed_bag_bwd_sparse")
         u = int(n_u.item())
+        if u < 0:
+            raise L.KrsError("krs_embed_bag_bwd_sparse: the workspace holds a table-segmented plan; "
+                             "plan_backward(global_order=True) is what the compact form needs")
         return rows[:u], vals[:u]

@@ -217,7 +217,8 @@ def make_layers(keras) -> types.SimpleNamespace:
             new = {k: torch.as_tensor(store[k][...]).to(v.dtype) for k, v in sd.items()}
             its = {k: int(store["iterations/" + k][...]) for k in (extra or {}).get("iterations", {})
                    if "iterations/" + k in store}
-            new["_extra_state"] = {"iterations": its}
+            if extra is not None:     # (a module without extra state rejects the key under strict loading)
+                new["_extra_state"] = {"iterations": its}
             self._impl.load_state_dict(new)
 
         def preprocess(self, inputs, weights=None, training=False):

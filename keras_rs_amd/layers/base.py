@@ -210,6 +210,96 @@ def clone_initializer(init: Initializer) -> Initializer:
 
 
 # --------------------------------------------------------------------------- #
+# regularizers (keras.regularizers subset: L1, L2, L1L2, callables).  A regulariser on a weight is what it is in
+# Keras: a penalty term the layer REPORTS in `layer.losses` (evaluated on the current weight at access time) and the
+# training loop adds to its loss -- keras.layers.Dense(kernel_regularizer=...) inside the reference's FeatureCross
+# (feature_cross.py:134-151) and keras.layers.Embedding(embeddings_regularizer=...) under EmbedReduce do exactly that.
+# The penalties are O(weight) elementwise sums on small dense weights, evaluated with torch (not part of the hot path).
+# --------------------------------------------------------------------------- #
+class Regularizer:
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def get_config(self) -> dict:
+        return {}
+
+    def serialize(self) -> dict:
+        return {"class_name": type(self).__name__, "config": self.get_config()}
+
+
+class L1L2(Regularizer):
+    """keras.regularizers.L1L2: l1 * sum(|x|) + l2 * sum(x^2), in fp32."""
+
+    def __init__(self, l1: float = 0.0, l2: float = 0.0):
+        for name, v in (("l1", l1), ("l2", l2)):
+            if v is None or not math.isfinite(float(v)) or float(v) < 0:
+                raise ValueError(f"Invalid value for argument {name}: expected a non-negative finite float. Received: {name}={v}")
+        self.l1, self.l2 = float(l1), float(l2)
+
+    def __call__(self, x):
+        xf = x.float()
+        out = xf.new_zeros(())
+        if self.l1:
+            out = out + self.l1 * xf.abs().sum()
+        if self.l2:
+            out = out + self.l2 * xf.square().sum()
+        return out
+
+    def get_config(self):
+        return {"l1": self.l1, "l2": self.l2}
+
+
+class L1(L1L2):
+    def __init__(self, l1: float = 0.01):
+        super().__init__(l1=l1, l2=0.0)
+
+    def get_config(self):
+        return {"l1": self.l1}
+
+
+class L2(L1L2):
+    def __init__(self, l2: float = 0.01):
+        super().__init__(l1=0.0, l2=l2)
+
+    def get_config(self):
+        return {"l2": self.l2}
+
+
+class CallableRegularizer(Regularizer):
+    def __init__(self, fn: Callable):
+        self.fn = fn
+
+    def __call__(self, x):
+        return self.fn(x)
+
+    def get_config(self):
+        return {"fn": getattr(self.fn, "__name__", repr(self.fn))}
+
+
+_REGULARIZERS = {"l1": lambda: L1(), "l2": lambda: L2(), "l1_l2": lambda: L1L2(l1=0.01, l2=0.01),
+                 "L1": L1, "L2": L2, "L1L2": L1L2}
+
+
+def get_regularizer(identifier):
+    """None | Regularizer | "l1" / "l2" / "l1_l2" | serialized dict | callable  (keras.regularizers.get)."""
+    if identifier is None or isinstance(identifier, Regularizer):
+        return identifier
+    if isinstance(identifier, str):
+        if identifier not in _REGULARIZERS:
+            raise ValueError(f"Unknown regularizer '{identifier}'")
+        return _REGULARIZERS[identifier]()
+    if isinstance(identifier, dict):
+        return _REGULARIZERS[identifier["class_name"]](**identifier.get("config", {}))
+    if callable(identifier):
+        return CallableRegularizer(identifier)
+    raise ValueError(f"Cannot interpret regularizer {identifier!r}")
+
+
+def serialize_regularizer(reg):
+    return None if reg is None else reg.serialize()
+
+
+# --------------------------------------------------------------------------- #
 # activations fused in the GEMM epilogue
 # --------------------------------------------------------------------------- #
 def relu(x):
@@ -352,6 +442,7 @@ class Layer(torch.nn.Module):
         self.supports_masking = False
         self._device = torch.device(device) if device is not None else default_device()
         self._weight_order: list[torch.nn.Parameter] = []
+        self._regularized: list[tuple[torch.nn.Parameter, Regularizer]] = []
 
     # keras spelling
     @property
@@ -366,10 +457,16 @@ class Layer(torch.nn.Module):
     def dtype(self):
         return self.dtype_policy.variable_dtype
 
-    def add_weight(self, shape, initializer, name: str, dtype=None, trainable=True) -> torch.nn.Parameter:
+    def add_weight(self, shape, initializer, name: str, dtype=None, trainable=True, regularizer=None) -> torch.nn.Parameter:
         init = get_initializer(initializer)
         value = init(tuple(shape), dtype or self.variable_dtype, self._device)
         p = torch.nn.Parameter(value, requires_grad=trainable and self.trainable)
+        reg = get_regularizer(regularizer)
+        if reg is not None:
+            self._regularized.append((p, reg))
+            # the penalty is a second gradient contribution to this weight (autograd.CrossLayerFn keeps such a weight's
+            # gradient on the main stream)
+            p._krs_has_regularizer = True
         pname = name.replace(".", "_")
         if pname in self._parameters:
             self._parameters[pname] = p  # declared as None in __init__
@@ -393,6 +490,16 @@ class Layer(torch.nn.Module):
     @property
     def variables(self):
         return self.weights
+
+    @property
+    def losses(self) -> list[torch.Tensor]:
+        """Weight-regularisation penalties of this layer and its sublayers, evaluated on the current weights
+        (keras.layers.Layer.losses): add `sum(layer.losses)` to the training loss, as `Model.fit` does."""
+        out = [reg(w) for w, reg in self._regularized if w.requires_grad]
+        for m in self.children():
+            if isinstance(m, Layer):
+                out += m.losses
+        return out
 
     def build(self, *input_shapes) -> None:
         self.built = True

@@ -76,8 +76,15 @@ class EmbedReduce(base.Layer):
         self.input_dim = int(input_dim)
         self.output_dim = int(output_dim)
         self.embeddings_initializer = base.get_initializer(embeddings_initializer)
-        self.embeddings_regularizer = embeddings_regularizer
-        self.embeddings_constraint = embeddings_constraint
+        # keras.layers.Embedding under the reference's EmbedReduce (embed_reduce.py:138-150) hands both to its variable:
+        # the regulariser's penalty appears in `layer.losses`; a constraint is a projection the KERAS optimizer applies
+        # after its update, which no optimizer here does -- rejected loudly rather than stored and dropped
+        self.embeddings_regularizer = base.get_regularizer(embeddings_regularizer)
+        if embeddings_constraint is not None:
+            raise NotImplementedError("EmbedReduce(embeddings_constraint=...) needs an optimizer that applies variable "
+                                      "constraints after each update (keras optimizers do); the optimizers of this "
+                                      "package do not -- project the table in the training loop instead")
+        self.embeddings_constraint = None
         self.mask_zero = mask_zero
         self.combiner = combiner
         self._initial_weights = weights
@@ -87,7 +94,7 @@ class EmbedReduce(base.Layer):
     def build(self, *_) -> None:
         if self.embeddings is None:
             self.embeddings = self.add_weight((self.input_dim, self.output_dim), self.embeddings_initializer,
-                                              "embeddings")
+                                              "embeddings", regularizer=self.embeddings_regularizer)
             if self._initial_weights is not None:
                 with torch.no_grad():
                     self.embeddings.copy_(torch.as_tensor(np.asarray(self._initial_weights)))
@@ -196,7 +203,7 @@ class EmbedReduce(base.Layer):
             "input_dim": self.input_dim,
             "output_dim": self.output_dim,
             "embeddings_initializer": self.embeddings_initializer.serialize(),
-            "embeddings_regularizer": self.embeddings_regularizer,
+            "embeddings_regularizer": base.serialize_regularizer(self.embeddings_regularizer),
             "embeddings_constraint": self.embeddings_constraint,
             "mask_zero": self.mask_zero,
             "combiner": self.combiner,

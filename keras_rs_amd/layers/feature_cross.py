@@ -37,8 +37,10 @@ class FeatureCross(base.Layer):
         self.pre_activation = base.get_activation(pre_activation)
         self.kernel_initializer = base.get_initializer(kernel_initializer)
         self.bias_initializer = base.get_initializer(bias_initializer)
-        self.kernel_regularizer = kernel_regularizer
-        self.bias_regularizer = bias_regularizer
+        # applied as in the reference (its Dense sublayers, feature_cross.py:134-151): the penalties appear in
+        # `layer.losses` (kernel_regularizer on BOTH kernels, bias_regularizer on the bias)
+        self.kernel_regularizer = base.get_regularizer(kernel_regularizer)
+        self.bias_regularizer = base.get_regularizer(bias_regularizer)
         self.supports_masking = True
         if self.diag_scale is not None and self.diag_scale < 0.0:  # feature_cross.py:124-128
             raise ValueError(f"`diag_scale` should be non-negative. Received: `diag_scale={self.diag_scale}`")
@@ -51,12 +53,14 @@ class FeatureCross(base.Layer):
         # [down_proj.kernel (d,p)], dense.kernel (p|d, d), dense.bias (d)
         if self.projection_dim is not None:
             self.down_kernel = self.add_weight((d, self.projection_dim),
-                                               base.clone_initializer(self.kernel_initializer), "down_kernel")
+                                               base.clone_initializer(self.kernel_initializer), "down_kernel",
+                                               regularizer=self.kernel_regularizer)
         k_in = d if self.projection_dim is None else self.projection_dim
-        self.kernel = self.add_weight((k_in, d), base.clone_initializer(self.kernel_initializer), "kernel")
+        self.kernel = self.add_weight((k_in, d), base.clone_initializer(self.kernel_initializer), "kernel",
+                                      regularizer=self.kernel_regularizer)
         if self.use_bias:
             self.bias = self.add_weight((d,), base.clone_initializer(self.bias_initializer), "bias",
-                                        dtype=torch.float32)
+                                        dtype=torch.float32, regularizer=self.bias_regularizer)
         self.built = True
 
     def call(self, x0: torch.Tensor, x: torch.Tensor | None = None) -> torch.Tensor:
@@ -100,8 +104,8 @@ class FeatureCross(base.Layer):
             "pre_activation": base.serialize_activation(self.pre_activation),
             "kernel_initializer": self.kernel_initializer.serialize(),
             "bias_initializer": self.bias_initializer.serialize(),
-            "kernel_regularizer": self.kernel_regularizer,
-            "bias_regularizer": self.bias_regularizer,
+            "kernel_regularizer": base.serialize_regularizer(self.kernel_regularizer),
+            "bias_regularizer": base.serialize_regularizer(self.bias_regularizer),
         })
         return config
 

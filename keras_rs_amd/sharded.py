@@ -324,6 +324,13 @@ class ShardedDistributedEmbedding(base.Layer):
         #   TableConfig.max_ids_per_partition / max_unique_ids_per_partition over the group's features; or an
         #   explicit (lookups, segments) pair per (home, owner) block.  Lookups that do not fit are dropped and
         #   counted (`overflow_steps`), and the capacity grows to the need every rank has seen (same step on all ranks).
+        #   What dropping means for the result (as on SparseCore, jax/embedding_utils.py:187-197): the dropped lookups
+        #   contribute nothing and are NOT renormalised away -- the mean / sqrtn scale of a bag is computed at home from
+        #   ALL its lookups and folded into the per-lookup weights before the route, so a bag that lost lookups keeps the
+        #   full-bag denominator (its output is biased towards zero for that step, not a mean over the survivors); the
+        #   backward drops the same lookups.  Capacities react two steps late and only while `update_stats` is on.
+        #   `overflow_steps` counts the steps in which anything was dropped (0 = the exact result); bench.py puts it at
+        #   the top level of its line and marks the line invalid when it is not 0.
         self.exchange = exchange
         self._capacity_spec = capacity
         self.capacity_headroom = float(capacity_headroom)
@@ -661,6 +668,13 @@ class ShardedDistributedEmbedding(base.Layer):
             cap = [up4(spec[0]), up4(spec[1])]
         elif spec == "table_config":
             tcs = [g.table_configs[t] for t in g.table_of_feature]
+            for tc in tcs:
+                for field in ("max_ids_per_partition", "max_unique_ids_per_partition"):
+                    v = getattr(tc, field, None)
+                    if v is None or int(v) <= 0:
+                        raise ValueError(f"capacity='table_config': table '{tc.name}' has {field}={v!r}; the static "
+                                         "exchange sizes its blocks from these limits (distributed_embedding_config.py:"
+                                         "54-61) and needs a positive value on every sharded table")
             cap = [up4(sum(tc.max_ids_per_partition for tc in tcs)), up4(sum(tc.max_unique_ids_per_partition for tc in tcs))]
         elif spec == "auto" and hots is not None:
             h = self.capacity_headroom
@@ -725,6 +739,17 @@ class ShardedDistributedEmbedding(base.Layer):
         if need_s > cap[1]:
             cap[1] = up64(need_s * 1.125)
         return True
+
+    def flush_exchange_stats(self) -> int:
+        """Looks at the statistics of the steps still in the two-step queue (waits for them): `overflow_steps` is then
+        final for everything run so far.  Returns it."""
+        for q in self._stats_q.values():
+            while q:
+                _, ev0, h0, key0 = q.pop(0)
+                if ev0 is not None:
+                    ev0.synchronize()
+                self._apply_stats(h0, key0)
+        return self.overflow_steps
 
     def poll_exchange_stats(self) -> bool:
         """For steps replayed from a graph (torch.cuda.graph around the step): waits for the device, looks at the

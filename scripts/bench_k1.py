@@ -113,9 +113,9 @@ if not a.fmajor_out:
     import ctypes as C
     for pv in (1, 0, 1, 0):          # KRS_EMBED_OPT_PLAN: 1 = global sort, 0 = table-segmented sort
         L.check(L.lib().krs_embed_set_option(C.c_int(2), C.c_int(pv)), "set_option")
-        print(json.dumps({"plan_variant": pv, "k2_plan_us": timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots)) * 1e6}))
-    t_plan = timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots))
-    ws = fb.plan_backward(ids, a.batch, hots=hots)
+        print(json.dumps({"plan_variant": pv, "k2_plan_us": timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots, global_order=False)) * 1e6}))
+    t_plan = timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots, global_order=False))
+    ws = fb.plan_backward(ids, a.batch, hots=hots, global_order=False)
     for variant in (0, 1, 0, 1):     # KRS_EMBED_OPT_APPLY: 0 = bag_apply_fast_kernel, 1 = the round-1 kernel
         L.check(L.lib().krs_embed_set_option(C.c_int(1), C.c_int(variant)), "set_option")
         t_ada = timeit(lambda: fb.backward_fused("adagrad", ws, grad, a.batch, nnz, hots=hots))
@@ -142,7 +142,7 @@ if not a.fmajor_out:
                         eA.record()
                 def run_plan():
                     with torch.cuda.stream(sB):
-                        fb.plan_backward(ids, a.batch, hots=hots)
+                        fb.plan_backward(ids, a.batch, hots=hots, global_order=False)
                         eB.record()
                 (run_apply(), run_plan()) if order == "apply_first" else (run_plan(), run_apply())
                 torch.cuda.synchronize()

@@ -87,7 +87,7 @@ def test_fused_adagrad_touches_exactly_the_looked_up_rows(c5):
         expect.append(((w0.float() - LR * gsum / acc.sqrt()).to(torch.bfloat16), acc))
         uniq.append(u)
         rows_before.append((w0.clone(), slots[t][u].clone()))
-    ws = fb.plan_backward(flat, B, hots=HOTS)
+    ws = fb.plan_backward(flat, B, hots=HOTS, global_order=False)
     fb.backward_fused("adagrad", ws, grad, B, flat.numel(), hots=HOTS)
     for t in range(3):
         w1, a1 = tables[t][uniq[t]], slots[t][uniq[t]]

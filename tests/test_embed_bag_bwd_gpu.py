@@ -326,7 +326,7 @@ def test_pipelined_apply_kernel_equals_round1_kernel_bit_for_bit(kind, tdt, gdt,
             tables, slots, fb = build()
             out = torch.empty((batch, cols), dtype=TORCH_DT[tdt], device=dev)
             _, scale = fb.forward(ids, batch, hots=hots, weights=w, out=out, want_scale=True)
-            ws = fb.plan_backward(ids, batch, hots=hots)
+            ws = fb.plan_backward(ids, batch, hots=hots, global_order=False)
             hyper = (0.9, 0.999, 1e-7, 0.3) if kind == "adam" else None
             fb.backward_fused(kind, ws, grad, batch, ids.numel(), hots=hots, weights=w, bag_scale=scale, hyper=hyper)
             torch.cuda.synchronize()
@@ -422,7 +422,7 @@ def test_table_segmented_plan_equals_global_plan(vocabs, dim, with_bad):
             fb = FusedBags(tables, [(tix[f], "sum", f * dim) for f in range(len(tix))], slots=slots,
                            lrs=[0.01 * (t + 1) for t in range(len(vocabs))])
             err = torch.zeros(1, dtype=torch.int32, device=dev)
-            ws = fb.plan_backward(ids, batch, hots=hots, err_flag=err)
+            ws = fb.plan_backward(ids, batch, hots=hots, err_flag=err, global_order=False)
             assert bool(int(err.item()) & 1) == with_bad
             dense = fb.backward_dense(ws, grad, batch, ids.numel(), hots=hots, weights=w)
             fb.backward_fused("adagrad", ws, grad, batch, ids.numel(), hots=hots, weights=w)
@@ -434,3 +434,40 @@ def test_table_segmented_plan_equals_global_plan(vocabs, dim, with_bad):
         for a, b in zip(res[0][part], res[1][part]):
             assert torch.equal(a, b)
     assert not torch.equal(res[0][0][0], torch.from_numpy(np.random.default_rng(9).uniform(-1, 1, (vocabs[0], dim)).astype(np.float32)).to(dev))
+
+
+def test_compact_form_refuses_a_table_segmented_plan_and_default_plan_serves_it():
+    """the table-segmented sort leaves out-of-range ids at the end of every TABLE's run, the compact
+    (sparse) form counts ONE trailing invalid run.  `plan_backward` defaults to the global sort (every apply form accepts
+    it); a plan made with global_order=False is refused by backward_sparse (KRS_ERR_UNSUPPORTED from the host registry of
+    workspaces, and n_unique = -1 from the mode word inside a workspace that was copied elsewhere)."""
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd.embedding_ops import FusedBags
+
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    batch, dim, vocabs, hots = 257, 16, [50, 70, 30], [3, 2, 4]
+    ids_np = np.concatenate([rng.integers(0, vocabs[f], batch * hots[f]) for f in range(3)]).astype(np.int32)
+    ids_np[5] = -1                       # out of range in the FIRST table (not the last run of the array)
+    ids_np[batch * 3 + 7] = 10_000       # ... and in the second
+    ids = torch.from_numpy(ids_np).to(dev)
+    tables = [torch.from_numpy(rng.uniform(-1, 1, (v, dim)).astype(np.float32)).to(dev) for v in vocabs]
+    fb = FusedBags(tables, [(f, "sum", f * dim) for f in range(3)])
+    grad = torch.from_numpy(rng.uniform(-1, 1, (batch, 3 * dim)).astype(np.float32)).to(dev)
+    ws = fb.plan_backward(ids, batch, hots=hots)                       # default: global order
+    rows, vals = fb.backward_sparse(ws, grad, batch, ids.numel(), hots=hots)
+    dense = fb.backward_dense(ws, grad, batch, ids.numel(), hots=hots)
+    full = torch.cat(dense, dim=0)
+    touched = torch.zeros(sum(vocabs), dtype=torch.bool, device=dev)
+    touched[rows] = True
+    assert rows.numel() == int((full.abs().sum(1) > 0).sum()) and torch.equal(full[rows], vals)
+    assert not bool(full[~touched].any())
+    ws_t = fb.plan_backward(ids, batch, hots=hots, global_order=False)  # table-segmented
+    d2 = fb.backward_dense(ws_t, grad, batch, ids.numel(), hots=hots)
+    for a, b in zip(dense, d2):
+        assert torch.equal(a, b)
+    with pytest.raises(L.KrsError):
+        fb.backward_sparse(ws_t, grad, batch, ids.numel(), hots=hots)
+    moved = ws_t.clone()                                                 # an address the library has not seen
+    with pytest.raises(L.KrsError):
+        fb.backward_sparse(moved, grad, batch, ids.numel(), hots=hots)

@@ -207,3 +207,83 @@ def test_c3_gemm_slices_against_fp64():
     torch.testing.assert_close(dk[:, cols].double(), h.double().t() @ dz[:, cols].double(), rtol=2e-4, atol=2e-3)
     du, _ = Dn.gemm(x, dh, a_is_km=True, out_dtype=torch.float32)                         # dU = x^T dh
     torch.testing.assert_close(du[cols].double(), x[:, cols].double().t() @ dh.double(), rtol=2e-4, atol=2e-3)
+
+
+def test_c3_full_size_meets_the_oracle_on_a_slice(c3):
+    """Round-3 review: at C3 full size the pooled output and the fused Adagrad update met the oracle only through
+    properties and a torch slice.  Here the ORACLE itself (oracle/krs_oracle.c) is the checker, at the real sizes --
+    26 x 1 M x 128 bf16 tables, batch 65,536, the ml_perf bag lengths, sum / mean / sqrtn combiners:
+      * forward: krs_oracle_embed_bag_fwd on the first 4096 samples of the batch (0.9 M lookups; the tables it needs are
+        the rows those samples touch, handed to it as compact tables with remapped ids -- same rows, same order);
+      * backward: the fused Adagrad update of the FULL batch on a subset of rows (the rows the first 512 samples touch,
+        ~0.4 M of the 14 M lookups land on them, from anywhere in the batch): krs_oracle_embed_bag_bwd_dense over exactly
+        those lookups in their original order + krs_oracle_apply_optimizer(adagrad), against the rows and accumulators
+        K2 left in the real tables."""
+    from keras_rs_amd.embedding_ops import FusedBags
+    from oracle import krs_oracle as ko
+    from tests.helpers import to_f32, to_np
+
+    tables, _, g = c3
+    S, RS, LR, ACC0 = 4096, 512, 0.01, 0.1
+    combs = [("sum", "mean", "sqrtn")[t % 3] for t in range(T)]
+    ids = [torch.randint(0, V, (B, h), device=DEV, generator=g, dtype=torch.int32) for h in HOTS]
+    flat = torch.cat([x.reshape(-1) for x in ids])
+    nnz = flat.numel()
+    tabs2 = [t.clone() for t in tables]
+    slots = [torch.full((V, D), ACC0, device=DEV) for _ in range(T)]
+    fb = FusedBags(tabs2, [(t, combs[t], t * D) for t in range(T)], slots=slots, lrs=[LR] * T)
+    out, scale = fb.forward(flat, B, hots=HOTS, want_scale=True)
+    # ---- forward slice through the oracle
+    comp, cids = [], []
+    for t in range(T):
+        uniq, inv = torch.unique(ids[t][:S].long(), return_inverse=True)
+        comp.append(np.ascontiguousarray(to_np(tables[t][uniq])))
+        cids.append(inv.reshape(-1).to(torch.int32).cpu().numpy())
+    feats = ko.make_features(list(range(T)), combs, [t * D for t in range(T)], hots=HOTS, batch=S)
+    exp = np.zeros((S, T * D), np.uint16)
+    exp_scale = np.zeros(T * S, np.float32)
+    flags = ko.embed_bag_fwd_raw(ko.make_tables(comp), ko.BF16, feats, np.concatenate(cids), None, None, S, D, exp, exp_scale)
+    assert flags == 0
+    got = to_np(out[:S])
+    assert (got == exp).mean() > 0.9999, (got == exp).mean()
+    np.testing.assert_allclose(to_f32(got), to_f32(exp), rtol=2.0 ** -7, atol=1e-7)
+    sc = scale.reshape(T, B)[:, :S].cpu().numpy()
+    np.testing.assert_allclose(sc, exp_scale.reshape(T, S), rtol=1e-6, atol=0)
+    # ---- fused Adagrad at full size, checked by the oracle on a subset of rows
+    grad = (torch.rand(B, T * D, device=DEV, generator=g) - 0.5).to(torch.bfloat16)
+    ws = fb.plan_backward(flat, B, hots=HOTS, global_order=False)
+    fb.backward_fused("adagrad", ws, grad, B, nnz, hots=HOTS, bag_scale=scale)
+    torch.cuda.synchronize()
+    rows_sel, ids_c, lens = [], [], []
+    for t in range(T):
+        R = torch.unique(ids[t][:RS].long())
+        mask = torch.isin(ids[t].long(), R)
+        sel = ids[t].long()[mask]                           # sample-major, position-minor: the feature's lookup order
+        ids_c.append(torch.searchsorted(R, sel).to(torch.int32).cpu().numpy())
+        lens.append(mask.sum(1).cpu().numpy().astype(np.int64))
+        rows_sel.append(R)
+    offsets = np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.int64)
+    n_sel = int(offsets[-1])
+    assert 100_000 < n_sel < 2_000_000, n_sel
+    feats_csr = ko.make_features(list(range(T)), combs, [t * D for t in range(T)])
+    dense = [np.zeros((len(r), D), np.float32) for r in rows_sel]
+    gnp = np.ascontiguousarray(to_np(grad))
+    ko.embed_bag_bwd_dense(ko.make_tables(dense), feats_csr, np.concatenate(ids_c), offsets, None,
+                           np.ascontiguousarray(scale.cpu().numpy()), gnp, B, D)
+    worst = 1.0
+    for t in range(T):
+        R = rows_sel[t]
+        tab = np.ascontiguousarray(to_np(tables[t][R]))             # the rows BEFORE the update
+        acc = np.full((len(R), D), ACC0, np.float32)
+        ko.apply_optimizer(tab, acc, dense[t], None, LR, "adagrad")
+        got_t, got_a = to_np(tabs2[t][R]), slots[t][R].cpu().numpy()
+        np.testing.assert_allclose(got_a, acc, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(to_f32(got_t), to_f32(tab), rtol=2.0 ** -7, atol=1e-7)
+        worst = min(worst, float((got_t == tab).mean()))
+        assert not np.array_equal(got_t, to_np(tables[t][R]))      # the rows did move
+    assert worst > 0.999, worst
+    # rows outside every lookup of the batch keep value and accumulator (checked on the heaviest table)
+    f = 20
+    untouched = torch.ones(V, dtype=torch.bool, device=DEV)
+    untouched[ids[f].reshape(-1).long()] = False
+    assert torch.equal(tabs2[f][untouched], tables[f][untouched]) and bool((slots[f][untouched] == ACC0).all())

