@@ -394,6 +394,8 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     from events recorded at the step boundaries) and, with `probe_steps`, `probe` (in-step kernel spans of that many
     EXTRA steps run after the timed region; keras_rs_amd/probe.py).
     With `loader`, every step takes its preprocessed ids from it (host-resident inputs)."""
+    from keras_rs_amd import probe as krs_probe
+
     ids, dense = make_inputs(a, hots, b_local, rank, dev)
     pre = model.embedding.preprocess(ids)
     scale = 1.0 / (b_local * (a.tables + 1) * a.dim)
@@ -425,7 +427,8 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
                     opt_box[1].launch(p)
         opt = opt_box[0]
         if dp:
-            opt_box[1].wait()
+            with krs_probe.span("allreduce_wait"):
+                opt_box[1].wait()
         opt.step()
         opt.zero_grad(set_to_none=True)
 
@@ -529,12 +532,49 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
                 mask[v.reshape(-1).long()] = True
                 uniq += int(mask.sum())
             res["unique_rows"] = uniq
+    if probe_steps > 0 and sharded:
+        res["phases"] = exchange_phases(res["probe"], probe_steps, world)
     flush = getattr(model.embedding, "flush_exchange_stats", None)
     res["overflow_steps"] = int(flush()) if flush is not None else 0
     ex = getattr(model.embedding, "last_exchange", None)
     if ex:
         res["exchange"] = dict(ex)
     return res
+
+
+PHASES = ("route", "counts_host_wait", "a2a_ids", "unpack", "pool", "a2a_partials", "combine", "gather_grads",
+          "a2a_grads", "k2", "allreduce_wait")
+
+
+def exchange_phases(pr, n_steps, world):
+    """Per-phase GPU time of the sharded step (event spans on the launch stream inside real steps, keras_rs_amd/probe.py
+    spans in sharded.py): this rank's ms per step, then min / max over the ranks; for the all-to-alls the bytes this rank
+    sends to OTHER ranks per call and the rate that makes (per rank: xGMI is point-to-point, so with N ranks the bytes
+    spread over N - 1 links).  What a first hardware N > 1 run needs to attribute its time (examples/ml_perf/main.py:330-357
+    wraps a profiler trace around the run for the same purpose)."""
+    mine = {}
+    for name in PHASES:
+        if name in pr:
+            e = pr[name]
+            mine[name] = {"ms": e["ms_total"] / n_steps, "calls": e["calls"] // n_steps, "bytes": e["work_total"] / n_steps}
+    allr = [mine]
+    if world > 1:
+        allr = [None] * world
+        torch.distributed.all_gather_object(allr, mine)
+    out = {}
+    for name in PHASES:
+        rows = [r[name] for r in allr if r and name in r]
+        if not rows:
+            continue
+        ms = [r["ms"] for r in rows]
+        ent = {"ms_per_step": mine.get(name, rows[0])["ms"], "min_ms": min(ms), "max_ms": max(ms), "calls_per_step": rows[0]["calls"]}
+        if name.startswith("a2a"):
+            b = mine.get(name, rows[0])["bytes"]
+            ent["bytes_off_rank_per_step"] = int(b)
+            ent["bytes_per_link_per_step"] = int(b / max(world - 1, 1))
+            ent["GB_per_s_per_rank"] = b / (max(ms) * 1e-3) / 1e9 if max(ms) > 0 else None
+        out[name] = ent
+    return out
 
 
 def step_stats(step_ms):
@@ -773,6 +813,13 @@ def main():
         out["exchange"] = {k: v for k, v in ex.items() if k in ("mode", "bytes", "capacity", "need", "received")}
         # static exchange: lookups beyond a block's capacity are DROPPED (the reference's id dropping) -- `value` would
         # then count dropped lookups as work, so the line says so at the top level
+        if "phases" in r1:
+            ph = dict(r1["phases"])
+            gpu_ms = step_stats(r1["step_ms"])["median_ms"]
+            ph["dense_and_rest"] = {"ms_per_step": gpu_ms - sum(v["ms_per_step"] for v in ph.values()),
+                                    "note": "median GPU step minus the phases above: DotInteraction + cross stack forward / "
+                                            "backward, dense optimizer, launch gaps (the probe steps keep every span on one stream)"}
+            out["phases"] = ph
         out["overflow_steps"] = int(r1.get("overflow_steps", 0)) + int(r2.get("overflow_steps", 0))
         if out["overflow_steps"]:
             out["invalid"] = ("the static exchange dropped lookups in %d step(s) (capacity %s, largest per-owner need %s): "

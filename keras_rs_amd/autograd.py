@@ -248,8 +248,19 @@ class CrossLayerFn(torch.autograd.Function):
         direct = dx0 if same else (dxd if need_dxd else g)  # dL/dx through "+ x" and "diag * x"
         # (worth it when the kernels are long against a launch: at a per-rank batch of 8192 the step is bound by the
         #  host's enqueue rate and the extra events cost more than the overlap returns: 2.42 -> 2.54 ms)
+        # a weight with several pending uses gets several contributions in THIS pass (summed by autograd's input buffer
+        # on the main stream): the first backward that runs sees the full count and marks the pass, the later ones --
+        # which see a count of one again -- read the mark
+        shared = False
+        for r in ctx.w_refs:
+            w = r()
+            if w is None:
+                continue
+            if getattr(w, "_krs_pending_cross", 1) != 1:
+                w._krs_shared_in_task = task
+            shared = shared or (task != -1 and getattr(w, "_krs_shared_in_task", None) == task)
         side_ok = low_rank and WGRAD_SIDE_STREAM and dz.is_cuda and dz.shape[0] >= WGRAD_SIDE_MIN_ROWS and \
-            all(_wgrad_side_ok(r()) for r in ctx.w_refs)
+            not shared and all(_wgrad_side_ok(r()) for r in ctx.w_refs)
         if ctx.counted:
             ctx.counted = False
             for r in ctx.w_refs:

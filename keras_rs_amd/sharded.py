@@ -59,6 +59,7 @@ import torch
 import torch.distributed as dist
 
 from keras_rs_amd import _lib as L
+from keras_rs_amd import probe
 from keras_rs_amd.layers import base
 from keras_rs_amd.layers.distributed_embedding import (DistributedEmbedding, FusedOptimizer,
                                                        resolve_fused_optimizer)
@@ -769,22 +770,29 @@ class ShardedDistributedEmbedding(base.Layer):
         dev = ids.device
         n_feats = len(g.paths)
         shard = getattr(self, g.pname).data
-        r = k.route_static(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, cap_l, cap_s,
-                           self._err_flag(dev))
-        recv_packed = self._a2a(r["packed"])                                    # [n, W]: equal splits, no counts
-        rows, w, off, stats = k.unpack_static(recv_packed, cap_l, cap_s, emit_w)
+        off_rank = (n - 1) / n if n > 1 else 1.0   # one-GPU dry run: what the stand-in copies move
+        # (probe.span: per-phase event pairs when bench.py is probing -- `phases` of its line; otherwise one global read)
+        with probe.span("route"):
+            r = k.route_static(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, cap_l, cap_s,
+                               self._err_flag(dev))
+        words = r["packed"].shape[1]
+        with probe.span("a2a_ids", off_rank * 4 * n * words):
+            recv_packed = self._a2a(r["packed"])                                # [n, W]: equal splits, no counts
+        with probe.span("unpack"):
+            rows, w, off, stats = k.unpack_static(recv_packed, cap_l, cap_s, emit_w)
         pdt = self._partial_dtype or self.compute_dtype
         if isinstance(pdt, str):
             pdt = {"float32": torch.float32, "bfloat16": torch.bfloat16}[pdt]
-        partial = k.pool_segments(shard, rows, off, w, pdt)                       # [n * cap_s, dim]: one per segment slot
-        back = self._a2a(partial)
-        slab = torch.empty((batch, lead + n_feats * g.dim), dtype=back.dtype, device=dev)
-        k.combine(back, r["bag_seg"], batch, n_feats, g.dim, slab[:, lead:])
-        if slab.dtype != self.compute_dtype:
-            slab = slab.to(self.compute_dtype)
+        with probe.span("pool"):
+            partial = k.pool_segments(shard, rows, off, w, pdt)                   # [n * cap_s, dim]: one per segment slot
+        with probe.span("a2a_partials", off_rank * partial.numel() * partial.element_size()):
+            back = self._a2a(partial)
+        with probe.span("combine"):
+            slab = torch.empty((batch, lead + n_feats * g.dim), dtype=back.dtype, device=dev)
+            k.combine(back, r["bag_seg"], batch, n_feats, g.dim, slab[:, lead:])
+            if slab.dtype != self.compute_dtype:
+                slab = slab.to(self.compute_dtype)
         es = back.element_size()
-        words = r["packed"].shape[1]
-        off_rank = (n - 1) / n if n > 1 else 1.0   # one-GPU dry run: what the stand-in copies move
         self.last_exchange = dict(mode="static", capacity=(cap_l, cap_s),
                                   bytes=dict(ids_fwd=4 * n * words, partials_fwd=n * cap_s * g.dim * es,
                                              grads_bwd=n * cap_s * g.dim * es),
@@ -805,8 +813,10 @@ class ShardedDistributedEmbedding(base.Layer):
             cap, key = self._capacity(gi, g, batch, hots, ids.numel())
             if cap is not None:
                 return self._forward_static(gi, g, cap, key, ids, batch, hots, offsets, weights, lead, emit_w)
-        r = k.route(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, self._err_flag(dev))
-        mine, theirs = self._exchange_sizes(r["counts"])
+        with probe.span("route"):
+            r = k.route(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, self._err_flag(dev))
+        with probe.span("counts_host_wait"):
+            mine, theirs = self._exchange_sizes(r["counts"])
         send_cnt, send_segs, send_words = mine
         recv_cnt, recv_segs, recv_words = theirs
         n_seg = sum(send_segs)
@@ -821,17 +831,22 @@ class ShardedDistributedEmbedding(base.Layer):
                                   bytes_per_step=int(4 * off_words + 2 * off_segs * g.dim * es_p) if n > 1 else
                                   int(4 * sum(send_words) + 2 * n_seg * g.dim * es_p))
         # to the owners: ONE packed buffer (rows | weights | segment lengths per owner)
-        recv_packed = self._a2a(r["packed"][:sum(send_words)], send_words, recv_words)
-        rows, w, off = k.unpack(recv_packed, recv_cnt, recv_segs, emit_w)
+        with probe.span("a2a_ids", 4 * (off_words if n > 1 else sum(send_words))):
+            recv_packed = self._a2a(r["packed"][:sum(send_words)], send_words, recv_words)
+        with probe.span("unpack"):
+            rows, w, off = k.unpack(recv_packed, recv_cnt, recv_segs, emit_w)
         pdt = self._partial_dtype or self.compute_dtype
         if isinstance(pdt, str):
             pdt = {"float32": torch.float32, "bfloat16": torch.bfloat16}[pdt]
-        partial = k.pool_segments(shard, rows, off, w, pdt)
-        back = self._a2a(partial, recv_segs, send_segs)                           # home side, segment order
-        slab = torch.empty((batch, lead + n_feats * g.dim), dtype=back.dtype, device=dev)
-        k.combine(back, r["bag_seg"], batch, n_feats, g.dim, slab[:, lead:])
-        if slab.dtype != self.compute_dtype:
-            slab = slab.to(self.compute_dtype)
+        with probe.span("pool"):
+            partial = k.pool_segments(shard, rows, off, w, pdt)
+        with probe.span("a2a_partials", (off_segs if n > 1 else n_seg) * g.dim * es_p):
+            back = self._a2a(partial, recv_segs, send_segs)                       # home side, segment order
+        with probe.span("combine"):
+            slab = torch.empty((batch, lead + n_feats * g.dim), dtype=back.dtype, device=dev)
+            k.combine(back, r["bag_seg"], batch, n_feats, g.dim, slab[:, lead:])
+            if slab.dtype != self.compute_dtype:
+                slab = slab.to(self.compute_dtype)
         saved = dict(batch=batch, seg_grow=r["seg_grow"][:n_seg], send_segs=send_segs, recv_segs=recv_segs,
                      rows=rows, off=off, w=w, pdt=pdt, out_meta=(slab.dtype, slab.device))
         return slab, saved
@@ -840,12 +855,16 @@ class ShardedDistributedEmbedding(base.Layer):
         k, g = self.kernels, self._sgroups[gi]
         n_feats, batch = len(g.paths), s["batch"]
         # d(partial of a segment) = the output gradient of its bag: rows of grad viewed as [batch * n_feats, dim]
-        grad = grad.contiguous()
-        if grad.dtype != s["pdt"]:
-            grad = grad.to(s["pdt"])
-        dpart = k.gather_rows(grad.view(batch * n_feats, g.dim), s["seg_grow"])
-        dseg = self._a2a(dpart, s["send_segs"], s["recv_segs"])                   # to the owners
+        with probe.span("gather_grads"):
+            grad = grad.contiguous()
+            if grad.dtype != s["pdt"]:
+                grad = grad.to(s["pdt"])
+            dpart = k.gather_rows(grad.view(batch * n_feats, g.dim), s["seg_grow"])
+        off_rank = (self.world - 1) / self.world if self.world > 1 else 1.0
+        with probe.span("a2a_grads", off_rank * dpart.numel() * dpart.element_size()):
+            dseg = self._a2a(dpart, s["send_segs"], s["recv_segs"])               # to the owners
         lr = g.fused.lr_at(g.step)
         g.step += 1
-        k.apply_segments(getattr(self, g.pname).data, self._slot(g), s["rows"], s["off"], s["w"], dseg, lr,
-                         g.fused.kind, g.fused.hyper(g.step), 1.0 / self.world if self.grad_average else 1.0)
+        with probe.span("k2"):
+            k.apply_segments(getattr(self, g.pname).data, self._slot(g), s["rows"], s["off"], s["w"], dseg, lr,
+                             g.fused.kind, g.fused.hyper(g.step), 1.0 / self.world if self.grad_average else 1.0)

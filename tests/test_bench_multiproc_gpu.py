@@ -55,6 +55,17 @@ def test_bare_bench_command_launches_its_own_ranks():
         assert "RCCL" in d["backend"]
     assert d["a2a_bytes_per_step"] > 0 and d["exchange"]["mode"] == "static"
     assert d["step_stats"]["median_ms"] > 0 and "roofline_step" in d
+    # the N > 1 line attributes its time (round-3 review, item 5): per-phase event times with min / max over the ranks,
+    # bytes per link and the achieved rate of every all-to-all, the wait for the dense all-reduce, dropped lookups
+    ph = d["phases"]
+    for name in ("route", "a2a_ids", "unpack", "pool", "a2a_partials", "combine", "gather_grads", "a2a_grads", "k2",
+                 "allreduce_wait", "dense_and_rest"):
+        assert name in ph and ph[name]["ms_per_step"] >= 0 or name == "dense_and_rest", name
+    for name in ("a2a_ids", "a2a_partials", "a2a_grads"):
+        e = ph[name]
+        assert e["min_ms"] <= e["max_ms"] and e["bytes_off_rank_per_step"] > 0 and e["bytes_per_link_per_step"] > 0
+        assert e["GB_per_s_per_rank"] > 0
+    assert d["overflow_steps"] == 0 and "invalid" not in d
 
 
 def test_sharded_step_through_a_one_rank_rccl_communicator():
