@@ -293,7 +293,8 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
 /* Tuning / diagnostic switches of krs_gemm (process-wide; results never depend on them).
  *   KRS_GEMM_OPT_PIPELINE: main loop of the 256x256 bf16 tiles -- 0 = two-stage loop that drains the
  *   DMA queue once per K tile, 4 / 5 = ping-pong ring with that many 32-deep stages (default 4, or
- *   the environment variable KRS_GEMM_PIPE at first use). */
+ *   the environment variable KRS_GEMM_PIPE at first use); 6 = prefetch schedule, 7 = 4 plus the deep ring on the
+ *   128x128 tile for small outputs (both measured no faster, kept for A/B). */
 enum { KRS_GEMM_OPT_PIPELINE = 0 };
 int krs_gemm_set_option(int key, int value);
 

@@ -1050,6 +1050,113 @@ __device__ __forceinline__ void pp_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Round 4: the 128x128 tile on a DEEP ring, for outputs too small to fill the chip with 256x256 tiles (the per-rank
+// step of a strongly-scaled job: M = 8192 against N = 512 is 64 such tiles, 256 tiles of 128x128).  A 128x128 tile moves
+// twice the operand bytes per flop of the 256x256 one, so this kernel is bound by the L2 -> LDS request path four to
+// one (16 LDS-DMA instructions of ~40-60 clocks against 8 MFMA of 32 clocks per wave and 32-k block): what matters is
+// that the DMA queue never drains.  The two-stage kernel above issues one 32 KB tile, computes, and waits for
+// `vmcnt(0)` once per tile; here K advances in blocks of 32 (A piece + B piece = 16 KB), NSTG stages (8 = 128 KB with
+// one workgroup per CU, 4 = 64 KB with two), NSTG-1 blocks in flight behind a COUNTED `vmcnt`, one barrier per block.
+// Same fragment layout, same k order per accumulator as gemm_glds_kernel: bit-identical results.
+template <int NSTG, int EPI>
+__global__ __launch_bounds__(256, (NSTG <= 4 ? 2 : 1)) void gemm_ring128_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PIECE = 128 * 64, STAGE = 2 * PIECE;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t nt = (p.n + BN - 1) / BN;
+  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int64_t m_tile = (slot / nt) * 8 + xcd;
+  if (m_tile * BM >= p.m) return;
+  const int64_t m0 = m_tile * BM, n0 = (slot % nt) * BN;
+  const int nkb = (int)(p.k / 32);   // (the host guarantees nkb >= NSTG)
+
+  // instruction q = wave*2 + i of a piece fills rows q*16 .. q*16+15 (64 B each): lane = row*4 + physical chunk, which
+  // holds the logical 16-byte chunk pc ^ ((row >> 2) & 3) -- the image of gemm_pp256_kernel
+  const char* ap[2];
+  const char* bp[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    ap[i] = p.a + min(m0 + r, p.m - 1) * p.lda * 2 + c * 16;
+    bp[i] = p.b + min(n0 + r, p.n - 1) * p.ldb * 2 + c * 16;
+  }
+  const int dma_off = wave * 2048;
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr)ap[i], (lptr)(smem + stage * STAGE + dma_off + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)bp[i], (lptr)(smem + stage * STAGE + PIECE + dma_off + i * 1024), 16, 0, 0);
+      ap[i] += 64;
+      bp[i] += 64;
+    }
+  };
+  const int frow = lane & 31, fhalf = lane >> 5, key = (frow >> 2) & 3;
+  const int a_lane = (wm * 64 + frow) * 64 + ((fhalf ^ key) << 4);
+  const int b_lane = PIECE + (wn * 64 + frow) * 64 + ((fhalf ^ key) << 4);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+#pragma unroll
+  for (int j = 0; j < NSTG - 1; ++j) issue(j);
+  int rd = 0, wr = NSTG - 1;
+  const int last = nkb - 1;
+  for (int kb = 0; kb <= last; ++kb) {
+    // block kb has landed when at most the blocks behind it (4 instructions each) are still in flight
+    const int rem = min(last - kb, NSTG - 2);
+    if constexpr (NSTG == 8) {
+      switch (rem) {
+        case 6: pp_vmcnt<24>(); break;
+        case 5: pp_vmcnt<20>(); break;
+        case 4: pp_vmcnt<16>(); break;
+        case 3: pp_vmcnt<12>(); break;
+        case 2: pp_vmcnt<8>(); break;
+        case 1: pp_vmcnt<4>(); break;
+        default: pp_vmcnt<0>(); break;
+      }
+    } else {
+      switch (rem) {
+        case 2: pp_vmcnt<8>(); break;
+        case 1: pp_vmcnt<4>(); break;
+        default: pp_vmcnt<0>(); break;
+      }
+    }
+    pp_barrier();   // block kb visible to every wave; every wave is done with block kb-1 (its MFMAs consumed the reads)
+    if (kb + NSTG - 1 <= last) issue(wr);
+    const char* st = smem + rd * STAGE;
+#pragma unroll
+    for (int hk = 0; hk < 2; ++hk) {
+      const int x = hk * 32;
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(st + (b_lane ^ x) + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + (a_lane ^ x) + i * 2048);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                            __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+    }
+    rd = rd + 1 == NSTG ? 0 : rd + 1;
+    wr = wr + 1 == NSTG ? 0 : wr + 1;
+  }
+  pp_barrier();      // the staging of the epilogue re-uses the ring
+  lds_dma_retired<0>();
+  gemm_epilogue<EPI>(p, acc, smem, m0, n0, 0);
+}
+
 template <bool TN, int NSTG, int EPI, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int mt, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1603,7 +1710,7 @@ int gemm_pipe() {
   if (g_pipe < 0) {
     const char* e = getenv("KRS_GEMM_PIPE");
     g_pipe = e ? atoi(e) : 4;
-    if (g_pipe != 0 && g_pipe != 4 && g_pipe != 5 && g_pipe != 6) g_pipe = 4;
+    if (g_pipe != 0 && g_pipe != 4 && g_pipe != 5 && g_pipe != 6 && g_pipe != 7) g_pipe = 4;
   }
   return g_pipe;
 }
@@ -1742,6 +1849,40 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     else KRS_GLDS256_LAUNCH(0)
 #undef KRS_GLDS256_LAUNCH
     KRS_CHECK_LAUNCH("gemm_glds256_kernel");
+    return KRS_OK;
+  }
+  if (use_glds && ES == 2 && gemm_pipe() == 7 && p.k % 32 == 0 && p.k / 32 >= 8) {
+    // (krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, 7): A/B only.)  The deep ring on the 128x128 tile -- one workgroup per
+    // CU with eight stages while the tiles fit one round of the 256 CUs, two per CU with four stages beyond -- measured
+    // EQUAL or slower than the two-stage kernel below (profiles/r4_gemm_ring128_b8192.txt: h = x U at M = 8192 47.2 us
+    // against 44.9, at M = 16384 77.8 against 64.7): a CU with one 128x128 tile already draws its operands at the
+    // ~40 GB/s per CU of the L2 -> LDS path that bounds the 256x256 kernels too, and the two-stage kernel's 128-byte
+    // row pieces are whole cache lines where the ring's 64-byte pieces are halves.  Not dispatched.
+    const int64_t tiles = ceil_div(p.m, BM) * ceil_div(p.n, BN);
+#define KRS_RING128_LAUNCH(NS, EP)                                                                   \
+  {                                                                                                  \
+    auto kern = gemm_ring128_kernel<NS, EP>;                                                         \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) {                                                                                 \
+      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, NS * 16384));          \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(256), NS * 16384, st, p);                                    \
+  }
+#define KRS_RING128_CASE(NS)                                                                         \
+  {                                                                                                  \
+    if (epi == 1) KRS_RING128_LAUNCH(NS, 1)                                                          \
+    else if (epi == 2) KRS_RING128_LAUNCH(NS, 2)                                                     \
+    else KRS_RING128_LAUNCH(NS, 0)                                                                   \
+  }
+    if constexpr (ES == 2) {
+      if (tiles <= 320) KRS_RING128_CASE(8)
+      else KRS_RING128_CASE(4)
+    }
+#undef KRS_RING128_CASE
+#undef KRS_RING128_LAUNCH
+    KRS_CHECK_LAUNCH("gemm_ring128_kernel");
     return KRS_OK;
   }
   if (use_glds) {
@@ -2131,7 +2272,7 @@ using namespace krs;
 
 extern "C" int krs_gemm_set_option(int key, int value) {
   if (key == KRS_GEMM_OPT_PIPELINE) {
-    KRS_REQUIRE(value == 0 || value == 4 || value == 5 || value == 6, "krs_gemm_set_option: pipeline must be 0, 4, 5 or 6");
+    KRS_REQUIRE(value == 0 || (value >= 4 && value <= 7), "krs_gemm_set_option: pipeline must be 0, 4, 5, 6 or 7");
     g_pipe = value;
     return KRS_OK;
   }
