@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="one rank only: capture the step in a HIP graph (keras_rs_amd.graphs.GraphedStep) and time its "
                          "replays -- for the host-bound per-rank step of a strongly-scaled job (--force-sharded --batch 8192)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="sharded runs: keep the id exchange of every step at the head of its forward (A/B of prefetch())")
     ap.add_argument("--rccl-self", action="store_true",
                     help="with --force-sharded at N = 1: route the layer's collectives through a ONE-rank RCCL communicator "
                          "instead of device copies (proves the RCCL call path on a one-GPU box)")
@@ -398,6 +400,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
 
     ids, dense = make_inputs(a, hots, b_local, rank, dev)
     pre = model.embedding.preprocess(ids)
+    sharded_run = world > 1 or a.force_sharded
     scale = 1.0 / (b_local * (a.tables + 1) * a.dim)
     k1_ev = []
     g_xl = torch.full((b_local, (a.tables + 1) * a.dim), scale, dtype=torch.bfloat16, device=dev)
@@ -405,8 +408,15 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     g_inter = torch.full((b_local, n_inter), 0.1 * scale, dtype=torch.bfloat16, device=dev)
     dp = world > 1 or (a.force_sharded and a.rccl_self)   # dense gradients go through the all-reduce
 
+    # sharded + static exchange: the id side of the NEXT step's lookup (route -> id all-to-all -> unpack) runs on the
+    # layer's exchange stream under this step's backward pass (ShardedDistributedEmbedding.prefetch)
+    prefetch = (sharded_run and loader is None and not getattr(a, "graph", False) and not a.no_prefetch
+                and getattr(model.embedding, "exchange", None) == "static")
+
     def step():
         xl, inter = model(dense, pre if loader is None else next(loader))
+        if prefetch:
+            model.embedding.prefetch(pre)
         # loss = scale * sum(xl) + 0.1 * scale * sum(inter), taken through its (constant) output
         # gradients: the reduction to a scalar is not part of the hot path
         torch.autograd.backward([xl, inter], [g_xl, g_inter])

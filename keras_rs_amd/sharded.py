@@ -288,9 +288,15 @@ class _ShardedLookupFn(torch.autograd.Function):
         from keras_rs_amd.autograd import _sum_slab_and_feature_grads
 
         out_dtype, device = ctx.saved["out_meta"]
-        grad = _sum_slab_and_feature_grads(g_slab, gs, ctx.lead, ctx.saved["batch"], len(g.paths), g.dim, out_dtype,
-                                           device)
-        layer._backward_impl(ctx.gi, grad, ctx.saved)
+        lead, n = ctx.lead, len(g.paths)
+        if (lead > 0 and lead % g.dim == 0 and g_slab is not None and all(x is None for x in gs) and g_slab.is_contiguous()
+                and g_slab.dtype == ctx.saved["pdt"] and g_slab.shape[1] == lead + n * g.dim):
+            # the gradient of the whole slab [B, lead + n*dim] IS a table of B * (n + lead/dim) rows of `dim`: the
+            # segments' gradient rows are gathered straight out of it (no copy of its feature columns)
+            layer._backward_impl(ctx.gi, None, ctx.saved, slab_grad=g_slab, lead_slots=lead // g.dim)
+        else:
+            grad = _sum_slab_and_feature_grads(g_slab, gs, lead, ctx.saved["batch"], n, g.dim, out_dtype, device)
+            layer._backward_impl(ctx.gi, grad, ctx.saved)
         return (None, None, None, None, None, None, None, None, torch.zeros((), device=device))
 
 
@@ -307,7 +313,7 @@ class ShardedDistributedEmbedding(base.Layer):
     def __init__(self, feature_configs: dict[str, FeatureConfig], *, process_group=None, kernels=None,
                  slab_lead_cols: int = 0, replicate_below: int = 0, grad_average: bool = False,
                  partial_dtype=None, exchange: str = "exact", capacity="auto", capacity_headroom: float = 1.25,
-                 update_stats: bool = True, **kwargs: Any):
+                 update_stats: bool = True, capacity_settle_steps: int = 16, **kwargs: Any):
         super().__init__(**kwargs)
         # (base_distributed_embedding.py:461-464: whether the per-partition limits follow the running statistics; here
         #  the capacities of the static exchange.  False = they stay what they were sized to, overflows are only counted)
@@ -335,6 +341,9 @@ class ShardedDistributedEmbedding(base.Layer):
         self.exchange = exchange
         self._capacity_spec = capacity
         self.capacity_headroom = float(capacity_headroom)
+        self.capacity_settle_steps = int(capacity_settle_steps)   # 0 = never shrink
+        self.capacity_shrinks = 0
+        self._settle: dict = {}          # caps key -> [steps that fit in a row, their largest need_l, need_s]
         self._caps: dict = {}            # (group, batch, hots) -> [cap_lookups, cap_segments]
         self._stats_q: dict = {}           # group -> list of (step, event, pinned stats, caps key)
         self._stat_bufs: dict = {}         # group -> ring of four page-locked buffers the statistics land in
@@ -397,6 +406,10 @@ class ShardedDistributedEmbedding(base.Layer):
             self._replicated = DistributedEmbedding(rep_cfgs, dtype=self.dtype_policy, device=self._device,
                                                     name=f"{self.name}_replicated")
         self._anchor = None
+        self._xstream = None              # exchange stream of prefetch()
+        self._prefetched: dict = {}       # group -> what prefetch() ran ahead for the next call
+        self.prefetch_hits = 0
+        self.slab_grad_gathers = 0        # backward passes that gathered the segment gradients out of the slab gradient
         self._host_counts = None
         self._collectives_at_world1 = False   # bench --rccl-self: run the collectives through a one-rank communicator
         self._err_dev = self._err_host = self._err_event = None
@@ -729,8 +742,24 @@ class ShardedDistributedEmbedding(base.Layer):
         need_l, need_s = int(h0[0]), int(h0[1])
         cap = self._caps.get(key0)
         self.last_exchange.update(need=(need_l, need_s), received=(int(h0[2]), int(h0[3])))
-        if cap is None or (need_l <= cap[0] and need_s <= cap[1]):
+        if cap is None:
             return False
+        if need_l <= cap[0] and need_s <= cap[1]:
+            # Settled statistics shrink the blocks (every slot of a block crosses the link, padding included): once
+            # `capacity_settle_steps` steps in a row fit, the capacity drops to the largest need they showed + 6 % + 64
+            # (rounded to 64) -- every rank sees the same maxima at the same step, so all ranks resize together.
+            if self.update_stats and self.capacity_settle_steps > 0 and self._capacity_spec == "auto":
+                w = self._settle.setdefault(key0, [0, 0, 0])
+                w[0], w[1], w[2] = w[0] + 1, max(w[1], need_l), max(w[2], need_s)
+                if w[0] >= self.capacity_settle_steps:
+                    up64 = lambda v: int(-(-int(v) // 64) * 64)   # noqa: E731
+                    new = [min(cap[0], up64(w[1] * 1.0625 + 64)), min(cap[1], up64(w[2] * 1.0625 + 64))]
+                    self._settle[key0] = [0, 0, 0]
+                    if new != cap:
+                        cap[0], cap[1] = new
+                        self.capacity_shrinks += 1
+            return False
+        self._settle.pop(key0, None)
         self.overflow_steps += 1
         if not self.update_stats:
             return False
@@ -764,6 +793,64 @@ class ShardedDistributedEmbedding(base.Layer):
             grew = self._apply_stats(host, key) or grew
         return grew
 
+    def _route_exchange(self, g, cap_l, cap_s, ids, batch, hots, offsets, weights, emit_w):
+        """The part of a static-capacity lookup that depends on the ids alone: route -> all-to-all of the fixed-size
+        id blocks -> unpack (what prefetch() runs ahead of the step)."""
+        k, n = self.kernels, self.world
+        off_rank = (n - 1) / n if n > 1 else 1.0
+        # (probe.span: per-phase event pairs when bench.py is probing -- `phases` of its line; otherwise one global read)
+        with probe.span("route"):
+            r = k.route_static(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, cap_l, cap_s,
+                               self._err_flag(ids.device))
+        with probe.span("a2a_ids", off_rank * 4 * n * r["packed"].shape[1]):
+            recv_packed = self._a2a(r["packed"])                                # [n, W]: equal splits, no counts
+        with probe.span("unpack"):
+            rows, w, off, stats = k.unpack_static(recv_packed, cap_l, cap_s, emit_w)
+        return r, rows, w, off, stats
+
+    def prefetch(self, inputs, weights=None, training: bool = False):
+        """Runs the id side of a LATER call now, on the layer's exchange stream: krs_shard_route -> the all-to-all of the
+        id blocks -> krs_shard_unpack depend on the ids only (not on the tables), so the next step's can run under this
+        step's backward pass instead of at the head of the next forward.  Static exchange only (the exact form sizes its
+        all-to-all with a host wait).  Takes raw inputs or the result of preprocess(); returns the preprocessed inputs to
+        hand to the call.  Every rank must call it at the same point of its step (the collectives of one communicator
+        run in issue order).  The analogue in the reference: the host-side preprocessing + enqueue of batch i+1 while the
+        SparseCore step of batch i runs (jax/distributed_embedding.py:405-462, embedding_lookup.py:134-147)."""
+        if not (isinstance(inputs, dict) and "preprocessed_inputs_per_placement" in inputs):
+            inputs = self.preprocess(inputs, weights, training)
+        if self.exchange != "static" or base.stream_capturing():
+            return inputs
+        pre = inputs["preprocessed_inputs_per_placement"]["sparsecore"]
+        for gi, (g, fi) in enumerate(zip(self._sgroups, pre["groups"])):
+            ids, batch, hots = fi["ids"], fi["batch"], fi["hots"]
+            cap, _ = self._capacity(gi, g, batch, hots, ids.numel())
+            if cap is None:
+                continue
+            emit_w = fi["weights"] is not None or any(g.table_configs[t].combiner != "sum" for t in g.table_of_feature)
+            cap_l, cap_s = cap
+            if ids.is_cuda:
+                main = torch.cuda.current_stream(ids.device)
+                xs = self._xstream
+                if xs is None:
+                    xs = self._xstream = torch.cuda.Stream(device=ids.device)
+                self._err_flag(ids.device)      # (allocated on the main stream, before the fork)
+                xs.wait_stream(main)            # the ids (and the previous call's use of the descriptors) are ordered first
+                with torch.cuda.stream(xs):
+                    r, rows, w, off, stats = self._route_exchange(g, cap_l, cap_s, ids, batch, hots, fi["offsets"],
+                                                                  fi["weights"], emit_w)
+                    ev = torch.cuda.Event()
+                    ev.record(xs)
+                for t in (ids, fi["offsets"], fi["weights"]):
+                    if t is not None:
+                        t.record_stream(xs)
+            else:
+                r, rows, w, off, stats = self._route_exchange(g, cap_l, cap_s, ids, batch, hots, fi["offsets"],
+                                                              fi["weights"], emit_w)
+                ev = None
+            self._prefetched[gi] = dict(ids=ids, cap=(cap_l, cap_s), emit_w=emit_w, r=r, rows=rows, w=w, off=off,
+                                        stats=stats, event=ev)
+        return inputs
+
     def _forward_static(self, gi, g, cap, key, ids, batch, hots, offsets, weights, lead, emit_w):
         k, n = self.kernels, self.world
         cap_l, cap_s = cap
@@ -771,15 +858,23 @@ class ShardedDistributedEmbedding(base.Layer):
         n_feats = len(g.paths)
         shard = getattr(self, g.pname).data
         off_rank = (n - 1) / n if n > 1 else 1.0   # one-GPU dry run: what the stand-in copies move
-        # (probe.span: per-phase event pairs when bench.py is probing -- `phases` of its line; otherwise one global read)
-        with probe.span("route"):
-            r = k.route_static(self._route_desc(g, batch, hots), ids, offsets, weights, batch, n, emit_w, cap_l, cap_s,
-                               self._err_flag(dev))
+        pf = self._prefetched.pop(gi, None)
+        if pf is not None and (pf["ids"].data_ptr() != ids.data_ptr() or pf["ids"].numel() != ids.numel() or
+                               pf["ids"]._version != ids._version or pf["cap"] != (cap_l, cap_s) or pf["emit_w"] != emit_w):
+            pf = None      # another batch, or the capacity moved since: the prefetched blocks do not fit this call
+        if pf is not None:
+            # route / id all-to-all / unpack of this call ran ahead on the exchange stream (prefetch()): join it here
+            r, rows, w, off, stats = pf["r"], pf["rows"], pf["w"], pf["off"], pf["stats"]
+            if pf["event"] is not None:
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(pf["event"])
+                for t in (*r.values(), rows, w, off, stats):
+                    if t is not None:
+                        t.record_stream(cur)
+            self.prefetch_hits += 1
+        else:
+            r, rows, w, off, stats = self._route_exchange(g, cap_l, cap_s, ids, batch, hots, offsets, weights, emit_w)
         words = r["packed"].shape[1]
-        with probe.span("a2a_ids", off_rank * 4 * n * words):
-            recv_packed = self._a2a(r["packed"])                                # [n, W]: equal splits, no counts
-        with probe.span("unpack"):
-            rows, w, off, stats = k.unpack_static(recv_packed, cap_l, cap_s, emit_w)
         pdt = self._partial_dtype or self.compute_dtype
         if isinstance(pdt, str):
             pdt = {"float32": torch.float32, "bfloat16": torch.bfloat16}[pdt]
@@ -851,15 +946,23 @@ class ShardedDistributedEmbedding(base.Layer):
                      rows=rows, off=off, w=w, pdt=pdt, out_meta=(slab.dtype, slab.device))
         return slab, saved
 
-    def _backward_impl(self, gi, grad, s):
+    def _backward_impl(self, gi, grad, s, slab_grad=None, lead_slots=0):
         k, g = self.kernels, self._sgroups[gi]
         n_feats, batch = len(g.paths), s["batch"]
         # d(partial of a segment) = the output gradient of its bag: rows of grad viewed as [batch * n_feats, dim]
         with probe.span("gather_grads"):
-            grad = grad.contiguous()
-            if grad.dtype != s["pdt"]:
-                grad = grad.to(s["pdt"])
-            dpart = k.gather_rows(grad.view(batch * n_feats, g.dim), s["seg_grow"])
+            if slab_grad is not None:
+                self.slab_grad_gathers += 1
+                # row of (sample b, feature f) in the slab gradient seen as [B * (n + ls), dim]: b * (n + ls) + ls + f
+                # = seg_grow + (seg_grow // n + 1) * ls
+                grow = s["seg_grow"]
+                grow = grow + (torch.div(grow, n_feats, rounding_mode="floor") + 1) * lead_slots
+                dpart = k.gather_rows(slab_grad.view(batch * (n_feats + lead_slots), g.dim), grow)
+            else:
+                grad = grad.contiguous()
+                if grad.dtype != s["pdt"]:
+                    grad = grad.to(s["pdt"])
+                dpart = k.gather_rows(grad.view(batch * n_feats, g.dim), s["seg_grow"])
         off_rank = (self.world - 1) / self.world if self.world > 1 else 1.0
         with probe.span("a2a_grads", off_rank * dpart.numel() * dpart.element_size()):
             dseg = self._a2a(dpart, s["send_segs"], s["recv_segs"])               # to the owners

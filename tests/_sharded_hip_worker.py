@@ -114,11 +114,28 @@ def main():
               for i in range(4)} for r in range(world)]
 
     exchange = sys.argv[2] if len(sys.argv) > 2 else "exact"
-    layer = ShardedDistributedEmbedding(configs(), slab_lead_cols=8, exchange=exchange)
+    prefetch = exchange == "static_prefetch"          # round 4: id exchange on the layer's stream ahead of the call,
+    if prefetch:                                      # segment gradients gathered out of the slab gradient (lead = D)
+        exchange = "static"
+    layer = ShardedDistributedEmbedding(configs(), slab_lead_cols=D if prefetch else 8, exchange=exchange)
     layer.build(None)
     layer.set_embedding_tables(full)
-    out = layer(all_ids[rank], all_w[rank])
-    sum((o * torch.from_numpy(all_g[rank][k]).cuda()).sum() for k, o in out.items()).backward()
+    if prefetch:
+        pre = layer.preprocess(all_ids[rank], all_w[rank])
+        torch.cuda.synchronize()
+        layer.prefetch(pre)
+        # (work on the main stream while the exchange stream runs ahead)
+        busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")
+        out = layer(pre)
+        assert layer.prefetch_hits == 1 and busy is not None
+        head = torch.zeros((B, D), device="cuda", requires_grad=True)
+        catd = kl.concat_features([head] + [out[f"f{i}"] for i in range(4)])
+        gm = torch.cat([torch.zeros(B, D)] + [torch.from_numpy(all_g[rank][f"f{i}"]) for i in range(4)], dim=1).cuda()
+        (catd * gm).sum().backward()
+        assert layer.slab_grad_gathers == 1
+    else:
+        out = layer(all_ids[rank], all_w[rank])
+        sum((o * torch.from_numpy(all_g[rank][k]).cuda()).sum() for k, o in out.items()).backward()
     torch.cuda.synchronize()
     got_tables = {k: v.cpu().numpy() for k, v in layer.get_embedding_tables().items()}
 

@@ -90,6 +90,9 @@ def main():
     opt = {"sgd": kl.SGD(0.1), "adagrad": kl.Adagrad(0.1, 0.1), "adam": kl.Adam(0.1, 0.9, 0.999, 1e-7),
            "ftrl": kl.Ftrl(0.1, -0.5, 0.1, 0.01, 0.02, 0.3)}[kind]
     V, D, B = [37, 10, 64], 8, 6
+    mode = sys.argv[3] if len(sys.argv) > 3 else "exact"
+    if mode == "static_shrink":
+        B = 600           # enough lookups for the settled capacity to sit below the generous first guess
     combs = ["sum", "mean", "sqrtn", "sum"]
     tcs = [kl.TableConfig(f"t{i}", V[i], D, optimizer=opt, combiner="sum", placement="sparsecore") for i in range(3)]
     feats = {}
@@ -109,7 +112,13 @@ def main():
         exchange, kw = "static", dict(capacity=(4, 4))
     elif exchange == "static_cfg":
         exchange, kw = "static", dict(capacity="table_config")
-    layer = ShardedDistributedEmbedding(feats, kernels=OracleShardKernels(), device="cpu", slab_lead_cols=3 * rank,
+    elif exchange == "static_prefetch":
+        exchange = "static"
+    elif exchange == "static_shrink":
+        exchange, kw = "static", dict(capacity_headroom=4.0, capacity_settle_steps=3)
+    # (static_prefetch: a lead of whole feature slots on ranks > 0, so that the slab-gradient path of the backward runs)
+    lead = D * rank if mode == "static_prefetch" else 3 * rank
+    layer = ShardedDistributedEmbedding(feats, kernels=OracleShardKernels(), device="cpu", slab_lead_cols=lead,
                                         exchange=exchange, **kw)
     rng = np.random.default_rng(7)
     full = {f"t{i}": rng.uniform(-1, 1, (V[i], D)).astype(np.float32) for i in range(3)}
@@ -140,11 +149,38 @@ def main():
                     layer(ids, w if use_w else None)
                     assert layer.kernels.flags & ko.FLAG_CAPACITY_OVERFLOW
             assert layer.overflow_steps >= 1 and min(next(iter(layer._caps.values()))) >= 8
-        out = layer(ids, w if use_w else None)
+        if mode == "static_shrink":
+            cap0 = list(next(iter(layer._caps.values()))) if layer._caps else None
+            with torch.no_grad():
+                for _ in range(7):      # statistics are read two steps late; three fitting steps in a row shrink
+                    layer(ids, w if use_w else None)
+            cap1 = list(next(iter(layer._caps.values())))
+            assert layer.capacity_shrinks >= 1 and layer.overflow_steps == 0, (layer.capacity_shrinks, cap1)
+            need = layer.last_exchange["need"]
+            assert need[0] <= cap1[0] < 0.8 * 4.0 * (B * sum(hots) / world) and need[1] <= cap1[1], (cap0, cap1, need)
+        if mode == "static_prefetch":
+            # the id side of the call (route -> id all-to-all -> unpack) issued ahead of it: same result, one hit
+            pre = layer.preprocess(ids, w if use_w else None)
+            layer.prefetch(pre)
+            out = layer(pre)
+            assert layer.prefetch_hits == 1
+        else:
+            out = layer(ids, w if use_w else None)
         if exchange == "static":
             assert layer.last_exchange["mode"] == "static" and not layer.kernels.flags & ko.FLAG_CAPACITY_OVERFLOW
     g = {k: torch.from_numpy(rng_r.uniform(0, 1, (B, D)).astype(np.float32)) for k in out}
-    sum((o * g[k]).sum() for k, o in out.items()).backward()
+    if mode == "static_prefetch":
+        # the gradient arrives as ONE matrix for the whole slab (layers.concat_features hands the slab itself on):
+        # ranks with a lead of whole feature slots gather the segment gradients straight out of it
+        import keras_rs_amd.layers as kl2
+
+        head = torch.zeros((B, lead), requires_grad=True)
+        cat = kl2.concat_features(([head] if lead else []) + [out[f"f{i}"] for i in range(4)])
+        gm = torch.cat(([torch.zeros(B, lead)] if lead else []) + [g[f"f{i}"] for i in range(4)], dim=1)
+        (cat * gm).sum().backward()
+        assert layer.slab_grad_gathers == (1 if lead else 0)
+    else:
+        sum((o * g[k]).sum() for k, o in out.items()).backward()
 
     # unsharded oracle: forward per rank, table update from the contributions of ALL ranks
     gathered = [None] * world

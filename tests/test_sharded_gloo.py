@@ -25,6 +25,9 @@ def _free_port():
     # from a capacity the first steps overflow (ids dropped + flagged, limits learnt from the running statistics)
     ("adagrad", "w", 2, "static"), ("sgd", "now", 3, "static"), ("adam", "w", 2, "static_cfg"),
     ("adagrad", "w", 2, "static_tiny"), ("sgd", "now", 3, "static_tiny"), ("adagrad", "wragged", 2, "static"),
+    # round 4: the id side of the lookup issued ahead of the call (prefetch()), the segment gradients gathered straight
+    # out of the slab gradient (no copy), capacities that shrink to the settled statistics
+    ("adagrad", "w", 2, "static_prefetch"), ("sgd", "now", 3, "static_prefetch"), ("adagrad", "now", 2, "static_shrink"),
     # the world the scaling run ends on (8 owners, every bag split over up to 8 partial sums)
     ("adagrad", "w", 8, "static"), ("adagrad", "nowragged", 8, "exact")])
 def test_sharded_embedding_matches_unsharded_oracle(kind, weighted, world, exchange):

@@ -20,6 +20,7 @@ def _free_port():
 
 @pytest.mark.parametrize("kind,exchange,world", [("sgd", "exact", 2), ("adagrad", "exact", 2), ("adam", "exact", 2),
                                                  ("sgd", "static", 2), ("adagrad", "static", 2),
+                                                 ("adagrad", "static_prefetch", 2), ("sgd", "static_prefetch", 8),
                                                  # the world of the scaling run's last point: eight owners, the HIP
                                                  # routing / unpack / combine kernels with n_shards = 8
                                                  ("sgd", "static", 8), ("adam", "exact", 8)])
