@@ -290,6 +290,27 @@ int krs_gemm(const void* a, int64_t lda, int a_is_km,
              void* workspace, size_t workspace_bytes, void* stream);
 size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
 
+/* Data-gradient product of a cross layer FUSED with the elementwise backward of the cross layer below it in a stack
+ * on one x0 (`xl = layer(x0, xl)` repeated, examples/ml_perf/model.py:332-336; gradients of feature_cross.py:182-194):
+ *      G   = A[M,K] @ Bt[N,K]^T + beta * R            dL/dx of the upper layer = dL/dy of the lower one (stored)
+ *      dz  = G * x0 * act'(u)                          d(pre-activation) of the lower layer   (act' from its saved output u)
+ *      dx0 = [dx0 +] G * u [+ G]                       its term of dL/dx0 (dx0_accumulate != 0: added to what dx0 holds;
+ *                                                      fold_direct != 0: the lower layer's x IS x0, so the direct term
+ *                                                      joins, the `dxd == dx0` rule of krs_cross_epilogue_bwd)
+ *      dbias[n] = sum_m dz[m,n]                        fp32, fixed summation order (NULL: not wanted)
+ * i.e. exactly krs_gemm(A, Bt, epilogue{r = R, beta}) followed by krs_cross_epilogue_bwd(g = G, u, x0, diag_scale = 0),
+ * with G, dz and dx0 BIT-IDENTICAL to those two calls (dz and dx0 are computed from G as it is stored, after its one
+ * rounding) -- without the second pass reading G, x0 and u back and with the streams written by the product's epilogue.
+ * Row stride `ld` for x0, u, dz and dx0; workspace: krs_gemm_cross_bwd_workspace_bytes(m, n) when dbias is wanted.
+ * bf16 tiles the 256x256 ring kernel covers run fused; every other shape / dtype runs the two calls (needs ldg == ld). */
+size_t krs_gemm_cross_bwd_workspace_bytes(int64_t m, int64_t n);
+int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, int64_t ldb,
+                       const void* r, int64_t ldr, float beta,
+                       void* g_out, int64_t ldg,
+                       const void* x0, const void* u, void* dz, void* dx0, int64_t ld, int dx0_accumulate,
+                       int fold_direct, float* dbias, int64_t m, int64_t n, int64_t k, int act, int dtype,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* Tuning / diagnostic switches of krs_gemm (process-wide; results never depend on them).
  *   KRS_GEMM_OPT_PIPELINE: main loop of the 256x256 bf16 tiles -- 0 = two-stage loop that drains the
  *   DMA queue once per K tile, 4 / 5 = ping-pong ring with that many 32-deep stages (default 4, or

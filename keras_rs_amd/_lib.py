@@ -75,6 +75,8 @@ SYMBOLS = [
     "krs_embed_set_option",
     "krs_cross_epilogue_fwd",
     "krs_cross_epilogue_bwd",
+    "krs_gemm_cross_bwd",
+    "krs_gemm_cross_bwd_workspace_bytes",
     "krs_colsum",
     "krs_colsum_workspace_bytes",
     "krs_cast_transpose",
@@ -118,7 +120,8 @@ def lib() -> C.CDLL:
         _lib.krs_last_error.restype = C.c_char_p
         for name in ("krs_embed_bag_bwd_workspace_bytes", "krs_gemm_workspace_bytes",
                      "krs_mod_bucketize_workspace_bytes", "krs_shard_route_workspace_bytes",
-                     "krs_shard_unpack_workspace_bytes", "krs_colsum_workspace_bytes"):
+                     "krs_shard_unpack_workspace_bytes", "krs_colsum_workspace_bytes",
+                     "krs_gemm_cross_bwd_workspace_bytes"):
             getattr(_lib, name).restype = C.c_size_t
         _lib.krs_shard_static_block_words.restype = C.c_int64
     return _lib

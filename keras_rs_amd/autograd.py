@@ -143,10 +143,15 @@ class Dx0Relay:
     of the stack returns the total.  `task` is the autograd graph-task id of the pass that filled `buf`:
     a buffer left over from another backward pass is ignored."""
 
-    __slots__ = ("x0", "buf", "task")
+    __slots__ = ("x0", "buf", "task", "lower", "fused")
 
     def __init__(self, x0: torch.Tensor):
         self.x0, self.buf, self.task = x0, None, -1
+        # lower: what the consumer of y needs to run THIS layer's elementwise backward inside its own data-gradient
+        #   product (krs_gemm_cross_bwd): (u, act, diag_scale, has_bias, x_is_x0), left by this layer's forward;
+        # fused: (G, version of G, dz, dbias) left by that consumer's backward when it did so -- `buf` then already
+        #   holds this layer's term of dL/dx0 as well.
+        self.lower, self.fused = None, None
 
     def matches(self, x0: torch.Tensor) -> bool:
         a = self.x0
@@ -177,6 +182,30 @@ class SlabGradRelay:
         # set when the slab got a second consumer (a second concat of the same features): autograd then sums the two
         # gradients of the slab in a buffer of its own, and an in-place add into the first one could be lost
         self.disabled = False
+
+
+# Round 4: dx = dh U^T + g of a layer IS dL/dy of the layer below it in the stack, whose elementwise backward starts
+# by re-reading it.  krs_gemm_cross_bwd does that pass in the product's epilogue (one 453 MB stream less per layer at C3,
+# and the other streams at the epilogue's rate): environment KRS_FUSE_CROSS_BWD=0 switches it off (A/B).
+FUSE_CROSS_BWD = bool(int(__import__("os").environ.get("KRS_FUSE_CROSS_BWD", "1")))
+
+
+def _dx_product(ctx, dh, dc, direct, dx0, x0c, task):
+    """dx = dh U^T + direct.  When x was produced by a cross layer on the same x0 (ctx.relay_up) whose elementwise
+    backward can ride in this product's epilogue, it does: that layer's dz / dbias and its term of dL/dx0 (added into
+    this layer's dx0 buffer) are left on its relay.  Returns (dx, dx0)."""
+    up = ctx.relay_up
+    low = up.lower if up is not None else None
+    if (low is None or task == -1 or not FUSE_CROSS_BWD or low[2] != 0.0 or dh.dtype != torch.bfloat16
+            or ctx.meta[6] != dh.dtype      # (dx is handed to autograd as it is: a cast would be a different tensor)
+            or (up.buf is not None and up.task == task) or not dx0.is_contiguous() or dx0.dtype != dh.dtype):
+        dx, _ = D.gemm(dh, dc, b_is_nk=True, r=direct, beta=1.0)
+        return dx, dx0
+    u_low, act_low, _, bias_low, same_low = low
+    dx, dz_low, dx0, db_low = D.gemm_cross_bwd(dh, dc, direct, x0c, u_low, act=act_low, dx0_into=dx0,
+                                               want_dbias=bias_low, fold_direct=same_low)
+    up.fused = (dx, dx._version, dz_low, db_low, task)
+    return dx, dx0
 
 
 class CrossLayerFn(torch.autograd.Function):
@@ -211,6 +240,8 @@ class CrossLayerFn(torch.autograd.Function):
         ctx.meta = (diag_scale, act, same, down is not None, bias is not None,
                     x0.dtype, x.dtype, None if down is None else down.dtype, kernel.dtype)
         ctx.relay_in = relay_in
+        if relay_in is not None and FUSE_CROSS_BWD and down is not None:
+            relay_in.lower = (u, act, float(diag_scale or 0.0), bias is not None, same)
         ctx.w_refs = tuple(weakref.ref(w) for w in (down, kernel) if w is not None)
         # pending uses of each weight (a weight shared by two layer calls gets two gradient contributions)
         ctx.counted = any(ctx.needs_input_grad[i] for i in (2, 3))
@@ -232,6 +263,9 @@ class CrossLayerFn(torch.autograd.Function):
         # dL/dx0 of the layers above, left by the consumer of y during this backward pass
         incoming, extra = None, None
         rin = ctx.relay_in
+        fused = None
+        if rin is not None:
+            fused, rin.fused = rin.fused, None
         if rin is not None and rin.buf is not None:
             if rin.task == task and task != -1:
                 if rin.buf.dtype == x0c.dtype and rin.buf.shape == x0c.shape and rin.buf.is_contiguous():
@@ -239,10 +273,29 @@ class CrossLayerFn(torch.autograd.Function):
                 else:
                     extra = rin.buf
             rin.buf = None
-        # x is x0 (the first layer of a stack): both halves of dL/dx0 go through one buffer, which
-        # the data-gradient GEMM then takes as its residual -- no separate add.
-        dz, dx0, dxd, dbias = D.cross_epilogue_bwd(g, u, x0c, xc, diag, act=act, want_dxd=need_dxd,
-                                                   want_dbias=has_bias, fold_direct=same, dx0_into=incoming)
+        if fused is not None and (incoming is None or fused[4] != task):
+            fused = None
+        if fused is not None:
+            # The consumer of y ran this layer's elementwise backward inside its data-gradient product
+            # (krs_gemm_cross_bwd): `incoming` already holds this layer's term, dz and dbias are done.  That is only
+            # right when its G is ALL of dL/dy -- the very tensor autograd hands over, untouched.  If y had another
+            # consumer the engine summed their gradients (a new tensor, or in place: the version moves): the difference
+            # goes through the elementwise kernel (linear in g), dz and dbias are redone.
+            G, g_version, dz, dbias = fused[:4]
+            if g.data_ptr() == G.data_ptr() and g.shape == G.shape and g._version == g_version:
+                dx0, dxd = incoming, (incoming if same else None)
+            else:
+                delta = (g.float() - G.float()).to(g.dtype)
+                _, dx0, _, _ = D.cross_epilogue_bwd(delta, u, x0c, xc, diag, act=act, want_du=False, want_dxd=False,
+                                                    want_dbias=False, fold_direct=same, dx0_into=incoming)
+                dz, _, _, dbias = D.cross_epilogue_bwd(g, u, x0c, xc, diag, act=act, want_dxd=False,
+                                                       want_dbias=has_bias, want_dx0=False)
+                dxd = dx0 if same else None
+        else:
+            # x is x0 (the first layer of a stack): both halves of dL/dx0 go through one buffer, which
+            # the data-gradient GEMM then takes as its residual -- no separate add.
+            dz, dx0, dxd, dbias = D.cross_epilogue_bwd(g, u, x0c, xc, diag, act=act, want_dxd=need_dxd,
+                                                       want_dbias=has_bias, fold_direct=same, dx0_into=incoming)
         if extra is not None:
             dx0 = dx0 + extra.to(dx0.dtype)
         direct = dx0 if same else (dxd if need_dxd else g)  # dL/dx through "+ x" and "diag * x"
@@ -273,7 +326,7 @@ class CrossLayerFn(torch.autograd.Function):
             # main stream (the dz / dx0 pass of the layer below, or the DotInteraction gradient and the table update
             # behind the bottom layer).  The main stream rejoins at the end of the backward pass (wgrad_stream_sync).
             dh, _ = D.gemm(dz, kc, b_is_nk=True)                               # dh = dz K^T     [B, p]
-            dx, _ = D.gemm(dh, dc, b_is_nk=True, r=direct, beta=1.0)           # dx = dh U^T + direct
+            dx, dx0 = _dx_product(ctx, dh, dc, direct, dx0, x0c, task)         # dx = dh U^T + direct
             main = torch.cuda.current_stream()
             side = _wgrad_stream(dz.device)
             ev = torch.cuda.Event()
@@ -296,7 +349,7 @@ class CrossLayerFn(torch.autograd.Function):
             dk, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)      # dK = h^T dz     [p, d]
             dh, _ = D.gemm(dz, kc, b_is_nk=True)                               # dh = dz K^T     [B, p]
             dd, _ = D.gemm(xc, dh, a_is_km=True, out_dtype=torch.float32)      # dU = x^T dh     [d, p]
-            dx, _ = D.gemm(dh, dc, b_is_nk=True, r=direct, beta=1.0)           # dx = dh U^T + direct
+            dx, dx0 = _dx_product(ctx, dh, dc, direct, dx0, x0c, task)         # dx = dh U^T + direct
         else:
             dk, _ = D.gemm(xc, dz, a_is_km=True, out_dtype=torch.float32)      # dK = x^T dz     [d, d]
             dd = None

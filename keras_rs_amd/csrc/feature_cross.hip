@@ -64,6 +64,8 @@ struct GemmParams {
   // split-K
   int splits; int64_t k_per_split; float* slabs;
   int ep_vec;  // every epilogue operand allows 8-wide vector access
+  // fused cross-backward epilogue (EPI 3 / 4 of gemm_pp256_kernel, krs_gemm_cross_bwd): operands of the layer below
+  const void* f_x0; const void* f_u; void* f_dz; void* f_dx0; float* f_partial; int64_t f_ld; int f_act; int f_fold;
 };
 
 __device__ __forceinline__ float apply_act(int act, float v) {
@@ -72,6 +74,15 @@ __device__ __forceinline__ float apply_act(int act, float v) {
     case KRS_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
     case KRS_ACT_TANH: return tanhf(v);
     default: return v;
+  }
+}
+
+__device__ __forceinline__ float act_grad_from_output(int act, float u) {
+  switch (act) {
+    case KRS_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
+    case KRS_ACT_SIGMOID: return u * (1.0f - u);
+    case KRS_ACT_TANH: return 1.0f - u * u;
+    default: return 1.0f;
   }
 }
 
@@ -962,6 +973,102 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
   gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
 }
 
+// ---- fused epilogue of krs_gemm_cross_bwd (round 4) ----------------------------------------------------------------
+// The data-gradient product of a cross layer, G = A B^T + beta R, is dL/dy of the layer BELOW it in a stack on one x0,
+// whose elementwise backward (cross_bwd_vec_kernel) starts by re-reading G.  This epilogue does that pass on the tile
+// while it is in registers: G is rounded and stored (the layer below needs it again as the residual of ITS data-gradient
+// product), then from the ROUNDED value -- what the separate pass would have read --
+//   dz = G x0 act'(u),   dx0 = [dx0 +] G u,   column sums of dz -> partial[group][n]  (bias gradient, fixed order)
+// with the arithmetic of cross_bwd_vec_kernel for diag_scale = 0: G, dz and dx0 are bit-identical to the two calls.
+// A wave's 128 x 64 block in four chunks of 32 rows; a chunk's R / x0 / u / dx0 vectors are requested before its
+// accumulators are staged.  ACC: dx0 already holds the terms of the layers above (a template parameter: a load behind
+// a run-time branch makes hipcc drain the load queue).
+template <bool ACC>
+__device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
+                                                               int64_t wm0, int64_t wn0, int64_t group) {
+  const int lane = threadIdx.x & 63;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  constexpr int SST = 68;
+  const int ec = (lane & 7) * 8;
+  const int64_t gn = wn0 + ec;
+  const int64_t gnc = min(gn, p.n - 8);
+  float db[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) db[q] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t row0 = wm0 + c * 32;
+    uint4 er[4], ex0[4], eu[4], ed[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t gmc = min(row0 + it * 8 + (lane >> 3), p.m - 1);
+      er[it] = load8_bf16_nt(p.ep.r, gmc * p.ep.ldr + gnc);
+      ex0[it] = load8_bf16_nt(p.f_x0, gmc * p.f_ld + gnc);
+      eu[it] = load8_bf16_nt(p.f_u, gmc * p.f_ld + gnc);
+      if constexpr (ACC) ed[it] = load8_bf16_nt(p.f_dx0, gmc * p.f_ld + gnc);
+      else ed[it] = er[it];
+    }
+    f32x16(&acc2)[2] = acc[c >> 1][c & 1];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc2[j][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int er_ = it * 8 + (lane >> 3);
+      const int64_t gm = row0 + er_;
+      if (gm >= p.m || gn >= p.n) continue;
+      float v[8], rv[8], x0v[8], uv[8], tv[8], g[8], dz[8];
+      const float4 v0 = *reinterpret_cast<const float4*>(stage + er_ * SST + ec);
+      const float4 v1 = *reinterpret_cast<const float4*>(stage + er_ * SST + ec + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      unpack_bf16x8(er[it], rv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
+      // G as it is stored (one rounding) is what everything below sees
+      const uint4 gq = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                  pack_bf16x2(v[6], v[7]));
+      {
+        const u32x4 gs = {gq.x, gq.y, gq.z, gq.w};
+        __builtin_nontemporal_store(gs, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.c) + gm * p.ldc + gn));
+      }
+      unpack_bf16x8(gq, g);
+      unpack_bf16x8(ex0[it], x0v);
+      unpack_bf16x8(eu[it], uv);
+      unpack_bf16x8(ed[it], tv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float gx0 = g[q] * x0v[q];
+        dz[q] = gx0 * act_grad_from_output(p.f_act, uv[q]);
+        db[q] += dz[q];
+        tv[q] = __builtin_fmaf(g[q], uv[q], ACC ? tv[q] : 0.0f);
+        if (p.f_fold) tv[q] += g[q];     // the layer below is the bottom of its stack (x is x0): the direct term too
+      }
+      store8(p.f_dz, KRS_BF16, gm * p.f_ld + gn, dz);                   // (read next by the dh and dK products)
+      store8_bf16_nt(p.f_dx0, gm * p.f_ld + gn, tv);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (p.f_partial) {
+    // column sums over the wave's 128 rows: the eight lanes with one (lane & 7) hold the same 8 columns
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float t = db[q];
+      t += __shfl_xor(t, 8);
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      db[q] = t;
+    }
+    if ((lane >> 3) == 0 && gn < p.n) {
+      float* dst = p.f_partial + group * p.n + gn;
+      *reinterpret_cast<float4*>(dst) = make_float4(db[0], db[1], db[2], db[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(db[4], db[5], db[6], db[7]);
+    }
+  }
+}
+
 // ---- ping-pong ring pipeline: the 256x256 bf16 tile of both operand layouts -------------------------
 // The two kernels above run "issue tile t+1 -> 32 MFMA on tile t -> vmcnt(0) -> barrier": the DMA queue is
 // filled in one burst and drained to empty once per tile, all eight waves read LDS at the same time and
@@ -1489,6 +1596,10 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
   }
   lds_dma_retired<NPF>();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  if constexpr (EPI == 3 || EPI == 4) {
+    gemm_epilogue_wave128_crossbwd<EPI == 4>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
+    return;
+  }
   if constexpr (NPFC > 0 && SCHED == 0 && KRS_PP_PROBE != 4)
     gemm_epilogue_wave128_pre<EPI, NPFC>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split, opf);
   else
@@ -1980,14 +2091,6 @@ struct CrossParams {
   int dtype;
 };
 
-__device__ __forceinline__ float act_grad_from_output(int act, float u) {
-  switch (act) {
-    case KRS_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
-    case KRS_ACT_SIGMOID: return u * (1.0f - u);
-    case KRS_ACT_TANH: return 1.0f - u * u;
-    default: return 1.0f;
-  }
-}
 
 // one thread per 8 columns; rows strided by gridDim.y*ROWS_PER_BLOCK
 template <typename T, int V>
@@ -2131,7 +2234,7 @@ __global__ __launch_bounds__(256) void cross_bwd_vec_kernel(const CrossParams p,
       }
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        t[k] = (ACC ? t[k] : 0.0f) + g[k] * (u[k] + p.diag * x[k]);
+        t[k] = __builtin_fmaf(g[k], __builtin_fmaf(p.diag, x[k], u[k]), ACC ? t[k] : 0.0f);
         if (fold) t[k] += g[k] + p.diag * gx0[k];
       }
       RowVec<T, V>::store(p.dx0, o, t);
@@ -2296,7 +2399,7 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
   if (epilogue && epilogue->x0) KRS_REQUIRE(epilogue->x, "krs_gemm: cross epilogue needs x with x0");
   if (m == 0 || n == 0) return KRS_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  GemmParams p;
+  GemmParams p{};
   p.a = reinterpret_cast<const char*>(a); p.lda = lda; p.a_km = a_is_km != 0;
   p.b = reinterpret_cast<const char*>(b); p.ldb = ldb; p.b_nk = b_is_nk != 0;
   p.c = reinterpret_cast<char*>(c); p.ldc = ldc; p.m = m; p.n = n; p.k = k; p.out_dtype = out_dtype;
@@ -2455,6 +2558,70 @@ extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* 
   }
   KRS_CHECK_LAUNCH("cross_bwd_kernel");
   if (two_stage) return finish_colsum(p.partial, vec ? cc.groups4 : cc.chunks, n, dbias, st);
+  return KRS_OK;
+}
+
+// ---- krs_gemm_cross_bwd: data-gradient product + the elementwise backward of the layer below, one launch ---------------
+extern "C" size_t krs_gemm_cross_bwd_workspace_bytes(int64_t m, int64_t n) {
+  if (m <= 0 || n <= 0) return 0;
+  return std::max(krs_colsum_workspace_bytes(m, n), (size_t)(2 * ceil_div(m, 256)) * (size_t)n * sizeof(float));
+}
+
+extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, int64_t ldb, const void* r, int64_t ldr,
+                                  float beta, void* g_out, int64_t ldg, const void* x0, const void* u, void* dz,
+                                  void* dx0, int64_t ld, int dx0_accumulate, int fold_direct, float* dbias,
+                                  int64_t m, int64_t n, int64_t k, int act, int dtype, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  KRS_REQUIRE(a && bt && r && g_out && x0 && u && dz && dx0, "krs_gemm_cross_bwd: null operand");
+  KRS_REQUIRE(dtype == KRS_BF16 || dtype == KRS_F32, "krs_gemm_cross_bwd: bad dtype");
+  KRS_REQUIRE(m >= 0 && n >= 0 && k > 0 && ld >= n && ldg >= n && ldr >= n, "krs_gemm_cross_bwd: bad sizes");
+  if (dbias) KRS_REQUIRE(workspace && workspace_bytes >= krs_gemm_cross_bwd_workspace_bytes(m, n),
+                         "krs_gemm_cross_bwd: workspace too small (krs_gemm_cross_bwd_workspace_bytes)");
+  if (m == 0 || n == 0) return KRS_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool fused = dtype == KRS_BF16 && gemm_pipe() != 0 && m >= 256 && n >= 256 && k >= 256 && k % 64 == 0 &&
+                     ceil_div(m, 256) * ceil_div(n, 256) >= 192 && n % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                     ldr % 8 == 0 && ldg % 8 == 0 && ld % 8 == 0 && al16(a) && al16(bt) && al16(r) && al16(g_out) &&
+                     al16(x0) && al16(u) && al16(dz) && al16(dx0);
+  if (!fused) {
+    // any other shape / dtype: the two calls this entry stands for
+    krs_gemm_epilogue ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.r = r; ep.ldr = ldr; ep.beta = beta;
+    if (int rc = krs_gemm(a, lda, 0, bt, ldb, 1, g_out, ldg, m, n, k, dtype, dtype, &ep, nullptr, 0, stream)) return rc;
+    KRS_REQUIRE(ldg == ld, "krs_gemm_cross_bwd: the two-call form needs one row stride for G, x0, u, dz and dx0");
+    return krs_cross_epilogue_bwd(g_out, u, x0, x0, dz, dx0, dx0_accumulate, fold_direct ? dx0 : nullptr, dbias, m, n,
+                                  ld, 0.0f, act, dtype, workspace, workspace_bytes, stream);
+  }
+  GemmParams p{};
+  p.a = reinterpret_cast<const char*>(a); p.lda = lda; p.a_km = 0;
+  p.b = reinterpret_cast<const char*>(bt); p.ldb = ldb; p.b_nk = 1;
+  p.c = reinterpret_cast<char*>(g_out); p.ldc = ldg; p.m = m; p.n = n; p.k = k; p.out_dtype = KRS_BF16;
+  p.has_ep = 1;
+  memset(&p.ep, 0, sizeof(p.ep));
+  p.ep.r = r; p.ep.ldr = ldr; p.ep.beta = beta;
+  p.splits = 1; p.k_per_split = k; p.slabs = nullptr; p.ep_vec = 1;
+  p.f_x0 = x0; p.f_u = u; p.f_dz = dz; p.f_dx0 = dx0; p.f_ld = ld; p.f_act = act; p.f_fold = fold_direct != 0;
+  p.f_partial = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
+  const int nt_ = (int)ceil_div(n, 256);
+  const dim3 grid256((unsigned)(ceil_div(ceil_div(m, 256), 8) * 8 * nt_));
+#define KRS_CB_LAUNCH(EP)                                                                              \
+  {                                                                                                    \
+    auto kern = gemm_pp256_kernel<false, 4, EP, 0>;                                                    \
+    static bool attr_set = false;                                                                      \
+    if (!attr_set) {                                                                                   \
+      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pp::STAGE));         \
+      attr_set = true;                                                                                 \
+    }                                                                                                  \
+    hipLaunchKernelGGL(kern, grid256, dim3(512), 4 * pp::STAGE, st, p, 0, nt_);                        \
+  }
+  if (dx0_accumulate) KRS_CB_LAUNCH(4)
+  else KRS_CB_LAUNCH(3)
+#undef KRS_CB_LAUNCH
+  KRS_CHECK_LAUNCH("gemm_pp256_kernel (fused cross backward)");
+  if (dbias) return finish_colsum(p.f_partial, 2 * ceil_div(m, 256), n, dbias, st);
   return KRS_OK;
 }
 

@@ -108,16 +108,18 @@ def _colsum_ws(m: int, n: int, device):
 
 def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
                        dx0_into: torch.Tensor | None = None,
-                       want_du=True, want_dxd=True, want_dbias=True, fold_direct=False):
+                       want_du=True, want_dxd=True, want_dbias=True, fold_direct=False, want_dx0=True):
     """Returns (du, dx0, dxd, dbias); dx0 accumulates into `dx0_into` when given.
     fold_direct (the case x is x0): the direct term g + diag*g*x0 is added into dx0 instead of
     being written to its own buffer (the C ABI's `dxd == dx0` aliasing rule); dxd is then dx0."""
     g, u, x0, x = (_rowmajor(t, "cross_epilogue_bwd").contiguous() for t in (g, u, x0, x))
     m, n = x.shape
     du = torch.empty_like(x) if want_du else None
-    dx0 = dx0_into if dx0_into is not None else torch.empty_like(x)
-    if not dx0.is_contiguous():
-        raise L.KrsError("cross_epilogue_bwd: dx0 buffer must be contiguous")
+    dx0 = None
+    if want_dx0:
+        dx0 = dx0_into if dx0_into is not None else torch.empty_like(x)
+        if not dx0.is_contiguous():
+            raise L.KrsError("cross_epilogue_bwd: dx0 buffer must be contiguous")
     dxd = dx0 if fold_direct else (torch.empty_like(x) if want_dxd else None)
     dbias = torch.empty(n, dtype=torch.float32, device=x.device) if want_dbias else None
     ws, ws_ptr, ws_bytes = _colsum_ws(m, n, x.device) if want_dbias else (None, None, C.c_size_t(0))
@@ -127,6 +129,41 @@ def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
         C.c_int(act), C.c_int(L.fdtype(x)), ws_ptr, ws_bytes, L.stream_ptr())
     L.check(rc, "krs_cross_epilogue_bwd")
     return du, dx0, dxd, dbias
+
+
+def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch.Tensor, u: torch.Tensor, *,
+                   act: int = L.ACT_NONE, dx0_into: torch.Tensor | None = None, want_dbias: bool = True,
+                   fold_direct: bool = False, beta: float = 1.0):
+    """krs_gemm_cross_bwd: G = A @ Bt^T + beta * R (the data gradient of a cross layer = dL/dy of the layer below it)
+    and, from G as stored, the elementwise backward of that layer below -- dz = G x0 act'(u), dx0 = [dx0_into +] G u,
+    dbias = column sums of dz -- in ONE launch (fold_direct: the layer below is fed x0 itself, its direct term G joins
+    dx0).  Returns (G, dz, dx0, dbias).  a: [M, K], bt: [N, K] (K-contiguous
+    weight), r / x0 / u: [M, N] row-major of a's dtype."""
+    a, bt = _rowmajor(a, "gemm_cross_bwd A"), _rowmajor(bt, "gemm_cross_bwd Bt")
+    r, x0, u = (_rowmajor(t, "gemm_cross_bwd operand").contiguous() for t in (r, x0, u))
+    m, k = a.shape
+    n = bt.shape[0]
+    if bt.shape[1] != k or tuple(r.shape) != (m, n) or tuple(x0.shape) != (m, n) or tuple(u.shape) != (m, n):
+        raise L.KrsError("gemm_cross_bwd: shapes do not fit")
+    if not (a.dtype == bt.dtype == r.dtype == x0.dtype == u.dtype):
+        raise L.KrsError("gemm_cross_bwd: one dtype for every operand")
+    g = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    dz = torch.empty_like(g)
+    dx0 = dx0_into if dx0_into is not None else torch.empty_like(g)
+    if not dx0.is_contiguous() or dx0.dtype != a.dtype or tuple(dx0.shape) != (m, n):
+        raise L.KrsError("gemm_cross_bwd: dx0 buffer must be a contiguous [M, N] matrix of the operands' dtype")
+    dbias = torch.empty(n, dtype=torch.float32, device=a.device) if want_dbias else None
+    nbytes = int(L.lib().krs_gemm_cross_bwd_workspace_bytes(C.c_int64(m), C.c_int64(n))) if want_dbias else 0
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=a.device) if want_dbias else None
+    with probe.span("gemm", 2.0 * m * n * k):
+        rc = L.lib().krs_gemm_cross_bwd(
+            L.ptr(a), C.c_int64(a.stride(0)), L.ptr(bt), C.c_int64(bt.stride(0)), L.ptr(r), C.c_int64(r.stride(0)),
+            C.c_float(beta), L.ptr(g), C.c_int64(n), L.ptr(x0), L.ptr(u), L.ptr(dz), L.ptr(dx0), C.c_int64(n),
+            C.c_int(int(dx0_into is not None)), C.c_int(int(fold_direct)), L.ptr(dbias), C.c_int64(m), C.c_int64(n),
+            C.c_int64(k), C.c_int(act),
+            C.c_int(L.fdtype(a)), L.ptr(ws), C.c_size_t(nbytes), L.stream_ptr())
+    L.check(rc, "krs_gemm_cross_bwd")
+    return g, dz, dx0, dbias
 
 
 def colsum(a: torch.Tensor) -> torch.Tensor:

@@ -425,3 +425,39 @@ def test_bias_gradients_are_two_stage_sums_identical_from_run_to_run(dt, m, n):
     rc = L.lib().krs_colsum(L.ptr(g), C.c_int64(n), C.c_int64(m), C.c_int64(n), C.c_int(L.fdtype(g)), L.ptr(out), L.ptr(ws),
                             C.c_size_t(nbytes // 2), L.stream_ptr())
     assert rc != 0 and b"workspace too small" in L.lib().krs_last_error()
+
+
+@pytest.mark.parametrize("acc,fold,act", [(False, False, "linear"), (True, False, "relu"), (True, True, "linear")])
+def test_fused_data_gradient_and_cross_backward_equals_the_two_calls(acc, fold, act):
+    """krs_gemm_cross_bwd (round 4): G = A Bt^T + R, then from G as stored dz = G x0 act'(u), dx0 = [dx0 +] G u [+ G],
+    dbias = colsum(dz) -- against krs_gemm(residual) followed by krs_cross_epilogue_bwd: G, dz and dx0 BIT-identical
+    (bf16 shape the fused ring kernel takes: 192 tiles of 256 x 256), dbias to fp32 summation order; both against the
+    oracle composition on a slice; and a small shape, which takes the two-call form inside the entry."""
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd import dense_ops as D
+    from oracle import krs_oracle as ko
+    from tests.helpers import to_f32, to_np
+
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(11)
+    a_id = {"linear": L.ACT_NONE, "relu": L.ACT_RELU}[act]
+    for (m, n, k) in ((16384, 768, 256), (320, 264, 64)):
+        rnd = lambda *sh: ((torch.rand(*sh, device=dev, generator=gen) - 0.5)).to(torch.bfloat16)  # noqa: E731
+        A, Bt, R, x0, u, told = rnd(m, k), rnd(n, k) * 0.2, rnd(m, n), rnd(m, n), rnd(m, n), rnd(m, n)
+        buf = told.clone() if acc else None
+        G, dz, dx0, db = D.gemm_cross_bwd(A, Bt, R, x0, u, act=a_id, dx0_into=buf, fold_direct=fold)
+        G2, _ = D.gemm(A, Bt, b_is_nk=True, r=R, beta=1.0)
+        buf2 = told.clone() if acc else None
+        dz2, dx02, _, db2 = D.cross_epilogue_bwd(G2, u, x0, x0, 0.0, act=a_id, dx0_into=buf2, want_dxd=False,
+                                                  fold_direct=fold)
+        assert torch.equal(G, G2) and torch.equal(dz, dz2) and torch.equal(dx0, dx02)
+        torch.testing.assert_close(db, db2, rtol=1e-5, atol=1e-4)
+        # oracle composition on the first 64 rows
+        s = 64
+        Gn, _ = ko.gemm(to_np(A[:s]), to_np(Bt), s, n, k, b_is_nk=True, r=to_np(R[:s]), beta=1.0)
+        np.testing.assert_allclose(to_f32(to_np(G[:s])), to_f32(Gn), rtol=2.0 ** -7, atol=1e-6)
+        dzn, dx0n, _, _ = ko.cross_epilogue_bwd(to_np(G[:s]), to_np(u[:s]), to_np(x0[:s]), to_np(x0[:s]), 0.0,
+                                                dx0_init=to_np(told[:s]) if acc else None, act=act if act != "linear" else None,
+                                                fold_direct=fold)
+        np.testing.assert_allclose(to_f32(to_np(dz[:s])), to_f32(dzn), rtol=2.0 ** -7, atol=1e-6)
+        np.testing.assert_allclose(to_f32(to_np(dx0[:s])), to_f32(dx0n), rtol=2.0 ** -7, atol=1e-6)

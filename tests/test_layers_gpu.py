@@ -1042,3 +1042,69 @@ def test_distributed_embedding_mixed_placement_and_update_stats_argument():
     for k, t, d in (("feature1", "table1", 16), ("feature2", "table2", 32), ("feature3", "table3", 64)):
         assert tuple(res[k].shape) == (B, d)
         np.testing.assert_array_equal(res[k].detach().cpu().numpy(), tables[t][ids[k][:, 0]])   # one id per bag: its row
+
+
+def test_cross_stack_backward_with_the_elementwise_pass_in_the_product_epilogue():
+    """Round 4 (krs_gemm_cross_bwd inside autograd.CrossLayerFn): in a stack `xl = layer(x0, xl)` the data-gradient
+    product of layer l+1 runs the elementwise backward of layer l in its epilogue.  Every gradient must be what the
+    separate pass gives -- bit for bit for the data path and the kernels' gradients, to summation order for the bias
+    gradients -- for a stack whose bottom layer is fed x0 itself (the direct term folds into dL/dx0) and with an
+    activation; and when an intermediate output has a SECOND consumer (autograd sums two gradients for it) the layers
+    notice that the product's G was not all of dL/dy and correct through the elementwise kernel."""
+    from keras_rs_amd import autograd as A
+    from keras_rs_amd.layers import base as kl_base
+
+    kl = _layers()
+    g = torch.Generator(device=DEV).manual_seed(21)
+    B, d, p = 16384, 768, 256                       # 64 x 3 tiles of 256 x 256: the fused ring kernel applies
+    x0 = (torch.randn(B, d, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+
+    def run(fuse, pre_activation=None, tap=False):
+        old = A.FUSE_CROSS_BWD
+        A.FUSE_CROSS_BWD = fuse
+        try:
+            layers = [kl.FeatureCross(projection_dim=p, kernel_initializer=kl_base.GlorotUniform(seed=40 + i),
+                                      bias_initializer=kl_base.RandomUniform(-0.1, 0.1, seed=50 + i),
+                                      pre_activation=pre_activation, dtype="mixed_bfloat16") for i in range(3)]
+            x = x0.clone().requires_grad_()
+            xl, outs = x, []
+            for layer in layers:
+                xl = layer(x, xl)
+                outs.append(xl)
+            loss = xl.float().pow(2).mean()
+            if tap:
+                loss = loss + outs[0].float().mean() * 3.0       # a second consumer of the first layer's output
+            loss.backward()
+            torch.cuda.synchronize()
+            named = [(f"{i}.{n}", q.grad.clone()) for i, layer in enumerate(layers) for n, q in layer.named_parameters()]
+            return named + [("x", x.grad.clone())]
+        finally:
+            A.FUSE_CROSS_BWD = old
+
+    calls = []
+    from keras_rs_amd import dense_ops as D
+
+    real = D.gemm_cross_bwd
+
+    def spy(*a, **k):
+        calls.append(k.get("fold_direct"))
+        return real(*a, **k)
+
+    D.gemm_cross_bwd = spy
+    try:
+        for kw in (dict(), dict(pre_activation="relu")):
+            del calls[:]
+            a = run(True, **kw)
+            assert calls == [False, True], calls       # layer 3 -> layer 2, layer 2 -> layer 1 (the bottom: x is x0)
+            b = run(False, **kw)
+            for (name, u), (_, v) in zip(a, b):
+                if name.endswith("bias"):
+                    torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-6)
+                else:
+                    assert torch.equal(u, v), name
+        a, b = run(True, tap=True), run(False, tap=True)
+        for (name, u), (_, v) in zip(a, b):
+            # (the corrected dL/dx0 went through two bf16 roundings instead of one)
+            torch.testing.assert_close(u.float(), v.float(), rtol=2.0 ** -6, atol=1e-6 if not name == "x" else 1e-7)
+    finally:
+        D.gemm_cross_bwd = real
