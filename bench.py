@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="one rank only: capture the step in a HIP graph (keras_rs_amd.graphs.GraphedStep) and time its "
                          "replays -- for the host-bound per-rank step of a strongly-scaled job (--force-sharded --batch 8192)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="sharded dry run without collectives: run the id exchange of the next step ahead anyway")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="sharded runs: keep the id exchange of every step at the head of its forward (A/B of prefetch())")
     ap.add_argument("--rccl-self", action="store_true",
@@ -410,8 +412,12 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
 
     # sharded + static exchange: the id side of the NEXT step's lookup (route -> id all-to-all -> unpack) runs on the
     # layer's exchange stream under this step's backward pass (ShardedDistributedEmbedding.prefetch)
+    # (on by default where real collectives run -- N > 1 or --rccl-self: 3.00 -> 2.81 ms at the per-rank batch of 8192
+    #  through a one-rank RCCL communicator; with device copies standing in for the links the step is bound by the host's
+    #  enqueue rate and the extra stream bookkeeping costs 0.2 ms, profiles/r4e_sharded_b8192_*.json)
+    real_collectives = world > 1 or (a.force_sharded and a.rccl_self)
     prefetch = (sharded_run and loader is None and not getattr(a, "graph", False) and not a.no_prefetch
-                and getattr(model.embedding, "exchange", None) == "static")
+                and (real_collectives or a.prefetch) and getattr(model.embedding, "exchange", None) == "static")
 
     def step():
         xl, inter = model(dense, pre if loader is None else next(loader))

@@ -410,6 +410,7 @@ class ShardedDistributedEmbedding(base.Layer):
         self._prefetched: dict = {}       # group -> what prefetch() ran ahead for the next call
         self.prefetch_hits = 0
         self.slab_grad_gathers = 0        # backward passes that gathered the segment gradients out of the slab gradient
+        self._grow_luts: dict = {}        # (batch, features, lead slots, device) -> row of (sample, feature) in the slab gradient
         self._host_counts = None
         self._collectives_at_world1 = False   # bench --rccl-self: run the collectives through a one-rank communicator
         self._err_dev = self._err_host = self._err_event = None
@@ -955,8 +956,13 @@ class ShardedDistributedEmbedding(base.Layer):
                 self.slab_grad_gathers += 1
                 # row of (sample b, feature f) in the slab gradient seen as [B * (n + ls), dim]: b * (n + ls) + ls + f
                 # = seg_grow + (seg_grow // n + 1) * ls
-                grow = s["seg_grow"]
-                grow = grow + (torch.div(grow, n_feats, rounding_mode="floor") + 1) * lead_slots
+                # (one gather through a cached table of the B * n remapped row numbers instead of three elementwise ops)
+                key = (batch, n_feats, lead_slots, str(slab_grad.device))
+                lut = self._grow_luts.get(key)
+                if lut is None:
+                    r = torch.arange(batch * n_feats, dtype=torch.int32, device=slab_grad.device)
+                    lut = self._grow_luts[key] = r + (torch.div(r, n_feats, rounding_mode="floor") + 1) * lead_slots
+                grow = torch.index_select(lut, 0, s["seg_grow"])
                 dpart = k.gather_rows(slab_grad.view(batch * (n_feats + lead_slots), g.dim), grow)
             else:
                 grad = grad.contiguous()
