@@ -292,7 +292,8 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
 
 /* Data-gradient product of a cross layer FUSED with the elementwise backward of the cross layer below it in a stack
  * on one x0 (`xl = layer(x0, xl)` repeated, examples/ml_perf/model.py:332-336; gradients of feature_cross.py:182-194):
- *      G   = A[M,K] @ Bt[N,K]^T + beta * R            dL/dx of the upper layer = dL/dy of the lower one (stored)
+ *      G   = A[M,K] @ Bt[N,K]^T [+ beta * R]          dL/dx of the upper layer = dL/dy of the lower one (stored;
+ *                                                      R == NULL: no residual -- the layer above is a Dense layer)
  *      dz  = G * x0 * act'(u)                          d(pre-activation) of the lower layer   (act' from its saved output u)
  *      dx0 = [dx0 +] G * u [+ G]                       its term of dL/dx0 (dx0_accumulate != 0: added to what dx0 holds;
  *                                                      fold_direct != 0: the lower layer's x IS x0, so the direct term

@@ -148,7 +148,8 @@ class Dx0Relay:
     def __init__(self, x0: torch.Tensor):
         self.x0, self.buf, self.task = x0, None, -1
         # lower: what the consumer of y needs to run THIS layer's elementwise backward inside its own data-gradient
-        #   product (krs_gemm_cross_bwd): (u, act, diag_scale, has_bias, x_is_x0), left by this layer's forward;
+        #   product (krs_gemm_cross_bwd): (u, act, diag_scale, has_bias, x_is_x0, x0 in the compute dtype), left by
+        #   this layer's forward;
         # fused: (G, version of G, dz, dbias) left by that consumer's backward when it did so -- `buf` then already
         #   holds this layer's term of dL/dx0 as well.
         self.lower, self.fused = None, None
@@ -190,18 +191,23 @@ class SlabGradRelay:
 FUSE_CROSS_BWD = bool(int(__import__("os").environ.get("KRS_FUSE_CROSS_BWD", "1")))
 
 
+def _fusable_below(up, a, x_dtype, task) -> bool:
+    """May the product `a @ Bt^T` run the elementwise backward of the cross layer behind relay `up` in its epilogue?"""
+    low = up.lower if up is not None else None
+    return not (low is None or task == -1 or not FUSE_CROSS_BWD or low[2] != 0.0 or a.dtype != torch.bfloat16
+                or x_dtype != a.dtype       # (the product is handed to autograd as it is: a cast would be a different tensor)
+                or low[5].dtype != a.dtype or (up.buf is not None and up.task == task))
+
+
 def _dx_product(ctx, dh, dc, direct, dx0, x0c, task):
     """dx = dh U^T + direct.  When x was produced by a cross layer on the same x0 (ctx.relay_up) whose elementwise
     backward can ride in this product's epilogue, it does: that layer's dz / dbias and its term of dL/dx0 (added into
     this layer's dx0 buffer) are left on its relay.  Returns (dx, dx0)."""
     up = ctx.relay_up
-    low = up.lower if up is not None else None
-    if (low is None or task == -1 or not FUSE_CROSS_BWD or low[2] != 0.0 or dh.dtype != torch.bfloat16
-            or ctx.meta[6] != dh.dtype      # (dx is handed to autograd as it is: a cast would be a different tensor)
-            or (up.buf is not None and up.task == task) or not dx0.is_contiguous() or dx0.dtype != dh.dtype):
+    if not _fusable_below(up, dh, ctx.meta[6], task) or not dx0.is_contiguous() or dx0.dtype != dh.dtype:
         dx, _ = D.gemm(dh, dc, b_is_nk=True, r=direct, beta=1.0)
         return dx, dx0
-    u_low, act_low, _, bias_low, same_low = low
+    u_low, act_low, _, bias_low, same_low, _ = up.lower
     dx, dz_low, dx0, db_low = D.gemm_cross_bwd(dh, dc, direct, x0c, u_low, act=act_low, dx0_into=dx0,
                                                want_dbias=bias_low, fold_direct=same_low)
     up.fused = (dx, dx._version, dz_low, db_low, task)
@@ -241,7 +247,7 @@ class CrossLayerFn(torch.autograd.Function):
                     x0.dtype, x.dtype, None if down is None else down.dtype, kernel.dtype)
         ctx.relay_in = relay_in
         if relay_in is not None and FUSE_CROSS_BWD and down is not None:
-            relay_in.lower = (u, act, float(diag_scale or 0.0), bias is not None, same)
+            relay_in.lower = (u, act, float(diag_scale or 0.0), bias is not None, same, x0c)
         ctx.w_refs = tuple(weakref.ref(w) for w in (down, kernel) if w is not None)
         # pending uses of each weight (a weight shared by two layer calls gets two gradient contributions)
         ctx.counted = any(ctx.needs_input_grad[i] for i in (2, 3))
@@ -377,12 +383,15 @@ class DenseFn(torch.autograd.Function):
     db = column sum, dx = dz K^T."""
 
     @staticmethod
-    def forward(ctx, x, kernel, bias, act, compute_dtype):
+    def forward(ctx, x, kernel, bias, act, compute_dtype, relay_up=None):
+        # relay_up: the Dx0Relay of the cross layer that produced x (layers.Dense reads it off its input): this layer's
+        # data-gradient product then runs that layer's elementwise backward in its epilogue (krs_gemm_cross_bwd)
         xc = x.to(compute_dtype).contiguous()
         kc, kct = D.cast_transpose(kernel, compute_dtype)
         y, _ = D.gemm(xc, kct, b_is_nk=True, bias=bias, act=act)
         ctx.save_for_backward(xc, kc, y if act != L.ACT_NONE else None)
         ctx.meta = (act, bias is not None, x.dtype, kernel.dtype)
+        ctx.relay_up = relay_up if ctx.needs_input_grad[0] else None
         return y
 
     @staticmethod
@@ -396,9 +405,19 @@ class DenseFn(torch.autograd.Function):
         dk, _ = D.gemm(xc, dz, a_is_km=True, out_dtype=torch.float32)            # [in, units]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx, _ = D.gemm(dz, kc, b_is_nk=True)                                   # [B, in]
-            dx = dx.to(x_dt)
-        return dx, dk.to(k_dt), db, None, None
+            up, task = ctx.relay_up, torch._C._current_graph_task_id()
+            if _fusable_below(up, dz, x_dt, task):
+                # x is the output of a cross layer: dx = dz K^T is its dL/dy, and its elementwise backward (dz, its
+                # term of dL/dx0, bias gradient) rides in the epilogue of this product
+                u_low, act_low, _, bias_low, same_low, x0c = up.lower
+                dx, dz_low, dx0, db_low = D.gemm_cross_bwd(dz, kc, None, x0c, u_low, act=act_low, want_dbias=bias_low,
+                                                           fold_direct=same_low)
+                up.buf, up.task = dx0, task
+                up.fused = (dx, dx._version, dz_low, db_low, task)
+            else:
+                dx, _ = D.gemm(dz, kc, b_is_nk=True)                               # [B, in]
+                dx = dx.to(x_dt)
+        return dx, dk.to(k_dt), db, None, None, None
 
 
 class BinaryCrossentropyFn(torch.autograd.Function):

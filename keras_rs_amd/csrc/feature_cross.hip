@@ -983,7 +983,7 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // A wave's 128 x 64 block in four chunks of 32 rows; a chunk's R / x0 / u / dx0 vectors are requested before its
 // accumulators are staged.  ACC: dx0 already holds the terms of the layers above (a template parameter: a load behind
 // a run-time branch makes hipcc drain the load queue).
-template <bool ACC>
+template <bool ACC, bool HAS_R>
 __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
                                                                int64_t wm0, int64_t wn0, int64_t group) {
   const int lane = threadIdx.x & 63;
@@ -1002,11 +1002,12 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int64_t gmc = min(row0 + it * 8 + (lane >> 3), p.m - 1);
-      er[it] = load8_bf16_nt(p.ep.r, gmc * p.ep.ldr + gnc);
       ex0[it] = load8_bf16_nt(p.f_x0, gmc * p.f_ld + gnc);
       eu[it] = load8_bf16_nt(p.f_u, gmc * p.f_ld + gnc);
+      if constexpr (HAS_R) er[it] = load8_bf16_nt(p.ep.r, gmc * p.ep.ldr + gnc);
+      else er[it] = ex0[it];
       if constexpr (ACC) ed[it] = load8_bf16_nt(p.f_dx0, gmc * p.f_ld + gnc);
-      else ed[it] = er[it];
+      else ed[it] = ex0[it];
     }
     f32x16(&acc2)[2] = acc[c >> 1][c & 1];
 #pragma unroll
@@ -1024,9 +1025,11 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
       const float4 v0 = *reinterpret_cast<const float4*>(stage + er_ * SST + ec);
       const float4 v1 = *reinterpret_cast<const float4*>(stage + er_ * SST + ec + 4);
       v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-      unpack_bf16x8(er[it], rv);
+      if constexpr (HAS_R) {
+        unpack_bf16x8(er[it], rv);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
+        for (int q = 0; q < 8; ++q) v[q] += p.ep.beta * rv[q];
+      }
       // G as it is stored (one rounding) is what everything below sees
       const uint4 gq = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                                   pack_bf16x2(v[6], v[7]));
@@ -1596,8 +1599,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
   }
   lds_dma_retired<NPF>();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  if constexpr (EPI == 3 || EPI == 4) {
-    gemm_epilogue_wave128_crossbwd<EPI == 4>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
+  if constexpr (EPI >= 3) {   // 3: + R, 4: + R, dx0 accumulates, 5: no R, 6: no R, dx0 accumulates
+    gemm_epilogue_wave128_crossbwd<EPI == 4 || EPI == 6, EPI == 3 || EPI == 4>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64,
+                                                                              (m0 >> 8) * 2 + wm);
     return;
   }
   if constexpr (NPFC > 0 && SCHED == 0 && KRS_PP_PROBE != 4)
@@ -2572,7 +2576,8 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
                                   void* dx0, int64_t ld, int dx0_accumulate, int fold_direct, float* dbias,
                                   int64_t m, int64_t n, int64_t k, int act, int dtype, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-  KRS_REQUIRE(a && bt && r && g_out && x0 && u && dz && dx0, "krs_gemm_cross_bwd: null operand");
+  KRS_REQUIRE(a && bt && g_out && x0 && u && dz && dx0, "krs_gemm_cross_bwd: null operand");
+  if (!r) { ldr = n; beta = 0.0f; }
   KRS_REQUIRE(dtype == KRS_BF16 || dtype == KRS_F32, "krs_gemm_cross_bwd: bad dtype");
   KRS_REQUIRE(m >= 0 && n >= 0 && k > 0 && ld >= n && ldg >= n && ldr >= n, "krs_gemm_cross_bwd: bad sizes");
   if (dbias) KRS_REQUIRE(workspace && workspace_bytes >= krs_gemm_cross_bwd_workspace_bytes(m, n),
@@ -2582,14 +2587,15 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool fused = dtype == KRS_BF16 && gemm_pipe() != 0 && m >= 256 && n >= 256 && k >= 256 && k % 64 == 0 &&
                      ceil_div(m, 256) * ceil_div(n, 256) >= 192 && n % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
-                     ldr % 8 == 0 && ldg % 8 == 0 && ld % 8 == 0 && al16(a) && al16(bt) && al16(r) && al16(g_out) &&
+                     ldr % 8 == 0 && ldg % 8 == 0 && ld % 8 == 0 && al16(a) && al16(bt) && (!r || al16(r)) && al16(g_out) &&
                      al16(x0) && al16(u) && al16(dz) && al16(dx0);
   if (!fused) {
     // any other shape / dtype: the two calls this entry stands for
     krs_gemm_epilogue ep;
     memset(&ep, 0, sizeof(ep));
     ep.r = r; ep.ldr = ldr; ep.beta = beta;
-    if (int rc = krs_gemm(a, lda, 0, bt, ldb, 1, g_out, ldg, m, n, k, dtype, dtype, &ep, nullptr, 0, stream)) return rc;
+    if (int rc = krs_gemm(a, lda, 0, bt, ldb, 1, g_out, ldg, m, n, k, dtype, dtype, r ? &ep : nullptr, nullptr, 0, stream))
+      return rc;
     KRS_REQUIRE(ldg == ld, "krs_gemm_cross_bwd: the two-call form needs one row stride for G, x0, u, dz and dx0");
     return krs_cross_epilogue_bwd(g_out, u, x0, x0, dz, dx0, dx0_accumulate, fold_direct ? dx0 : nullptr, dbias, m, n,
                                   ld, 0.0f, act, dtype, workspace, workspace_bytes, stream);
@@ -2617,8 +2623,13 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
     }                                                                                                  \
     hipLaunchKernelGGL(kern, grid256, dim3(512), 4 * pp::STAGE, st, p, 0, nt_);                        \
   }
-  if (dx0_accumulate) KRS_CB_LAUNCH(4)
-  else KRS_CB_LAUNCH(3)
+  if (r) {
+    if (dx0_accumulate) KRS_CB_LAUNCH(4)
+    else KRS_CB_LAUNCH(3)
+  } else {
+    if (dx0_accumulate) KRS_CB_LAUNCH(6)
+    else KRS_CB_LAUNCH(5)
+  }
 #undef KRS_CB_LAUNCH
   KRS_CHECK_LAUNCH("gemm_pp256_kernel (fused cross backward)");
   if (dbias) return finish_colsum(p.f_partial, 2 * ceil_div(m, 256), n, dbias, st);

@@ -140,12 +140,13 @@ def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch
     dx0).  Returns (G, dz, dx0, dbias).  a: [M, K], bt: [N, K] (K-contiguous
     weight), r / x0 / u: [M, N] row-major of a's dtype."""
     a, bt = _rowmajor(a, "gemm_cross_bwd A"), _rowmajor(bt, "gemm_cross_bwd Bt")
-    r, x0, u = (_rowmajor(t, "gemm_cross_bwd operand").contiguous() for t in (r, x0, u))
+    x0, u = (_rowmajor(t, "gemm_cross_bwd operand").contiguous() for t in (x0, u))
+    r = None if r is None else _rowmajor(r, "gemm_cross_bwd R").contiguous()      # (None: no residual term)
     m, k = a.shape
     n = bt.shape[0]
-    if bt.shape[1] != k or tuple(r.shape) != (m, n) or tuple(x0.shape) != (m, n) or tuple(u.shape) != (m, n):
+    if bt.shape[1] != k or (r is not None and tuple(r.shape) != (m, n)) or tuple(x0.shape) != (m, n) or tuple(u.shape) != (m, n):
         raise L.KrsError("gemm_cross_bwd: shapes do not fit")
-    if not (a.dtype == bt.dtype == r.dtype == x0.dtype == u.dtype):
+    if not (a.dtype == bt.dtype == x0.dtype == u.dtype) or (r is not None and r.dtype != a.dtype):
         raise L.KrsError("gemm_cross_bwd: one dtype for every operand")
     g = torch.empty((m, n), dtype=a.dtype, device=a.device)
     dz = torch.empty_like(g)
@@ -157,7 +158,8 @@ def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=a.device) if want_dbias else None
     with probe.span("gemm", 2.0 * m * n * k):
         rc = L.lib().krs_gemm_cross_bwd(
-            L.ptr(a), C.c_int64(a.stride(0)), L.ptr(bt), C.c_int64(bt.stride(0)), L.ptr(r), C.c_int64(r.stride(0)),
+            L.ptr(a), C.c_int64(a.stride(0)), L.ptr(bt), C.c_int64(bt.stride(0)), L.ptr(r),
+            C.c_int64(r.stride(0) if r is not None else n),
             C.c_float(beta), L.ptr(g), C.c_int64(n), L.ptr(x0), L.ptr(u), L.ptr(dz), L.ptr(dx0), C.c_int64(n),
             C.c_int(int(dx0_into is not None)), C.c_int(int(fold_direct)), L.ptr(dbias), C.c_int64(m), C.c_int64(n),
             C.c_int64(k), C.c_int(act),

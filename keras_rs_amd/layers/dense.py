@@ -50,8 +50,11 @@ class Dense(base.Layer):
         if d != self.kernel.shape[0]:
             raise ValueError(f"Dense: input feature size {d} does not match the kernel {tuple(self.kernel.shape)}")
         fused = self.activation in _FUSED_ACTS
+        # (an input that is the output of a FeatureCross stack carries that layer's relay: the data gradient of this
+        #  layer then runs the cross layer's elementwise backward in its epilogue, autograd.DenseFn)
         y = DenseFn.apply(x.reshape(-1, d), self.kernel, self.bias,
-                          _FUSED_ACTS[self.activation] if fused else L.ACT_NONE, self.compute_dtype)
+                          _FUSED_ACTS[self.activation] if fused else L.ACT_NONE, self.compute_dtype,
+                          getattr(x, "_krs_dx0_relay", None) if x.dim() == 2 else None)
         if not fused:
             y = self.activation(y)
         return y.reshape(*lead, self.units)

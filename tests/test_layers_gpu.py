@@ -1108,3 +1108,58 @@ def test_cross_stack_backward_with_the_elementwise_pass_in_the_product_epilogue(
             torch.testing.assert_close(u.float(), v.float(), rtol=2.0 ** -6, atol=1e-6 if not name == "x" else 1e-7)
     finally:
         D.gemm_cross_bwd = real
+
+
+def test_dense_layer_above_a_cross_stack_runs_the_top_layers_elementwise_backward_in_its_data_gradient():
+    """The top MLP of the ml_perf model is fed the cross stack's output (examples/ml_perf/model.py:209-211): its first
+    Dense layer's data-gradient product dx = dz K^T IS dL/dy of the top cross layer, so that layer's elementwise backward
+    rides in the product's epilogue too (krs_gemm_cross_bwd without a residual).  Same gradients as the separate passes."""
+    from keras_rs_amd import autograd as A
+    from keras_rs_amd import dense_ops as D
+    from keras_rs_amd.layers import base as kl_base
+
+    kl = _layers()
+    g = torch.Generator(device=DEV).manual_seed(31)
+    B, d, p = 16384, 768, 256
+    x0 = (torch.randn(B, d, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+    calls = []
+    real = D.gemm_cross_bwd
+
+    def spy(*a, **k):
+        calls.append(a[2] is None)
+        return real(*a, **k)
+
+    def run(fuse, n_cross):
+        old, A.FUSE_CROSS_BWD = A.FUSE_CROSS_BWD, fuse
+        try:
+            cross = [kl.FeatureCross(projection_dim=p, kernel_initializer=kl_base.GlorotUniform(seed=60 + i),
+                                     bias_initializer=kl_base.RandomUniform(-0.1, 0.1, seed=70 + i),
+                                     dtype="mixed_bfloat16") for i in range(n_cross)]
+            mlp = [kl.Dense(256, activation="relu", kernel_initializer=kl_base.GlorotUniform(seed=80), dtype="mixed_bfloat16"),
+                   kl.Dense(1, activation="sigmoid", kernel_initializer=kl_base.GlorotUniform(seed=81), dtype="mixed_bfloat16")]
+            x = x0.clone().requires_grad_()
+            xl = x
+            for layer in cross:
+                xl = layer(x, xl)
+            y = mlp[1](mlp[0](xl))
+            y.float().mean().backward()
+            torch.cuda.synchronize()
+            return [(f"{i}.{n}", q.grad.clone()) for i, layer in enumerate(cross + mlp) for n, q in layer.named_parameters()] \
+                + [("x", x.grad.clone())]
+        finally:
+            A.FUSE_CROSS_BWD = old
+
+    D.gemm_cross_bwd = spy
+    try:
+        for n_cross, expect in ((2, [True, False]), (1, [True])):   # (one layer: it is also the bottom, x is x0)
+            del calls[:]
+            a = run(True, n_cross)
+            assert calls == expect, calls                 # the Dense layer's product (no residual), then layer 2 -> layer 1
+            b = run(False, n_cross)
+            for (name, u), (_, v) in zip(a, b):
+                if name.endswith("bias") and int(name[0]) < n_cross:
+                    torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-7)
+                else:
+                    assert torch.equal(u, v), name
+    finally:
+        D.gemm_cross_bwd = real
