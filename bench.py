@@ -453,8 +453,10 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     eager_step = step
     if getattr(a, "graph", False) and not getattr(a, "_graph_used", False):
         a._graph_used = True      # (the primary leg only: see keras_rs_amd/graphs.py on a second capture in one process)
-        if world > 1 or loader is not None or dp:
-            raise SystemExit("--graph: one rank, device-resident inputs, no collectives")
+        if loader is not None:
+            raise SystemExit("--graph: device-resident inputs only")
+        # (collectives inside the capture -- N > 1 or --rccl-self: RCCL's kernels and torch's stream hand-offs are
+        #  captured with the step; every rank captures and replays the same graph)
         from keras_rs_amd.graphs import GraphedStep
 
         step = GraphedStep(eager_step, warmup=2)

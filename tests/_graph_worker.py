@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 DEV = "cuda:0"
 
 
-def _build(sharded: bool):
+def _build(sharded: bool, rccl: bool = False):
     import keras_rs_amd.layers as kl
     from keras_rs_amd.layers import base
 
@@ -27,6 +27,7 @@ def _build(sharded: bool):
         from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
         emb = ShardedDistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=D, exchange="static")
+        emb._collectives_at_world1 = rccl       # the all-to-alls through the one-rank RCCL communicator
     else:
         emb = kl.DistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=D)
     dot = kl.DotInteraction(dtype="bfloat16")
@@ -39,6 +40,7 @@ def _build(sharded: bool):
     g_xl = torch.full((B, 5 * D), 1.0 / B, dtype=torch.bfloat16, device=DEV)
     g_in = torch.full((B, 10), 0.1 / B, dtype=torch.bfloat16, device=DEV)
     box = [None]
+    red = [None]
 
     def step():
         out = emb(pre)
@@ -52,8 +54,17 @@ def _build(sharded: bool):
         if box[0] is None:
             from keras_rs_amd.optim import Adagrad
 
-            box[0] = Adagrad([p for layer in cross for p in layer.parameters()], lr=0.01, initial_accumulator_value=0.1,
-                             prepare_casts=True)
+            params = [p for layer in cross for p in layer.parameters()]
+            box[0] = Adagrad(params, lr=0.01, initial_accumulator_value=0.1, prepare_casts=True)
+            if rccl:
+                # the dense weights' data-parallel all-reduce as well (hooks from the next backward on)
+                from keras_rs_amd.dp import GradAllReduce
+
+                red[0] = GradAllReduce(params, run_at_world1=True)
+                for p in params:
+                    red[0].launch(p)
+        if red[0] is not None:
+            red[0].wait()
         box[0].step()
         box[0].zero_grad(set_to_none=True)
 
@@ -68,15 +79,22 @@ def _build(sharded: bool):
     return emb, step, state
 
 
-def main(sharded: bool):
+def main(sharded: bool, rccl: bool = False):
     from keras_rs_amd.graphs import GraphedStep
 
-    _, step_a, state_a = _build(sharded)
+    if rccl:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    build = lambda: _build(sharded, rccl)   # noqa: E731
+    _, step_a, state_a = build()
     for _ in range(5):
         step_a()
     ref = state_a()
 
-    emb, step_b, state_b = _build(sharded)
+    emb, step_b, state_b = build()
     graphed = GraphedStep(step_b, warmup=2)      # two eager steps, then the capture (which runs nothing)
     for _ in range(3):
         graphed()
@@ -89,12 +107,14 @@ def main(sharded: bool):
     for k in ref:
         assert torch.equal(ref[k], got[k]), k
     # ... and the steps did move the tables (the comparison is not between two untouched states)
-    emb0, step0, state0 = _build(sharded)
+    emb0, step0, state0 = build()
     step0()
     first = state0()
     assert not torch.equal(first["table.t0"], ref["table.t0"])
-    print("GRAPH_OK", "sharded" if sharded else "single")
+    print("GRAPH_OK", ("sharded_rccl" if rccl else "sharded") if sharded else "single")
+    if rccl:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] == "sharded")
+    main(sys.argv[1].startswith("sharded"), sys.argv[1] == "sharded_rccl")

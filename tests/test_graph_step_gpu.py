@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("which", ["single", "sharded"])
+# "sharded_rccl" (round 4): the sharded layer's three all-to-alls and the dense all-reduce run through a one-rank RCCL
+# communicator INSIDE the capture -- RCCL's kernels and torch's stream hand-offs replay with the step
+@pytest.mark.parametrize("which", ["single", "sharded", "sharded_rccl"])
 def test_replayed_steps_equal_eager_steps(which):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_graph_worker.py"), which], capture_output=True,
                        text=True, timeout=600, cwd=ROOT)
