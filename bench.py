@@ -600,6 +600,7 @@ def step_stats(step_ms):
     med = float(np.median(step_ms))
     return {"median_ms": med, "min_ms": float(np.min(step_ms)), "max_ms": float(np.max(step_ms)),
             "steps_over_1.5x_median": int(sum(t > 1.5 * med for t in step_ms)),
+            "each_ms": [round(float(t), 2) for t in step_ms],
             "source": "HIP events at the step boundaries of the timed steps (GPU time; `ms_per_step` is wall clock / steps)"}
 
 
@@ -634,6 +635,18 @@ def roofline_step(a, hots, b_local, res):
                               % (pr["gemm"]["calls"] // n), "bound": "mfma", "achieved": fl / sec / 1e12,
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / sec / MFMA_BF16_PEAK,
                     "ms_per_step": sec * 1e3, "flops_per_step": fl, "traffic": None})
+    if "gemm_cross_bwd" in pr:
+        e = pr["gemm_cross_bwd"]
+        calls = e["calls"] // n
+        sec = e["ms_total"] / n * 1e-3
+        dcols = (a.tables + 1) * a.dim
+        # per launch: operands (dh [B, p] + U [d, p]) + R, x0, u, dL/dx0 in and G, dz, dL/dx0 out: seven [B, d] bf16 streams
+        alg = calls * (7 * b_local * dcols * 2 + (b_local + dcols) * a.projection * 2)
+        out.append({"kernel": "krs_gemm_cross_bwd x %d per step (dx = dh U^T + g with the elementwise backward of the layer "
+                              "below in its epilogue; NOT in the aggregate above)" % calls,
+                    "bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": alg / sec / HBM_PEAK, "ms_per_step": sec * 1e3, "algorithmic_bytes": alg,
+                    "flops_per_step": e["work_total"] / n, "traffic": None})
     for key, label in (("k1", "K1 inside the step (beside the K2 plan on the side stream)"),
                        ("k2_plan", "K2 plan (radix sort + segment list; side stream)")):
         if key in pr:

@@ -156,7 +156,8 @@ def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch
     dbias = torch.empty(n, dtype=torch.float32, device=a.device) if want_dbias else None
     nbytes = int(L.lib().krs_gemm_cross_bwd_workspace_bytes(C.c_int64(m), C.c_int64(n))) if want_dbias else 0
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=a.device) if want_dbias else None
-    with probe.span("gemm", 2.0 * m * n * k):
+    # (its own span: the launch is a product AND five to seven [M, N] streams of elementwise work)
+    with probe.span("gemm_cross_bwd", 2.0 * m * n * k):
         rc = L.lib().krs_gemm_cross_bwd(
             L.ptr(a), C.c_int64(a.stride(0)), L.ptr(bt), C.c_int64(bt.stride(0)), L.ptr(r),
             C.c_int64(r.stride(0) if r is not None else n),

@@ -83,11 +83,19 @@ def main(sharded: bool, rccl: bool = False):
     from keras_rs_amd.graphs import GraphedStep
 
     if rccl:
+        import faulthandler
+        import socket
+
         import torch.distributed as dist
 
+        faulthandler.dump_traceback_later(150, exit=True)    # a capture that hangs must not take the session with it
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-        dist.init_process_group("nccl", rank=0, world_size=1)
+        os.environ.setdefault("MASTER_PORT", str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     build = lambda: _build(sharded, rccl)   # noqa: E731
     _, step_a, state_a = build()
     for _ in range(5):
@@ -111,9 +119,11 @@ def main(sharded: bool, rccl: bool = False):
     step0()
     first = state0()
     assert not torch.equal(first["table.t0"], ref["table.t0"])
-    print("GRAPH_OK", ("sharded_rccl" if rccl else "sharded") if sharded else "single")
+    print("GRAPH_OK", ("sharded_rccl" if rccl else "sharded") if sharded else "single", flush=True)
     if rccl:
-        dist.destroy_process_group()
+        # (destroy_process_group() waits forever while graphs that hold RCCL kernels are alive in this process, ROCm 7.2:
+        #  leave without the teardown)
+        os._exit(0)
 
 
 if __name__ == "__main__":
