@@ -460,10 +460,41 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         from keras_rs_amd.graphs import GraphedStep
 
         step = GraphedStep(eager_step, warmup=2)
-    # K1 launch duration, measured live with events on the launch stream, between the warm-up and the
-    # timed steps (one krs_embed_bag_fwd launch per event pair).
-    k1_s = None
     sharded = world > 1 or a.force_sharded
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # The timed region runs without the cyclic garbage collector: a full collection of a process that has imported
+    # torch walks ~10^6 objects (tens of milliseconds) and, when it lands inside the K steps, starves the GPU for a
+    # whole step -- the first run of this file on a fresh box did that once per run (one 55 ms step among 10.4 ms ones).
+    # Reference counting frees the step's tensors as before; the collector is switched back on behind the region.
+    import gc
+
+    gc.collect()
+    gc.disable()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        step()
+        marks[i + 1].record()     # step boundaries on the launch stream: per-step GPU time, no host wait
+    enqueue_s = time.perf_counter() - t0     # the host has ENQUEUED every step; the device may still be running
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    # K1 launch duration, measured live with events on the launch stream, BEHIND the timed steps (one krs_embed_bag_fwd
+    # launch per event pair).  It used to sit between the warm-up and the timed steps: its blocker copies left the first
+    # timed steps 0.3-1.8 ms slow (11.99, 10.46, then 10.1-10.2 ms in `step_stats.each_ms`), i.e. the warm-up was undone.
+    k1_s = None
     if sharded:
         # sharded run: the embedding call contains the all-to-alls, so K1 is timed on its own in the form
         # the owner side runs it (row gather of this rank's share of the lookups from its shard)
@@ -496,37 +527,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
             k1_ev.append((e0, e1))
         torch.cuda.synchronize()
     k1_s = float(np.median([e0.elapsed_time(e1) for e0, e1 in k1_ev])) * 1e-3
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    # The timed region runs without the cyclic garbage collector: a full collection of a process that has imported
-    # torch walks ~10^6 objects (tens of milliseconds) and, when it lands inside the K steps, starves the GPU for a
-    # whole step -- the first run of this file on a fresh box did that once per run (one 55 ms step among 10.4 ms ones).
-    # Reference counting frees the step's tensors as before; the collector is switched back on behind the region.
-    import gc
-
-    gc.collect()
-    gc.disable()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(steps):
-        step()
-        marks[i + 1].record()     # step boundaries on the launch stream: per-step GPU time, no host wait
-    enqueue_s = time.perf_counter() - t0     # the host has ENQUEUED every step; the device may still be running
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    res = {"elapsed": elapsed, "k1_s": k1_s, "enqueue_s": enqueue_s,
-           "step_ms": [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]}
+    res = {"elapsed": elapsed, "k1_s": k1_s, "enqueue_s": enqueue_s, "step_ms": step_ms}
     if probe_steps > 0:
         from keras_rs_amd import autograd as krs_autograd
         from keras_rs_amd import probe
