@@ -711,12 +711,14 @@ def main():
     if world > 1:
         torch.distributed.barrier()
 
-    # The step below owns every reader of the cross layers' weight gradients (one consumer per weight, gradients set to
-    # None after every step, the all-reduce hooks rejoin the stream): the second stream for dK / dU is safe here, and it
-    # is opt-in since round 4 (keras_rs_amd/autograd.py; KRS_WGRAD_SIDE=0 keeps it off for an A/B)
+    # The second stream for the cross layers' weight gradients (keras_rs_amd/autograd.py, opt-in) stays OFF here since the
+    # elementwise backward moved into the data-gradient products (krs_gemm_cross_bwd): the pass it used to run beside is
+    # gone, so dK / dU would run beside the next layer's ring GEMMs -- two chip-filling GEMMs side by side, which on this
+    # part can lock into a 2x slower interleaving (A/B in one call, profiles/r4k_wgrad_side_ab.txt: 10.13-10.18 ms off,
+    # 10.26 on, and one 22.5 ms leg on).  KRS_WGRAD_SIDE=1 switches it on for an A/B.
     from keras_rs_amd import autograd as krs_autograd
 
-    krs_autograd.set_wgrad_side_stream(bool(int(os.environ.get("KRS_WGRAD_SIDE", "1"))))
+    krs_autograd.set_wgrad_side_stream(bool(int(os.environ.get("KRS_WGRAD_SIDE", "0"))))
     model = Model(a, primary, world, rank)
     model.embedding.build(None)
     opt_box = [None]

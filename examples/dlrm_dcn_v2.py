@@ -120,13 +120,7 @@ def build_model(batch, vocab, hots, embedding_dim=128, projection=512, cross_lay
 
 
 def train_step(model, opt_box, inputs, labels):
-    """One step: forward, BCE, backward (table optimizers run inside it), dense optimizer step.
-    This step is the only reader of the weight gradients (one loss, no regularisers, gradients dropped after the
-    optimizer step), so it lets the cross layers compute dK / dU on their second stream (opt-in, autograd.py)."""
-    from keras_rs_amd import autograd as krs_autograd
-
-    if opt_box[0] is None:
-        krs_autograd.set_wgrad_side_stream(True)
+    """One step: forward, BCE, backward (table optimizers run inside it), dense optimizer step."""
     pred = model(inputs)
     loss = kl.binary_crossentropy(labels, pred)     # main.py:201-210, forward + backward in one pass (krs_bce_fwd_bwd)
     loss.backward()

@@ -30,8 +30,10 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # a little on this part (scripts/exp/overlap_probe2.py: 563 + 271 us apart, 707 together), two GEMMs or a GEMM and the
 # table update do not.  Measured in the step: 10.31-10.48 -> 10.20-10.29 ms.  Deferring all six to the table update was
 # slower (10.49).
-# OPT-IN since round 4 (`set_wgrad_side_stream(True)` or KRS_WGRAD_SIDE=1; bench.py and the example's training step
-# switch it on): a gradient produced on a private stream is only safe when NOTHING but the end-of-backward rejoin reads
+# OPT-IN since round 4 (`set_wgrad_side_stream(True)` or KRS_WGRAD_SIDE=1), and no longer used by bench.py / the example:
+# with the elementwise backward inside the data-gradient products (krs_gemm_cross_bwd) the pass these GEMMs overlapped
+# with is gone -- beside the next layer's ring GEMMs they measured 10.26 against 10.13-10.18 ms, and one leg locked into
+# a 2x slower interleaving of the two GEMM streams (profiles/r4k_wgrad_side_ab.txt).  Also: a gradient produced on a private stream is only safe when NOTHING but the end-of-backward rejoin reads
 # it, and a backward function cannot see every reader -- a second gradient contribution to the same weight (a manual
 # L2 term, a weight shared by two layers) is summed by autograd's input buffer on the main stream with nothing ordering
 # it behind this stream.  The owner of the training step can promise that; a library default cannot.  What the
