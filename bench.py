@@ -476,9 +476,16 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
+    dbg = [] if os.environ.get("KRS_BENCH_DEBUG") else None
     for i in range(steps):
+        if dbg is not None:
+            th = time.perf_counter()
         step()
         marks[i + 1].record()     # step boundaries on the launch stream: per-step GPU time, no host wait
+        if dbg is not None:
+            ms = torch.cuda.memory_stats(dev)
+            dbg.append((round((time.perf_counter() - th) * 1e3, 2), ms.get("reserved_bytes.all.current", 0) >> 20,
+                        ms.get("num_device_alloc", 0), ms.get("num_device_free", 0), ms.get("num_alloc_retries", 0)))
     enqueue_s = time.perf_counter() - t0     # the host has ENQUEUED every step; the device may still be running
     torch.cuda.synchronize()
     if world > 1:
@@ -486,6 +493,8 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if dbg is not None and rank == 0:
+        print("KRS_BENCH_DEBUG per step (host ms, reserved MiB, device allocs, frees, retries):", dbg, file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -713,9 +722,8 @@ def main():
 
     # The second stream for the cross layers' weight gradients (keras_rs_amd/autograd.py, opt-in) stays OFF here since the
     # elementwise backward moved into the data-gradient products (krs_gemm_cross_bwd): the pass it used to run beside is
-    # gone, so dK / dU would run beside the next layer's ring GEMMs -- two chip-filling GEMMs side by side, which on this
-    # part can lock into a 2x slower interleaving (A/B in one call, profiles/r4k_wgrad_side_ab.txt: 10.13-10.18 ms off,
-    # 10.26 on, and one 22.5 ms leg on).  KRS_WGRAD_SIDE=1 switches it on for an A/B.
+    # gone, dK / dU would run beside the next layer's ring GEMMs, and that measures no gain (A/B in one call,
+    # profiles/r4k_wgrad_side_ab.txt: 10.13-10.18 ms off, 10.26 on).  KRS_WGRAD_SIDE=1 switches it on for an A/B.
     from keras_rs_amd import autograd as krs_autograd
 
     krs_autograd.set_wgrad_side_stream(bool(int(os.environ.get("KRS_WGRAD_SIDE", "0"))))

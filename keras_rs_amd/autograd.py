@@ -32,8 +32,8 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # slower (10.49).
 # OPT-IN since round 4 (`set_wgrad_side_stream(True)` or KRS_WGRAD_SIDE=1), and no longer used by bench.py / the example:
 # with the elementwise backward inside the data-gradient products (krs_gemm_cross_bwd) the pass these GEMMs overlapped
-# with is gone -- beside the next layer's ring GEMMs they measured 10.26 against 10.13-10.18 ms, and one leg locked into
-# a 2x slower interleaving of the two GEMM streams (profiles/r4k_wgrad_side_ab.txt).  Also: a gradient produced on a private stream is only safe when NOTHING but the end-of-backward rejoin reads
+# with is gone -- beside the next layer's ring GEMMs they measured 10.26 against 10.13-10.18 ms
+# (profiles/r4k_wgrad_side_ab.txt).  Also: a gradient produced on a private stream is only safe when NOTHING but the end-of-backward rejoin reads
 # it, and a backward function cannot see every reader -- a second gradient contribution to the same weight (a manual
 # L2 term, a weight shared by two layers) is summed by autograd's input buffer on the main stream with nothing ordering
 # it behind this stream.  The owner of the training step can promise that; a library default cannot.  What the
@@ -546,6 +546,7 @@ class EmbedBagFusedFn(torch.autograd.Function):
         # HBM, the sort's scatter passes by LDS ranking work -- and the plan is done when the dense part starts
         # (queued behind the gather it ran under the first FeatureCross GEMMs and slowed them by 0.4 ms).
         ctx.plan = None
+        ctx.owns_plan_ws = False
         plan_first = not _PLAN_AFTER_GATHER
         # the per-bag combiner scale (1 / sum w, 1 / sqrt(sum w^2)) is what the backward multiplies by: all ones for
         # "sum" bags, which then neither write it here nor gather it per lookup there
@@ -563,10 +564,20 @@ class EmbedBagFusedFn(torch.autograd.Function):
             bags.table_desc()
             bags.feature_desc(batch, hots, ids.device)
             side.wait_stream(main)
+            # The plan's workspace (0.36 GB at C3) lives on the bags across steps.  Allocated per step inside the side
+            # stream's context it could only be re-used once the DEVICE had passed the step that used it (record_stream
+            # below), and a host that enqueues a step in 2 ms against 10 ms of device time gets ever further ahead: a
+            # fresh hipMalloc every other step (1 - 11 ms of host time each, box-dependent: one bench leg in three ran
+            # host-bound at 21 ms per step).  Safe: the side stream has just waited for everything the main stream holds,
+            # including the previous step's apply; a second forward before that step's backward gets its own tensor.
+            keep = None if getattr(bags, "_plan_ws_busy", False) else getattr(bags, "_plan_ws", None)
             with torch.cuda.stream(side):
-                ws = bags.plan_backward(ids, batch, hots=hots, offsets=offsets, global_order=False)
+                ws = bags.plan_backward(ids, batch, hots=hots, offsets=offsets, global_order=False, ws=keep)
                 done = torch.cuda.Event()
                 done.record(side)
+            if not getattr(bags, "_plan_ws_busy", False):
+                bags._plan_ws, bags._plan_ws_busy = ws, True
+                ctx.owns_plan_ws = True
             for t in (ws, ids, offsets):
                 if t is not None:
                     t.record_stream(side)
@@ -598,6 +609,8 @@ class EmbedBagFusedFn(torch.autograd.Function):
         hyper = None if isinstance(opt, str) else opt.next_hyper()   # also refreshes scheduled learning rates
         bags.backward_fused(kind, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                             bag_scale=scale, hyper=hyper)
+        if ctx.owns_plan_ws:
+            bags._plan_ws_busy = False     # (the next forward's plan is ordered behind this apply: it may take the buffer)
         return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device), None, None)
 
 

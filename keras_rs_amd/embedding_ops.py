@@ -126,7 +126,7 @@ class FusedBags:
     # ---- K2 ---------------------------------------------------------------
     def plan_backward(self, ids: torch.Tensor, batch: int, hots: Sequence[int] | None = None,
                       offsets: torch.Tensor | None = None, err_flag: torch.Tensor | None = None,
-                      global_order: bool = True):
+                      global_order: bool = True, ws: torch.Tensor | None = None):
         """Sorts the lookups by global row (krs_embed_bag_bwd_plan / _plan_tables).  Returns the opaque
         workspace tensor the apply calls consume; depends only on the ids, not on gradients.
         global_order (default): the global sort -- out-of-range ids form ONE trailing run, every apply form accepts
@@ -136,7 +136,10 @@ class FusedBags:
         L.require_device(ids, "ids")
         nnz = ids.numel()
         nbytes = L.lib().krs_embed_bag_bwd_workspace_bytes(C.c_int64(nnz))
-        ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=ids.device)
+        # ws: a workspace the caller keeps across steps (autograd.EmbedBagFusedFn: the plan runs on a side stream, and a
+        # fresh tensor per step there is a fresh hipMalloc per step for as long as the host runs ahead of the device)
+        if ws is None or ws.numel() < max(int(nbytes), 1) or ws.device != ids.device:
+            ws = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=ids.device)
         tdesc, fdesc = self.table_desc(), self.feature_desc(batch, hots, ids.device)
         if hots is not None and not global_order:
             th = self._tab_host

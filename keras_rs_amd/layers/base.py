@@ -363,65 +363,69 @@ def flatten(structure, is_leaf=None):
     return [v for _, v in flatten_with_path(structure, is_leaf)]
 
 
-def pack_sequence_as(structure, flat, is_leaf=None):
-    it = iter(flat)
-
-    def rec(s):
-        if is_leaf is not None and is_leaf(s):
-            return next(it)
-        if isinstance(s, dict):
-            vals = {k: rec(s[k]) for k in sorted(s.keys(), key=str)}
-            return {k: vals[k] for k in s.keys()}  # keep the caller's insertion order
-        if isinstance(s, tuple):
-            return tuple(rec(v) for v in s)
-        if isinstance(s, list):
-            return [rec(v) for v in s]
+# (The walkers below are module-level functions with explicit arguments, NOT recursive closures: a nested `def rec`
+#  that calls itself sits in its own closure cell, a reference cycle that keeps everything the closure captured -- the
+#  iterator over a step's output tensors, and through their `_krs_slab` tags the whole lookup slab -- alive until the
+#  cyclic collector runs.  With the collector switched off (bench.py's timed region) that leaked the slab of every step.)
+def _pack_rec(s, it, is_leaf):
+    if is_leaf is not None and is_leaf(s):
         return next(it)
+    if isinstance(s, dict):
+        vals = {k: _pack_rec(s[k], it, is_leaf) for k in sorted(s.keys(), key=str)}
+        return {k: vals[k] for k in s.keys()}  # keep the caller's insertion order
+    if isinstance(s, tuple):
+        return tuple(_pack_rec(v, it, is_leaf) for v in s)
+    if isinstance(s, list):
+        return [_pack_rec(v, it, is_leaf) for v in s]
+    return next(it)
 
-    return rec(structure)
+
+def pack_sequence_as(structure, flat, is_leaf=None):
+    return _pack_rec(structure, iter(flat), is_leaf)
+
+
+def _map_rec(s, others, fn, is_leaf):
+    if (is_leaf is not None and is_leaf(s)) or not isinstance(s, (dict, list, tuple)):
+        return fn(*others)
+    if isinstance(s, dict):
+        for o in others:
+            if not isinstance(o, dict) or set(o.keys()) != set(s.keys()):
+                raise ValueError("The two structures don't have the same nested structure.")
+        return {k: _map_rec(s[k], [o[k] for o in others], fn, is_leaf) for k in s.keys()}
+    for o in others:
+        if not isinstance(o, (list, tuple)) or len(o) != len(s):
+            raise ValueError("The two structures don't have the same nested structure.")
+    out = [_map_rec(v, [o[i] for o in others], fn, is_leaf) for i, v in enumerate(s)]
+    return tuple(out) if isinstance(s, tuple) else out
 
 
 def map_structure_up_to(shallow, fn, *structures, is_leaf=None):
     """Walks `shallow`; at each of its leaves calls fn(*matching sub-structures of `structures`)
     (keras.tree.map_structure_up_to)."""
+    return _map_rec(shallow, list(structures), fn, is_leaf)
 
-    def rec(s, others):
-        if (is_leaf is not None and is_leaf(s)) or not isinstance(s, (dict, list, tuple)):
-            return fn(*others)
-        if isinstance(s, dict):
-            for o in others:
-                if not isinstance(o, dict) or set(o.keys()) != set(s.keys()):
-                    raise ValueError("The two structures don't have the same nested structure.")
-            return {k: rec(s[k], [o[k] for o in others]) for k in s.keys()}
-        for o in others:
-            if not isinstance(o, (list, tuple)) or len(o) != len(s):
+
+def _assert_rec(x, y, is_leaf):
+    if (is_leaf is not None and is_leaf(x)) or not isinstance(x, (dict, list, tuple)):
+        if isinstance(y, (dict, list, tuple)) and not (is_leaf is not None and is_leaf(y)):
+            # a leaf on one side may face an array-like on the other; nests must match nests
+            if isinstance(y, dict) or (isinstance(y, (list, tuple)) and any(isinstance(e, (dict, list, tuple)) for e in y)):
                 raise ValueError("The two structures don't have the same nested structure.")
-        out = [rec(v, [o[i] for o in others]) for i, v in enumerate(s)]
-        return tuple(out) if isinstance(s, tuple) else out
-
-    return rec(shallow, list(structures))
+        return
+    if isinstance(x, dict):
+        if not isinstance(y, dict) or set(x.keys()) != set(y.keys()):
+            raise ValueError("The two structures don't have the same nested structure.")
+        for k in x:
+            _assert_rec(x[k], y[k], is_leaf)
+    else:
+        if not isinstance(y, (list, tuple)) or len(x) != len(y):
+            raise ValueError("The two structures don't have the same nested structure.")
+        for u, v in zip(x, y):
+            _assert_rec(u, v, is_leaf)
 
 
 def assert_same_structure(a, b, is_leaf=None):
-    def rec(x, y):
-        if (is_leaf is not None and is_leaf(x)) or not isinstance(x, (dict, list, tuple)):
-            if isinstance(y, (dict, list, tuple)) and not (is_leaf is not None and is_leaf(y)):
-                # a leaf on one side may face an array-like on the other; nests must match nests
-                if isinstance(y, dict) or (isinstance(y, (list, tuple)) and any(isinstance(e, (dict, list, tuple)) for e in y)):
-                    raise ValueError("The two structures don't have the same nested structure.")
-            return
-        if isinstance(x, dict):
-            if not isinstance(y, dict) or set(x.keys()) != set(y.keys()):
-                raise ValueError("The two structures don't have the same nested structure.")
-            for k in x:
-                rec(x[k], y[k])
-        else:
-            if not isinstance(y, (list, tuple)) or len(x) != len(y):
-                raise ValueError("The two structures don't have the same nested structure.")
-            for u, v in zip(x, y):
-                rec(u, v)
-
-    rec(a, b)
+    _assert_rec(a, b, is_leaf)
 
 
 # --------------------------------------------------------------------------- #

@@ -1163,3 +1163,62 @@ def test_dense_layer_above_a_cross_stack_runs_the_top_layers_elementwise_backwar
                     assert torch.equal(u, v), name
     finally:
         D.gemm_cross_bwd = real
+
+
+def test_training_step_leaves_no_cyclic_garbage_that_holds_device_tensors():
+    """bench.py times its steps with the cyclic collector off: anything a step leaves in a reference cycle then stays
+    allocated (round 4: a recursive closure of the output packing held the 453 MB lookup slab of every step, two fresh
+    hipMallocs per step).  With the collector off, a few steps must not grow the allocator's reservation, and a collection
+    afterwards must find no tensor."""
+    import gc
+
+    kl = _layers()
+    from keras_rs_amd.layers import base as kl_base
+
+    B, D, hots, vocabs = 4096, 32, [3, 1, 2], [500, 300, 1000]
+    feats = {}
+    for t in range(3):
+        tc = kl.TableConfig(name=f"t{t}", vocabulary_size=vocabs[t], embedding_dim=D, optimizer=kl.Adagrad(0.05, 0.1),
+                            initializer=kl_base.RandomUniform(-0.05, 0.05, seed=t), combiner="sum", placement="sparsecore")
+        feats[f"f{t}"] = kl.FeatureConfig(f"f{t}", tc, (B, hots[t]), (B, D))
+    emb = kl.DistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=D)
+    dot = kl.DotInteraction(dtype="bfloat16")
+    cross = [kl.FeatureCross(projection_dim=16, dtype="mixed_bfloat16") for _ in range(2)]
+    g = torch.Generator(device=DEV).manual_seed(1)
+    ids = {f"f{t}": torch.randint(0, vocabs[t], (B, hots[t]), device=DEV, generator=g, dtype=torch.int32) for t in range(3)}
+    dense = torch.rand(B, D, device=DEV, generator=g).to(torch.bfloat16)
+    pre = emb.preprocess(ids)
+
+    def step():
+        out = emb(pre)
+        fs = [dense] + [out[k] for k in out]
+        inter = dot(fs)
+        x0 = kl.concat_features(fs)
+        xl = x0
+        for layer in cross:
+            xl = layer(x0, xl)
+        (xl.float().mean() + inter.float().mean()).backward()
+        for layer in cross:
+            for p in layer.parameters():
+                p.grad = None
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    old_flags = gc.get_debug()
+    try:
+        before = torch.cuda.memory_reserved()
+        for _ in range(6):
+            step()
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_reserved() == before
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        gc.collect()
+        leaked = [o for o in gc.garbage if isinstance(o, torch.Tensor)]
+        assert not leaked, [(tuple(t.shape), t.dtype) for t in leaked][:8]
+    finally:
+        gc.set_debug(old_flags)
+        gc.garbage.clear()
+        gc.enable()

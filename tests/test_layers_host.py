@@ -295,3 +295,28 @@ def test_regularizers_are_applied_as_layer_losses_and_constraints_are_refused():
     assert float(er.losses[0]) == pytest.approx(0.1 * float(er.embeddings.detach().float().square().sum()), rel=1e-6)
     with pytest.raises(NotImplementedError):
         kl.EmbedReduce(7, 4, embeddings_constraint=lambda w: w)
+
+
+def test_structure_walkers_leave_no_reference_cycles():
+    """A recursive closure (`def rec` calling itself) is a reference cycle that keeps whatever it captured alive until
+    the cyclic collector runs -- in DistributedEmbedding.call that was the iterator over a step's output tensors, i.e.
+    (through their `_krs_slab` tags) the lookup slab of every step while bench.py had the collector switched off."""
+    import gc
+    import weakref
+
+    class Leaf:
+        pass
+
+    gc.collect()
+    gc.disable()
+    try:
+        leaves = [Leaf() for _ in range(4)]
+        refs = [weakref.ref(x) for x in leaves]
+        nest = {"a": [1, 2], "b": {"c": 3, "d": 4}}
+        packed = base.pack_sequence_as(nest, leaves)
+        base.map_structure_up_to(nest, lambda x, y: (x, y), packed, nest)
+        base.assert_same_structure(nest, packed)
+        del leaves, packed
+        assert all(r() is None for r in refs)        # freed by reference counting alone
+    finally:
+        gc.enable()
