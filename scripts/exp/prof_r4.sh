@@ -23,6 +23,10 @@ python bench.py --force-sharded --batch 8192 --no-cpu-baseline --rccl-self --no-
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/exp/gemm_bench.cpp -o /tmp/gemm_bench -I include -L keras_rs_amd -lkrs_hip -Wl,-rpath,$R/keras_rs_amd 2>/dev/null
 /tmp/gemm_bench 7 > $O/gemm_ab.txt 2>&1
 if [ "$2" = full ]; then
+  cd /tmp; rm -rf /tmp/prof3; rocprofv3 --kernel-trace --stats -d /tmp/prof3 -o b -- python $R/bench.py --full-model --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  python $R/scripts/rocpd_stats.py $(ls /tmp/prof3/*/*.db /tmp/prof3/*.db 2>/dev/null | head -1) 60 > $O/full_model_kernel_stats.md
+  cd $R
+  python bench.py --force-sharded --batch 8192 --no-cpu-baseline --rccl-self --graph 2>/dev/null | grep '^{' > $O/graph_replay_sharded_b8192_rccl_one_rank.json
   python bench.py --force-sharded --batch 8192 --no-cpu-baseline --exchange exact > $O/sharded_b8192_exact.json 2>/dev/null
   cd /tmp; rm -rf /tmp/prof2; rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o b -- python $R/bench.py --force-sharded --batch 8192 --steps 8 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
   python $R/scripts/rocpd_stats.py $(ls /tmp/prof2/*/*.db /tmp/prof2/*.db 2>/dev/null | head -1) 40 > $O/sharded_b8192_kernel_stats.md

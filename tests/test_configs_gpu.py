@@ -85,8 +85,13 @@ def test_c2_eight_tables_three_full_rank_cross_layers_fp32():
     W = [[p.detach().double().cpu().requires_grad_() for p in layer.weights] for layer in layers]
     r0 = torch.from_numpy(x0n).double().requires_grad_()
     rl = r0
+    xs, us = [], []
     for k, b in W:
-        rl = _cross64(r0, rl, k, b)
+        u = rl @ k + b                      # (_cross64 spelled out: the pre-activation's gradient is looked at below)
+        u.retain_grad()
+        xs.append(rl.detach())
+        us.append(u)
+        rl = r0 * u + rl
     rl.backward(g.double().cpu())
     # (weight gradients are fp32 sums of 8192 products of magnitude <= 1: 1e-4 of the column scale, ~ 1e-4 absolute)
     for layer, (k, b) in zip(layers, W):
@@ -95,6 +100,17 @@ def test_c2_eight_tables_three_full_rank_cross_layers_fp32():
         # ... and the north star's 1e-5 as a bound on the gradient as a whole (largest error against largest entry)
         for got, ref in ((layer.weights[0].grad, k.grad), (layer.weights[1].grad, b.grad)):
             assert np.abs(got.cpu().numpy() - ref.numpy()).max() <= 1e-5 * np.abs(ref.numpy()).max()
+    # ELEMENT-wise 1e-5 (round-3 review): every entry of dK = x^T dz is a sum of 8192 products; its fp32 error is bounded
+    # relative to the sum of the products' MAGNITUDES (entries that cancel to ~0 have no meaningful relative error of
+    # their own).  |got - ref|_ij <= 1e-5 * (|x|^T |dz|)_ij for every entry, likewise the bias gradient against sum |dz|.
+    for layer, (k, b), x_l, u_l in zip(layers, W, xs, us):
+        dz = u_l.grad
+        scale_k = (x_l.abs().T @ dz.abs()).numpy()
+        err_k = np.abs(layer.weights[0].grad.cpu().numpy().astype(np.float64) - k.grad.numpy())
+        assert (err_k <= 1e-5 * scale_k + 1e-30).all(), float((err_k / (scale_k + 1e-30)).max())
+        scale_b = dz.abs().sum(0).numpy()
+        err_b = np.abs(layer.weights[1].grad.cpu().numpy().astype(np.float64) - b.grad.numpy())
+        assert (err_b <= 1e-5 * scale_b + 1e-30).all(), float((err_b / (scale_b + 1e-30)).max())
     # embedding-table gradient = scatter-add of the x0 gradient slices (index work: exact rows, 1e-5 values)
     dx0 = r0.grad.numpy()
     for t in (0, 5):
