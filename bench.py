@@ -412,10 +412,11 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
 
     # sharded + static exchange: the id side of the NEXT step's lookup (route -> id all-to-all -> unpack) runs on the
     # layer's exchange stream under this step's backward pass (ShardedDistributedEmbedding.prefetch)
-    # (on by default where real collectives run -- N > 1 or --rccl-self: 3.00 -> 2.81 ms at the per-rank batch of 8192
-    #  through a one-rank RCCL communicator; with device copies standing in for the links the step is bound by the host's
-    #  enqueue rate and the extra stream bookkeeping costs 0.2 ms, profiles/r4e_sharded_b8192_*.json)
-    real_collectives = world > 1 or (a.force_sharded and a.rccl_self)
+    # (on by default for N > 1, where the id all-to-all has link time to hide.  On ONE GPU the per-rank step is bound by
+    #  the host's enqueue rate and prefetch only adds stream bookkeeping: through the one-rank RCCL communicator it measured
+    #  3.00 -> 2.81 ms in one call and 2.72 -> 2.98 in another (profiles/r4e_* / r4z_sharded_b8192_rccl_one_rank*.json:
+    #  inside the run-to-run spread of a host-bound step); --prefetch forces it for such dry runs)
+    real_collectives = world > 1
     prefetch = (sharded_run and loader is None and not getattr(a, "graph", False) and not a.no_prefetch
                 and (real_collectives or a.prefetch) and getattr(model.embedding, "exchange", None) == "static")
 
@@ -631,8 +632,11 @@ def roofline_step(a, hots, b_local, res):
         sec = pr["k2_apply"]["ms_total"] / n * 1e-3
         traffic = None
         if not a.criteo_vocab and a.id_skew == 0 and not a.rowwise_adagrad and a.batch == 65536 and a.vocab == 1_000_000 \
-                and list(hots) == (ML_PERF_HOTS * 8)[: a.tables] and a.tables == 26:
-            traffic = pmc_traffic_key("bag_apply_fast_kernel<adagrad> multi-hot")
+                and a.tables == 26:
+            if list(hots) == (ML_PERF_HOTS * 8)[: a.tables]:
+                traffic = pmc_traffic_key("bag_apply_fast_kernel<adagrad> multi-hot")
+            elif list(hots) == [1] * a.tables:
+                traffic = pmc_traffic_key("bag_apply_fast_kernel<adagrad> L=1")
         out.append({"kernel": "bag_apply_fast_kernel<adagrad> (K2 apply, krs_embed_bag_bwd_fused_adagrad)", "bound": "hbm",
                     "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK,
                     "launch_us": sec * 1e6, "algorithmic_bytes": alg, "unique_rows": u, "traffic": traffic,
