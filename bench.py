@@ -449,7 +449,7 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
         opt.step()
         opt.zero_grad(set_to_none=True)
 
-    for _ in range(warmup):
+    for _ in range(max(warmup - 1, 0)):     # (the last warm-up step runs behind the collection below)
         step()
     eager_step = step
     if getattr(a, "graph", False) and not getattr(a, "_graph_used", False):
@@ -471,6 +471,10 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
 
     gc.collect()
     gc.disable()
+    if warmup > 0:
+        # the LAST of the W warm-up steps: a full collection walks ~10^6 objects and leaves the interpreter's caches cold;
+        # timed right behind it, the first step enqueued slowly enough to starve the device (11.7 ms against 10.1)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
