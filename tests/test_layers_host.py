@@ -320,3 +320,25 @@ def test_structure_walkers_leave_no_reference_cycles():
         assert all(r() is None for r in refs)        # freed by reference counting alone
     finally:
         gc.enable()
+
+
+def test_bench_phase_table_of_a_sharded_run():
+    """bench.py::exchange_phases (the `phases` object of an N > 1 line): per-phase ms per step, min / max over the ranks,
+    and for the all-to-alls bytes off the rank, bytes per link and GB/s -- from probe spans, no GPU needed."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("krs_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pr = {"route": {"calls": 3, "ms_total": 0.3, "work_total": 0.0},
+          "a2a_partials": {"calls": 3, "ms_total": 1.5, "work_total": 3 * 7e6},
+          "k2": {"calls": 3, "ms_total": 1.8, "work_total": 0.0},
+          "gemm": {"calls": 54, "ms_total": 9.0, "work_total": 1e12}}       # (not a phase of the exchange)
+    ph = bench.exchange_phases(pr, 3, 1)
+    assert set(ph) == {"route", "a2a_partials", "k2"}
+    assert ph["route"]["ms_per_step"] == pytest.approx(0.1) and ph["route"]["calls_per_step"] == 1
+    a = ph["a2a_partials"]
+    assert a["min_ms"] == a["max_ms"] == pytest.approx(0.5) and a["bytes_off_rank_per_step"] == 7_000_000
+    assert a["bytes_per_link_per_step"] == 7_000_000 and a["GB_per_s_per_rank"] == pytest.approx(7e6 / 0.5e-3 / 1e9)
