@@ -660,11 +660,17 @@ def roofline_step(a, hots, b_local, res):
         dcols = (a.tables + 1) * a.dim
         # per launch: operands (dh [B, p] + U [d, p]) + R, x0, u, dL/dx0 in and G, dz, dL/dx0 out: seven [B, d] bf16 streams
         alg = calls * (7 * b_local * dcols * 2 + (b_local + dcols) * a.projection * 2)
+        traffic = None
+        if a.batch == 65536 and a.tables == 26 and a.dim == 128 and a.projection == 512 and b_local == a.batch:
+            per_launch = pmc_traffic_key("gemm_pp256_kernel<false, 4, 4, 0> (krs_gemm_cross_bwd, C3 shape)")
+            traffic = None if per_launch is None else calls * per_launch
         out.append({"kernel": "krs_gemm_cross_bwd x %d per step (dx = dh U^T + g with the elementwise backward of the layer "
                               "below in its epilogue; NOT in the aggregate above)" % calls,
                     "bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": alg / sec / HBM_PEAK, "ms_per_step": sec * 1e3, "algorithmic_bytes": alg,
-                    "flops_per_step": e["work_total"] / n, "traffic": None})
+                    "flops_per_step": e["work_total"] / n, "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes of this kernel at this shape under scripts/exp/gemm_bench, x launches per step)"})
     for key, label in (("k1", "K1 inside the step (beside the K2 plan on the side stream)"),
                        ("k2_plan", "K2 plan (radix sort + segment list; side stream)")):
         if key in pr:

@@ -116,10 +116,13 @@ int main(int argc, char** argv) {
   void* ws;
   CK(hipMalloc(&ws, wsb ? wsb : 16));
   printf("split-K workspace %.1f MB\n", wsb / 1e6);
+  const size_t ws2b = krs_gemm_cross_bwd_workspace_bytes(B, d);
+  void* ws2;
+  CK(hipMalloc(&ws2, ws2b ? ws2b : 16));
   hipStream_t st = 0;
   struct Case { const char* name; double flops; double bytes; };
   const double F = 2.0 * B * d * pj;
-  const Case cases[7] = {
+  const Case cases[8] = {
       {"fwd1 h = x U          (K=3456,N=512)", F, (double)(B * d + B * pj) * 2},
       {"fwd2 y = cross(h V)   (K=512,N=3456)", F, (double)(B * pj + 4 * B * d) * 2},
       {"bwd  elementwise dz, dx0", 0, (double)5 * B * d * 2},
@@ -127,6 +130,7 @@ int main(int argc, char** argv) {
       {"dh   = dz V^T         (K=3456,N=512)", F, (double)(B * d + B * pj) * 2},
       {"dU   = x^T dh         (split-K)", F, (double)(B * d + B * pj) * 2},
       {"dx   = dh U^T + g     (K=512,N=3456)", F, (double)(B * pj + 2 * B * d) * 2},
+      {"dx + elementwise bwd of the layer below", F, (double)(B * pj + 7 * B * d) * 2},
   };
   auto run_case = [&](int c, int i) {
     krs_gemm_epilogue ep;
@@ -159,12 +163,16 @@ int main(int argc, char** argv) {
         ep.r = g.p; ep.ldr = g.ld; ep.beta = 1.0f;
         KK(krs_gemm(dh[i].p, dh[i].ld, 0, U.p, U.ld, 1, dx[i].p, dx[i].ld, B, d, pj, KRS_BF16, KRS_BF16, &ep, nullptr, 0, st));
         break;
+      case 7:   // krs_gemm_cross_bwd: the same product + dz / dL/dx0 (accumulating) / bias gradient of the layer below
+        KK(krs_gemm_cross_bwd(dh[i].p, dh[i].ld, U.p, U.ld, g.p, g.ld, 1.0f, dx[i].p, dx[i].ld, x0.p, u[i].p, dz[i].p, dx0[i].p,
+                              x.ld, 1, 0, dbias, B, d, pj, KRS_ACT_NONE, KRS_BF16, ws2, ws2b, st));
+        break;
     }
   };
   // warm-up + outputs of every pipeline (cases in dependency order)
   for (int i = 0; i < NP; ++i) {
     KK(krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, pipes[i]));
-    for (int c = 0; c < 7; ++c) run_case(c, i);
+    for (int c = 0; c < 8; ++c) run_case(c, i);
   }
   CK(hipDeviceSynchronize());
   for (int i = 1; i < NP; ++i) {
@@ -191,9 +199,9 @@ int main(int argc, char** argv) {
   // timing: rounds x pipelines x cases, one event pair per call
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  std::vector<float> t[NP][7];
+  std::vector<float> t[NP][8];
   for (int r = 0; r < rounds; ++r)
-    for (int c = 0; c < 7; ++c)
+    for (int c = 0; c < 8; ++c)
       for (int i = 0; i < NP; ++i) {
         KK(krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, pipes[i]));
         run_case(c, i);  // untimed: same-variant warm caches / clocks
@@ -210,12 +218,12 @@ int main(int argc, char** argv) {
   for (int i = 0; i < NP; ++i) printf("   pipe %d          ", pipes[i]);
   printf("\n");
   double tot[NP] = {0, 0, 0};
-  for (int c = 0; c < 7; ++c) {
+  for (int c = 0; c < 8; ++c) {
     printf("%-40s", cases[c].name);
     for (int i = 0; i < NP; ++i) {
       std::sort(t[i][c].begin(), t[i][c].end());
       const double us = t[i][c][t[i][c].size() / 2];
-      tot[i] += us;
+      if (c != 7) tot[i] += us;     // (case 7 replaces cases 2 + 6 of a lower layer: listed, not summed)
       if (cases[c].flops > 0) printf("  %7.1f us %6.0f TF", us, cases[c].flops / us / 1e6);
       else printf("  %7.1f us %6.0f GB", us, cases[c].bytes / us / 1e3);
     }
