@@ -1049,7 +1049,8 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
         tv[q] = __builtin_fmaf(g[q], uv[q], ACC ? tv[q] : 0.0f);
         if (p.f_fold) tv[q] += g[q];     // the layer below is the bottom of its stack (x is x0): the direct term too
       }
-      store8(p.f_dz, KRS_BF16, gm * p.f_ld + gn, dz);                   // (read next by the dh and dK products)
+      store8_bf16_nt(p.f_dz, gm * p.f_ld + gn, dz);   // (nt like the other streams: 657-660 us against 664-667 with a plain store;
+                                                       //  the dh / dK products that read dz next measure the same either way)
       store8_bf16_nt(p.f_dx0, gm * p.f_ld + gn, tv);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
