@@ -92,9 +92,9 @@ def parse():
                     help="one rank only: capture the step in a HIP graph (keras_rs_amd.graphs.GraphedStep) and time its "
                          "replays -- for the host-bound per-rank step of a strongly-scaled job (--force-sharded --batch 8192)")
     ap.add_argument("--prefetch", action="store_true",
-                    help="sharded dry run without collectives: run the id exchange of the next step ahead anyway")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="sharded runs: keep the id exchange of every step at the head of its forward (A/B of prefetch())")
+                    help="sharded runs: the id side of the next step's lookup (route -> id all-to-all -> unpack) runs ahead "
+                         "on the layer's exchange stream (ShardedDistributedEmbedding.prefetch)")
+    ap.add_argument("--no-prefetch", action="store_true", help="(kept for old command lines: prefetch is opt-in)")
     ap.add_argument("--rccl-self", action="store_true",
                     help="with --force-sharded at N = 1: route the layer's collectives through a ONE-rank RCCL communicator "
                          "instead of device copies (proves the RCCL call path on a one-GPU box)")
@@ -412,13 +412,13 @@ def measure(model, a, hots, world, rank, dev, b_local, steps, warmup, opt_box, l
 
     # sharded + static exchange: the id side of the NEXT step's lookup (route -> id all-to-all -> unpack) runs on the
     # layer's exchange stream under this step's backward pass (ShardedDistributedEmbedding.prefetch)
-    # (on by default for N > 1, where the id all-to-all has link time to hide.  On ONE GPU the per-rank step is bound by
-    #  the host's enqueue rate and prefetch only adds stream bookkeeping: through the one-rank RCCL communicator it measured
-    #  3.00 -> 2.81 ms in one call and 2.72 -> 2.98 in another (profiles/r4e_* / r4z_sharded_b8192_rccl_one_rank*.json:
-    #  inside the run-to-run spread of a host-bound step); --prefetch forces it for such dry runs)
-    real_collectives = world > 1
-    prefetch = (sharded_run and loader is None and not getattr(a, "graph", False) and not a.no_prefetch
-                and (real_collectives or a.prefetch) and getattr(model.embedding, "exchange", None) == "static")
+    # (opt-in, --prefetch.  On ONE GPU the per-rank step is bound by the host's enqueue rate and prefetch only adds stream
+    #  bookkeeping: through the one-rank RCCL communicator it measured 3.00 -> 2.81 ms in one call and 2.72 -> 2.98 in
+    #  another (profiles/r4e_* / r4z_sharded_b8192_rccl_one_rank*.json: inside the run-to-run spread of a host-bound step).
+    #  Between real ranks it takes the id all-to-all's link time off the critical path, but RCCL between ranks has never
+    #  run in this environment: the first hardware run of `--gpus N` stays on the plain, fully tested order of collectives)
+    prefetch = (sharded_run and loader is None and not getattr(a, "graph", False) and a.prefetch
+                and getattr(model.embedding, "exchange", None) == "static")
 
     def step():
         xl, inter = model(dense, pre if loader is None else next(loader))
