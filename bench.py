@@ -91,6 +91,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="one rank only: capture the step in a HIP graph (keras_rs_amd.graphs.GraphedStep) and time its "
                          "replays -- for the host-bound per-rank step of a strongly-scaled job (--force-sharded --batch 8192)")
+    ap.add_argument("--capacity-settle", type=int, default=0, metavar="STEPS",
+                    help="sharded runs, static exchange: shrink the block capacities to the running statistics once STEPS steps "
+                         "in a row fit (the layer's default is 16; 0 = keep the first sizing for the whole run)")
     ap.add_argument("--prefetch", action="store_true",
                     help="sharded runs: the id side of the next step's lookup (route -> id all-to-all -> unpack) runs ahead "
                          "on the layer's exchange stream (ShardedDistributedEmbedding.prefetch)")
@@ -197,8 +200,10 @@ class Model(torch.nn.Module):
         if world > 1 or a.force_sharded:
             from keras_rs_amd.sharded import ShardedDistributedEmbedding
 
+            # (capacity_settle_steps: the blocks of the static exchange shrink to the settled statistics after that many
+            #  fitting steps -- a resize, i.e. fresh buffers, in the middle of a 20-step timed region; off unless asked for)
             self.embedding = ShardedDistributedEmbedding(feats, dtype="bfloat16", slab_lead_cols=a.dim,
-                                                         exchange=a.exchange)
+                                                         exchange=a.exchange, capacity_settle_steps=a.capacity_settle)
             self.embedding._collectives_at_world1 = bool(a.rccl_self)
         else:
             # the dense feature's 128 columns are reserved in front of the 26 embeddings: the lookups land
