@@ -298,6 +298,10 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
  *      dx0 = [dx0 +] G * u [+ G]                       its term of dL/dx0 (dx0_accumulate != 0: added to what dx0 holds;
  *                                                      fold_direct != 0: the lower layer's x IS x0, so the direct term
  *                                                      joins, the `dxd == dx0` rule of krs_cross_epilogue_bwd)
+ *                                                      u_upper != NULL (needs R, beta = 1, dx0_accumulate = 0): the term of
+ *                                                      the layer ABOVE joins here, dx0 = R * u_upper + G * u [+ G] -- R is its
+ *                                                      dL/dy, u_upper its saved activation output; that layer then writes
+ *                                                      no dL/dx0 of its own and this sum is rounded once, not twice)
  *      dbias[n] = sum_m dz[m,n]                        fp32, fixed summation order (NULL: not wanted)
  * i.e. exactly krs_gemm(A, Bt, epilogue{r = R, beta}) followed by krs_cross_epilogue_bwd(g = G, u, x0, diag_scale = 0),
  * with G, dz and dx0 BIT-IDENTICAL to those two calls (dz and dx0 are computed from G as it is stored, after its one
@@ -309,7 +313,7 @@ int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, int64_t ldb,
                        const void* r, int64_t ldr, float beta,
                        void* g_out, int64_t ldg,
                        const void* x0, const void* u, void* dz, void* dx0, int64_t ld, int dx0_accumulate,
-                       int fold_direct, float* dbias, int64_t m, int64_t n, int64_t k, int act, int dtype,
+                       const void* u_upper, int fold_direct, float* dbias, int64_t m, int64_t n, int64_t k, int act, int dtype,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tuning / diagnostic switches of krs_gemm (process-wide; results never depend on them).

@@ -191,6 +191,8 @@ class SlabGradRelay:
 # by re-reading it.  krs_gemm_cross_bwd does that pass in the product's epilogue (one 453 MB stream less per layer at C3,
 # and the other streams at the epilogue's rate): environment KRS_FUSE_CROSS_BWD=0 switches it off (A/B).
 FUSE_CROSS_BWD = bool(int(__import__("os").environ.get("KRS_FUSE_CROSS_BWD", "1")))
+# ... and the TOP layer's own term of dL/dx0 is computed in that epilogue too (it writes dz only): KRS_FUSE_TOP_DX0=0 for A/B
+FUSE_TOP_DX0 = bool(int(__import__("os").environ.get("KRS_FUSE_TOP_DX0", "1")))
 
 
 def _fusable_below(up, a, x_dtype, task) -> bool:
@@ -201,11 +203,19 @@ def _fusable_below(up, a, x_dtype, task) -> bool:
                 or low[5].dtype != a.dtype or (up.buf is not None and up.task == task))
 
 
-def _dx_product(ctx, dh, dc, direct, dx0, x0c, task):
+def _dx_product(ctx, dh, dc, direct, dx0, x0c, task, u_own=None):
     """dx = dh U^T + direct.  When x was produced by a cross layer on the same x0 (ctx.relay_up) whose elementwise
     backward can ride in this product's epilogue, it does: that layer's dz / dbias and its term of dL/dx0 (added into
-    this layer's dx0 buffer) are left on its relay.  Returns (dx, dx0)."""
+    this layer's dx0 buffer) are left on its relay.  Returns (dx, dx0).
+    dx0 None + u_own (the TOP layer of a stack, see CrossLayerFn.backward): this layer wrote no dL/dx0 of its own; its term
+    direct * u_own starts the matrix inside the fused epilogue."""
     up = ctx.relay_up
+    if dx0 is None:
+        u_low, act_low, _, bias_low, same_low, _ = up.lower
+        dx, dz_low, dx0, db_low = D.gemm_cross_bwd(dh, dc, direct, x0c, u_low, act=act_low, want_dbias=bias_low,
+                                                   fold_direct=same_low, u_upper=u_own)
+        up.fused = (dx, dx._version, dz_low, db_low, task)
+        return dx, dx0
     if not _fusable_below(up, dh, ctx.meta[6], task) or not dx0.is_contiguous() or dx0.dtype != dh.dtype:
         dx, _ = D.gemm(dh, dc, b_is_nk=True, r=direct, beta=1.0)
         return dx, dx0
@@ -283,6 +293,7 @@ class CrossLayerFn(torch.autograd.Function):
             rin.buf = None
         if fused is not None and (incoming is None or fused[4] != task):
             fused = None
+        defer_dx0 = False
         if fused is not None:
             # The consumer of y ran this layer's elementwise backward inside its data-gradient product
             # (krs_gemm_cross_bwd): `incoming` already holds this layer's term, dz and dbias are done.  That is only
@@ -299,6 +310,15 @@ class CrossLayerFn(torch.autograd.Function):
                 dz, _, _, dbias = D.cross_epilogue_bwd(g, u, x0c, xc, diag, act=act, want_dxd=False,
                                                        want_dbias=has_bias, want_dx0=False)
                 dxd = dx0 if same else None
+        elif (incoming is None and extra is None and not same and low_rank and not diag and FUSE_TOP_DX0
+              and _fusable_below(ctx.relay_up, g, x_dt, task)):
+            # The TOP layer of a stack (nothing above it left a dL/dx0) whose data-gradient product is going to run the
+            # layer below's elementwise backward: its own term g * u is computed THERE (g is that product's residual, already
+            # in registers), so this pass writes dz only -- three [B, d] streams instead of five, and no matrix for dL/dx0 is
+            # written here and read back there.
+            dz, _, dxd, dbias = D.cross_epilogue_bwd(g, u if act != L.ACT_NONE else None, x0c, xc, diag, act=act,
+                                                     want_dxd=False, want_dbias=has_bias, want_dx0=False)
+            dx0, defer_dx0 = None, True
         else:
             # x is x0 (the first layer of a stack): both halves of dL/dx0 go through one buffer, which
             # the data-gradient GEMM then takes as its residual -- no separate add.
@@ -306,6 +326,7 @@ class CrossLayerFn(torch.autograd.Function):
                                                        want_dbias=has_bias, fold_direct=same, dx0_into=incoming)
         if extra is not None:
             dx0 = dx0 + extra.to(dx0.dtype)
+        u_own = u if defer_dx0 else None
         direct = dx0 if same else (dxd if need_dxd else g)  # dL/dx through "+ x" and "diag * x"
         # (worth it when the kernels are long against a launch: at a per-rank batch of 8192 the step is bound by the
         #  host's enqueue rate and the extra events cost more than the overlap returns: 2.42 -> 2.54 ms)
@@ -334,7 +355,7 @@ class CrossLayerFn(torch.autograd.Function):
             # main stream (the dz / dx0 pass of the layer below, or the DotInteraction gradient and the table update
             # behind the bottom layer).  The main stream rejoins at the end of the backward pass (wgrad_stream_sync).
             dh, _ = D.gemm(dz, kc, b_is_nk=True)                               # dh = dz K^T     [B, p]
-            dx, dx0 = _dx_product(ctx, dh, dc, direct, dx0, x0c, task)         # dx = dh U^T + direct
+            dx, dx0 = _dx_product(ctx, dh, dc, direct, dx0, x0c, task, u_own)  # dx = dh U^T + direct
             main = torch.cuda.current_stream()
             side = _wgrad_stream(dz.device)
             ev = torch.cuda.Event()
@@ -357,7 +378,7 @@ class CrossLayerFn(torch.autograd.Function):
             dk, _ = D.gemm(h, dz, a_is_km=True, out_dtype=torch.float32)      # dK = h^T dz     [p, d]
             dh, _ = D.gemm(dz, kc, b_is_nk=True)                               # dh = dz K^T     [B, p]
             dd, _ = D.gemm(xc, dh, a_is_km=True, out_dtype=torch.float32)      # dU = x^T dh     [d, p]
-            dx, dx0 = _dx_product(ctx, dh, dc, direct, dx0, x0c, task)         # dx = dh U^T + direct
+            dx, dx0 = _dx_product(ctx, dh, dc, direct, dx0, x0c, task, u_own)  # dx = dh U^T + direct
         else:
             dk, _ = D.gemm(xc, dz, a_is_km=True, out_dtype=torch.float32)      # dK = x^T dz     [d, d]
             dd = None

@@ -65,7 +65,7 @@ struct GemmParams {
   int splits; int64_t k_per_split; float* slabs;
   int ep_vec;  // every epilogue operand allows 8-wide vector access
   // fused cross-backward epilogue (EPI 3 / 4 of gemm_pp256_kernel, krs_gemm_cross_bwd): operands of the layer below
-  const void* f_x0; const void* f_u; void* f_dz; void* f_dx0; float* f_partial; int64_t f_ld; int f_act; int f_fold;
+  const void* f_x0; const void* f_u; const void* f_uup; void* f_dz; void* f_dx0; float* f_partial; int64_t f_ld; int f_act; int f_fold;
 };
 
 __device__ __forceinline__ float apply_act(int act, float v) {
@@ -983,7 +983,10 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // A wave's 128 x 64 block in four chunks of 32 rows; a chunk's R / x0 / u / dx0 vectors are requested before its
 // accumulators are staged.  ACC: dx0 already holds the terms of the layers above (a template parameter: a load behind
 // a run-time branch makes hipcc drain the load queue).
-template <bool ACC, bool HAS_R>
+// DX0: where the running dL/dx0 comes from -- 0: nothing yet, 1: the dx0 buffer (terms of the layers above), 2: R * u_upper,
+// the term of the layer ABOVE computed here from its dL/dy (= R, already loaded) and its saved u, so that the top layer of a
+// stack neither writes nor this launch reads a [M, N] matrix for it (that one sum is rounded once instead of twice).
+template <int DX0, bool HAS_R>
 __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
                                                                int64_t wm0, int64_t wn0, int64_t group) {
   const int lane = threadIdx.x & 63;
@@ -1006,7 +1009,8 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
       eu[it] = load8_bf16_nt(p.f_u, gmc * p.f_ld + gnc);
       if constexpr (HAS_R) er[it] = load8_bf16_nt(p.ep.r, gmc * p.ep.ldr + gnc);
       else er[it] = ex0[it];
-      if constexpr (ACC) ed[it] = load8_bf16_nt(p.f_dx0, gmc * p.f_ld + gnc);
+      if constexpr (DX0 == 1) ed[it] = load8_bf16_nt(p.f_dx0, gmc * p.f_ld + gnc);
+      else if constexpr (DX0 == 2) ed[it] = load8_bf16_nt(p.f_uup, gmc * p.f_ld + gnc);
       else ed[it] = ex0[it];
     }
     f32x16(&acc2)[2] = acc[c >> 1][c & 1];
@@ -1046,7 +1050,8 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
         const float gx0 = g[q] * x0v[q];
         dz[q] = gx0 * act_grad_from_output(p.f_act, uv[q]);
         db[q] += dz[q];
-        tv[q] = __builtin_fmaf(g[q], uv[q], ACC ? tv[q] : 0.0f);
+        const float told = DX0 == 1 ? tv[q] : (DX0 == 2 ? rv[q] * tv[q] : 0.0f);
+        tv[q] = __builtin_fmaf(g[q], uv[q], told);
         if (p.f_fold) tv[q] += g[q];     // the layer below is the bottom of its stack (x is x0): the direct term too
       }
       store8_bf16_nt(p.f_dz, gm * p.f_ld + gn, dz);   // (nt like the other streams: 657-660 us against 664-667 with a plain store;
@@ -1600,9 +1605,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
   }
   lds_dma_retired<NPF>();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  if constexpr (EPI >= 3) {   // 3: + R, 4: + R, dx0 accumulates, 5: no R, 6: no R, dx0 accumulates
-    gemm_epilogue_wave128_crossbwd<EPI == 4 || EPI == 6, EPI == 3 || EPI == 4>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64,
-                                                                              (m0 >> 8) * 2 + wm);
+  if constexpr (EPI >= 3) {   // 3: + R, 4: + R, dx0 accumulates, 5: no R, 6: no R, dx0 accumulates, 7: + R, dx0 = R u_upper + ...
+    gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : 0), EPI == 3 || EPI == 4 || EPI == 7>(
+        p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
     return;
   }
   if constexpr (NPFC > 0 && SCHED == 0 && KRS_PP_PROBE != 4)
@@ -2574,11 +2579,13 @@ extern "C" size_t krs_gemm_cross_bwd_workspace_bytes(int64_t m, int64_t n) {
 
 extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, int64_t ldb, const void* r, int64_t ldr,
                                   float beta, void* g_out, int64_t ldg, const void* x0, const void* u, void* dz,
-                                  void* dx0, int64_t ld, int dx0_accumulate, int fold_direct, float* dbias,
-                                  int64_t m, int64_t n, int64_t k, int act, int dtype, void* workspace,
+                                  void* dx0, int64_t ld, int dx0_accumulate, const void* u_upper, int fold_direct,
+                                  float* dbias, int64_t m, int64_t n, int64_t k, int act, int dtype, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   KRS_REQUIRE(a && bt && g_out && x0 && u && dz && dx0, "krs_gemm_cross_bwd: null operand");
   if (!r) { ldr = n; beta = 0.0f; }
+  KRS_REQUIRE(!u_upper || (r && !dx0_accumulate && beta == 1.0f),
+              "krs_gemm_cross_bwd: u_upper (dx0 = R * u_upper + ...) needs R with beta = 1 and no dx0 to accumulate into");
   KRS_REQUIRE(dtype == KRS_BF16 || dtype == KRS_F32, "krs_gemm_cross_bwd: bad dtype");
   KRS_REQUIRE(m >= 0 && n >= 0 && k > 0 && ld >= n && ldg >= n && ldr >= n, "krs_gemm_cross_bwd: bad sizes");
   if (dbias) KRS_REQUIRE(workspace && workspace_bytes >= krs_gemm_cross_bwd_workspace_bytes(m, n),
@@ -2589,7 +2596,7 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
   const bool fused = dtype == KRS_BF16 && gemm_pipe() != 0 && m >= 256 && n >= 256 && k >= 256 && k % 64 == 0 &&
                      ceil_div(m, 256) * ceil_div(n, 256) >= 192 && n % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
                      ldr % 8 == 0 && ldg % 8 == 0 && ld % 8 == 0 && al16(a) && al16(bt) && (!r || al16(r)) && al16(g_out) &&
-                     al16(x0) && al16(u) && al16(dz) && al16(dx0);
+                     al16(x0) && al16(u) && al16(dz) && al16(dx0) && (!u_upper || al16(u_upper));
   if (!fused) {
     // any other shape / dtype: the two calls this entry stands for
     krs_gemm_epilogue ep;
@@ -2598,6 +2605,12 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
     if (int rc = krs_gemm(a, lda, 0, bt, ldb, 1, g_out, ldg, m, n, k, dtype, dtype, r ? &ep : nullptr, nullptr, 0, stream))
       return rc;
     KRS_REQUIRE(ldg == ld, "krs_gemm_cross_bwd: the two-call form needs one row stride for G, x0, u, dz and dx0");
+    if (u_upper) {   // the upper layer's term first: dx0 = R * u_upper (its own rounding here), then accumulate
+      KRS_REQUIRE(ldr == ld, "krs_gemm_cross_bwd: the two-call form needs R on the common row stride");
+      if (int rc = krs_cross_epilogue_bwd(r, u_upper, x0, x0, nullptr, dx0, 0, nullptr, nullptr, m, n, ld, 0.0f, KRS_ACT_NONE,
+                                          dtype, nullptr, 0, stream)) return rc;
+      dx0_accumulate = 1;
+    }
     return krs_cross_epilogue_bwd(g_out, u, x0, x0, dz, dx0, dx0_accumulate, fold_direct ? dx0 : nullptr, dbias, m, n,
                                   ld, 0.0f, act, dtype, workspace, workspace_bytes, stream);
   }
@@ -2609,7 +2622,7 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
   memset(&p.ep, 0, sizeof(p.ep));
   p.ep.r = r; p.ep.ldr = ldr; p.ep.beta = beta;
   p.splits = 1; p.k_per_split = k; p.slabs = nullptr; p.ep_vec = 1;
-  p.f_x0 = x0; p.f_u = u; p.f_dz = dz; p.f_dx0 = dx0; p.f_ld = ld; p.f_act = act; p.f_fold = fold_direct != 0;
+  p.f_x0 = x0; p.f_u = u; p.f_uup = u_upper; p.f_dz = dz; p.f_dx0 = dx0; p.f_ld = ld; p.f_act = act; p.f_fold = fold_direct != 0;
   p.f_partial = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
   const int nt_ = (int)ceil_div(n, 256);
   const dim3 grid256((unsigned)(ceil_div(ceil_div(m, 256), 8) * 8 * nt_));
@@ -2624,7 +2637,8 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
     }                                                                                                  \
     hipLaunchKernelGGL(kern, grid256, dim3(512), 4 * pp::STAGE, st, p, 0, nt_);                        \
   }
-  if (r) {
+  if (u_upper) KRS_CB_LAUNCH(7)
+  else if (r) {
     if (dx0_accumulate) KRS_CB_LAUNCH(4)
     else KRS_CB_LAUNCH(3)
   } else {

@@ -112,7 +112,11 @@ def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
     """Returns (du, dx0, dxd, dbias); dx0 accumulates into `dx0_into` when given.
     fold_direct (the case x is x0): the direct term g + diag*g*x0 is added into dx0 instead of
     being written to its own buffer (the C ABI's `dxd == dx0` aliasing rule); dxd is then dx0."""
-    g, u, x0, x = (_rowmajor(t, "cross_epilogue_bwd").contiguous() for t in (g, u, x0, x))
+    g, x0, x = (_rowmajor(t, "cross_epilogue_bwd").contiguous() for t in (g, x0, x))
+    # (u None: allowed when neither dL/dx0 nor an activation derivative is wanted -- dz = g * x0 needs no third stream)
+    u = None if u is None else _rowmajor(u, "cross_epilogue_bwd").contiguous()
+    if u is None and (want_dx0 or act != L.ACT_NONE):
+        raise L.KrsError("cross_epilogue_bwd: u is needed for dL/dx0 and for an activation's derivative")
     m, n = x.shape
     du = torch.empty_like(x) if want_du else None
     dx0 = None
@@ -133,11 +137,12 @@ def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
 
 def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch.Tensor, u: torch.Tensor, *,
                    act: int = L.ACT_NONE, dx0_into: torch.Tensor | None = None, want_dbias: bool = True,
-                   fold_direct: bool = False, beta: float = 1.0):
+                   fold_direct: bool = False, beta: float = 1.0, u_upper: torch.Tensor | None = None):
     """krs_gemm_cross_bwd: G = A @ Bt^T + beta * R (the data gradient of a cross layer = dL/dy of the layer below it)
     and, from G as stored, the elementwise backward of that layer below -- dz = G x0 act'(u), dx0 = [dx0_into +] G u,
     dbias = column sums of dz -- in ONE launch (fold_direct: the layer below is fed x0 itself, its direct term G joins
-    dx0).  Returns (G, dz, dx0, dbias).  a: [M, K], bt: [N, K] (K-contiguous
+    dx0; u_upper: the saved activation output of the layer ABOVE, whose own term R * u_upper then starts dx0 here instead
+    of in a matrix that layer would have written).  Returns (G, dz, dx0, dbias).  a: [M, K], bt: [N, K] (K-contiguous
     weight), r / x0 / u: [M, N] row-major of a's dtype."""
     a, bt = _rowmajor(a, "gemm_cross_bwd A"), _rowmajor(bt, "gemm_cross_bwd Bt")
     x0, u = (_rowmajor(t, "gemm_cross_bwd operand").contiguous() for t in (x0, u))
@@ -153,6 +158,10 @@ def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch
     dx0 = dx0_into if dx0_into is not None else torch.empty_like(g)
     if not dx0.is_contiguous() or dx0.dtype != a.dtype or tuple(dx0.shape) != (m, n):
         raise L.KrsError("gemm_cross_bwd: dx0 buffer must be a contiguous [M, N] matrix of the operands' dtype")
+    if u_upper is not None:
+        u_upper = _rowmajor(u_upper, "gemm_cross_bwd u_upper").contiguous()
+        if dx0_into is not None or r is None or beta != 1.0 or u_upper.dtype != a.dtype or tuple(u_upper.shape) != (m, n):
+            raise L.KrsError("gemm_cross_bwd: u_upper needs R (beta = 1), no dx0 to accumulate into, and the operands' shape / dtype")
     dbias = torch.empty(n, dtype=torch.float32, device=a.device) if want_dbias else None
     nbytes = int(L.lib().krs_gemm_cross_bwd_workspace_bytes(C.c_int64(m), C.c_int64(n))) if want_dbias else 0
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=a.device) if want_dbias else None
@@ -162,7 +171,8 @@ def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch
             L.ptr(a), C.c_int64(a.stride(0)), L.ptr(bt), C.c_int64(bt.stride(0)), L.ptr(r),
             C.c_int64(r.stride(0) if r is not None else n),
             C.c_float(beta), L.ptr(g), C.c_int64(n), L.ptr(x0), L.ptr(u), L.ptr(dz), L.ptr(dx0), C.c_int64(n),
-            C.c_int(int(dx0_into is not None)), C.c_int(int(fold_direct)), L.ptr(dbias), C.c_int64(m), C.c_int64(n),
+            C.c_int(int(dx0_into is not None)), L.ptr(u_upper), C.c_int(int(fold_direct)), L.ptr(dbias), C.c_int64(m),
+            C.c_int64(n),
             C.c_int64(k), C.c_int(act),
             C.c_int(L.fdtype(a)), L.ptr(ws), C.c_size_t(nbytes), L.stream_ptr())
     L.check(rc, "krs_gemm_cross_bwd")

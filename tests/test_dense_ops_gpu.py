@@ -461,3 +461,15 @@ def test_fused_data_gradient_and_cross_backward_equals_the_two_calls(acc, fold, 
                                                 fold_direct=fold)
         np.testing.assert_allclose(to_f32(to_np(dz[:s])), to_f32(dzn), rtol=2.0 ** -7, atol=1e-6)
         np.testing.assert_allclose(to_f32(to_np(dx0[:s])), to_f32(dx0n), rtol=2.0 ** -7, atol=1e-6)
+        if not acc:
+            # u_upper: the term of the layer above, R * u_upper, starts dL/dx0 inside the same epilogue (R is its dL/dy):
+            # G and dz as before, dL/dx0 = R u_upper + G u [+ G] rounded once (the two-pass composition rounds twice)
+            u_up = rnd(m, n)
+            G3, dz3, dx03, db3 = D.gemm_cross_bwd(A, Bt, R, x0, u, act=a_id, fold_direct=fold, u_upper=u_up)
+            assert torch.equal(G3, G) and torch.equal(dz3, dz)
+            torch.testing.assert_close(db3, db, rtol=1e-6, atol=1e-6)
+            ref = R.float() * u_up.float() + G.float() * u.float() + (G.float() if fold else 0.0)
+            # (one bf16 ulp of the LARGER of the two terms: they may cancel; the small shape runs the two-pass form
+            #  inside the entry, whose intermediate rounding doubles that)
+            scale = float((R.float() * u_up.float()).abs().max() + (G.float() * u.float()).abs().max())
+            torch.testing.assert_close(dx03.float(), ref, rtol=2.0 ** -7, atol=2.0 ** -7 * scale)
