@@ -302,6 +302,8 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
  *                                                      the layer ABOVE joins here, dx0 = R * u_upper + G * u [+ G] -- R is its
  *                                                      dL/dy, u_upper its saved activation output; that layer then writes
  *                                                      no dL/dx0 of its own and this sum is rounded once, not twice)
+ *                                                      dx0 == NULL (R == NULL form only): nothing is written -- the caller
+ *                                                      passes u as the u_upper of the NEXT launch, whose R is this G
  *      dbias[n] = sum_m dz[m,n]                        fp32, fixed summation order (NULL: not wanted)
  * i.e. exactly krs_gemm(A, Bt, epilogue{r = R, beta}) followed by krs_cross_epilogue_bwd(g = G, u, x0, diag_scale = 0),
  * with G, dz and dx0 BIT-IDENTICAL to those two calls (dz and dx0 are computed from G as it is stored, after its one

@@ -150,10 +150,11 @@ class Dx0Relay:
     def __init__(self, x0: torch.Tensor):
         self.x0, self.buf, self.task = x0, None, -1
         # lower: what the consumer of y needs to run THIS layer's elementwise backward inside its own data-gradient
-        #   product (krs_gemm_cross_bwd): (u, act, diag_scale, has_bias, x_is_x0, x0 in the compute dtype), left by
-        #   this layer's forward;
-        # fused: (G, version of G, dz, dbias) left by that consumer's backward when it did so -- `buf` then already
-        #   holds this layer's term of dL/dx0 as well.
+        #   product (krs_gemm_cross_bwd): (u, act, diag_scale, has_bias, x_is_x0, x0 in the compute dtype, (relay of the
+        #   layer that produced this layer's x | None, dtype of that x)), left by this layer's forward;
+        # fused: (G, version of G, dz, dbias, task, deferred) left by that consumer's backward when it did so -- `buf` then
+        #   already holds this layer's term of dL/dx0 as well, unless `deferred`: then this layer's own data-gradient
+        #   product computes it (u_upper) and no matrix exists yet.
         self.lower, self.fused = None, None
 
     def matches(self, x0: torch.Tensor) -> bool:
@@ -211,18 +212,18 @@ def _dx_product(ctx, dh, dc, direct, dx0, x0c, task, u_own=None):
     direct * u_own starts the matrix inside the fused epilogue."""
     up = ctx.relay_up
     if dx0 is None:
-        u_low, act_low, _, bias_low, same_low, _ = up.lower
+        u_low, act_low, _, bias_low, same_low = up.lower[:5]
         dx, dz_low, dx0, db_low = D.gemm_cross_bwd(dh, dc, direct, x0c, u_low, act=act_low, want_dbias=bias_low,
                                                    fold_direct=same_low, u_upper=u_own)
-        up.fused = (dx, dx._version, dz_low, db_low, task)
+        up.fused = (dx, dx._version, dz_low, db_low, task, False)
         return dx, dx0
     if not _fusable_below(up, dh, ctx.meta[6], task) or not dx0.is_contiguous() or dx0.dtype != dh.dtype:
         dx, _ = D.gemm(dh, dc, b_is_nk=True, r=direct, beta=1.0)
         return dx, dx0
-    u_low, act_low, _, bias_low, same_low, _ = up.lower
+    u_low, act_low, _, bias_low, same_low = up.lower[:5]
     dx, dz_low, dx0, db_low = D.gemm_cross_bwd(dh, dc, direct, x0c, u_low, act=act_low, dx0_into=dx0,
                                                want_dbias=bias_low, fold_direct=same_low)
-    up.fused = (dx, dx._version, dz_low, db_low, task)
+    up.fused = (dx, dx._version, dz_low, db_low, task, False)
     return dx, dx0
 
 
@@ -258,8 +259,10 @@ class CrossLayerFn(torch.autograd.Function):
         ctx.meta = (diag_scale, act, same, down is not None, bias is not None,
                     x0.dtype, x.dtype, None if down is None else down.dtype, kernel.dtype)
         ctx.relay_in = relay_in
+        both = ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        ctx.relay_up = relay_up if (relay_up is not None and not same and both and relay_up.matches(x0)) else None
         if relay_in is not None and FUSE_CROSS_BWD and down is not None:
-            relay_in.lower = (u, act, float(diag_scale or 0.0), bias is not None, same, x0c)
+            relay_in.lower = (u, act, float(diag_scale or 0.0), bias is not None, same, x0c, (ctx.relay_up, x.dtype))
         ctx.w_refs = tuple(weakref.ref(w) for w in (down, kernel) if w is not None)
         # pending uses of each weight (a weight shared by two layer calls gets two gradient contributions)
         ctx.counted = any(ctx.needs_input_grad[i] for i in (2, 3))
@@ -267,8 +270,6 @@ class CrossLayerFn(torch.autograd.Function):
             for w in (down, kernel):
                 if w is not None:
                     w._krs_pending_cross = getattr(w, "_krs_pending_cross", 0) + 1
-        both = ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-        ctx.relay_up = relay_up if (relay_up is not None and not same and both and relay_up.matches(x0)) else None
         return y
 
     @staticmethod
@@ -291,10 +292,21 @@ class CrossLayerFn(torch.autograd.Function):
                 else:
                     extra = rin.buf
             rin.buf = None
-        if fused is not None and (incoming is None or fused[4] != task):
+        if fused is not None and fused[5]:
+            # deferred: the consumer (a Dense layer) ran this layer's elementwise backward but left its term of dL/dx0 to
+            # THIS layer's data-gradient product (u_upper).  Anything that is not the plain case -- another consumer's
+            # buffer, a summed gradient, the layer below no longer fusable -- redoes this layer from g in the branches below.
+            if not (incoming is None and extra is None and fused[4] == task and g.data_ptr() == fused[0].data_ptr()
+                    and g.shape == fused[0].shape and g._version == fused[1]
+                    and _fusable_below(ctx.relay_up, g, x_dt, task)):
+                fused = None
+        elif fused is not None and (incoming is None or fused[4] != task):
             fused = None
         defer_dx0 = False
-        if fused is not None:
+        if fused is not None and fused[5]:
+            dz, dbias = fused[2], fused[3]
+            dx0, dxd, defer_dx0 = None, None, True
+        elif fused is not None:
             # The consumer of y ran this layer's elementwise backward inside its data-gradient product
             # (krs_gemm_cross_bwd): `incoming` already holds this layer's term, dz and dbias are done.  That is only
             # right when its G is ALL of dL/dy -- the very tensor autograd hands over, untouched.  If y had another
@@ -432,11 +444,15 @@ class DenseFn(torch.autograd.Function):
             if _fusable_below(up, dz, x_dt, task):
                 # x is the output of a cross layer: dx = dz K^T is its dL/dy, and its elementwise backward (dz, its
                 # term of dL/dx0, bias gradient) rides in the epilogue of this product
-                u_low, act_low, _, bias_low, same_low, x0c = up.lower
+                u_low, act_low, _, bias_low, same_low, x0c, (below, x_dt_low) = up.lower
+                # (that layer's own term of dL/dx0 waits for ITS data-gradient product when that one is going to be a fused
+                #  launch as well: u_upper there, one [B, d] matrix less written here and read there)
+                defer = FUSE_TOP_DX0 and not same_low and _fusable_below(below, dz, x_dt_low, task)
                 dx, dz_low, dx0, db_low = D.gemm_cross_bwd(dz, kc, None, x0c, u_low, act=act_low, want_dbias=bias_low,
-                                                           fold_direct=same_low)
-                up.buf, up.task = dx0, task
-                up.fused = (dx, dx._version, dz_low, db_low, task)
+                                                           fold_direct=same_low, want_dx0=not defer)
+                if not defer:
+                    up.buf, up.task = dx0, task
+                up.fused = (dx, dx._version, dz_low, db_low, task, defer)
             else:
                 dx, _ = D.gemm(dz, kc, b_is_nk=True)                               # [B, in]
                 dx = dx.to(x_dt)

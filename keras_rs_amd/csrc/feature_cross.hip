@@ -985,7 +985,8 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // a run-time branch makes hipcc drain the load queue).
 // DX0: where the running dL/dx0 comes from -- 0: nothing yet, 1: the dx0 buffer (terms of the layers above), 2: R * u_upper,
 // the term of the layer ABOVE computed here from its dL/dy (= R, already loaded) and its saved u, so that the top layer of a
-// stack neither writes nor this launch reads a [M, N] matrix for it (that one sum is rounded once instead of twice).
+// stack neither writes nor this launch reads a [M, N] matrix for it (that one sum is rounded once instead of twice);
+// 3: no dL/dx0 at all from this launch (the caller hands u to the NEXT launch as its u_upper: a Dense layer above a stack).
 template <int DX0, bool HAS_R>
 __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
                                                                int64_t wm0, int64_t wn0, int64_t group) {
@@ -1011,7 +1012,7 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
       else er[it] = ex0[it];
       if constexpr (DX0 == 1) ed[it] = load8_bf16_nt(p.f_dx0, gmc * p.f_ld + gnc);
       else if constexpr (DX0 == 2) ed[it] = load8_bf16_nt(p.f_uup, gmc * p.f_ld + gnc);
-      else ed[it] = ex0[it];
+      else ed[it] = ex0[it];   // (0, 3: unused)
     }
     f32x16(&acc2)[2] = acc[c >> 1][c & 1];
 #pragma unroll
@@ -1056,7 +1057,7 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
       }
       store8_bf16_nt(p.f_dz, gm * p.f_ld + gn, dz);   // (nt like the other streams: 657-660 us against 664-667 with a plain store;
                                                        //  the dh / dK products that read dz next measure the same either way)
-      store8_bf16_nt(p.f_dx0, gm * p.f_ld + gn, tv);
+      if constexpr (DX0 != 3) store8_bf16_nt(p.f_dx0, gm * p.f_ld + gn, tv);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
@@ -1605,8 +1606,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
   }
   lds_dma_retired<NPF>();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  if constexpr (EPI >= 3) {   // 3: + R, 4: + R, dx0 accumulates, 5: no R, 6: no R, dx0 accumulates, 7: + R, dx0 = R u_upper + ...
-    gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : 0), EPI == 3 || EPI == 4 || EPI == 7>(
+  if constexpr (EPI >= 3) {   // 3: + R, 4: + R, dx0 accumulates, 5: no R, 6: no R, dx0 accumulates, 7: + R, dx0 = R u_upper + ...,
+                              // 8: no R, no dx0
+    gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : (EPI == 8 ? 3 : 0)), EPI == 3 || EPI == 4 || EPI == 7>(
         p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
     return;
   }
@@ -2582,8 +2584,10 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
                                   void* dx0, int64_t ld, int dx0_accumulate, const void* u_upper, int fold_direct,
                                   float* dbias, int64_t m, int64_t n, int64_t k, int act, int dtype, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-  KRS_REQUIRE(a && bt && g_out && x0 && u && dz && dx0, "krs_gemm_cross_bwd: null operand");
+  KRS_REQUIRE(a && bt && g_out && x0 && u && dz, "krs_gemm_cross_bwd: null operand");
   if (!r) { ldr = n; beta = 0.0f; }
+  KRS_REQUIRE(dx0 || (!r && !dx0_accumulate && !u_upper && !fold_direct),
+              "krs_gemm_cross_bwd: dx0 = NULL (the term is left to the next launch's u_upper) is the form without R");
   KRS_REQUIRE(!u_upper || (r && !dx0_accumulate && beta == 1.0f),
               "krs_gemm_cross_bwd: u_upper (dx0 = R * u_upper + ...) needs R with beta = 1 and no dx0 to accumulate into");
   KRS_REQUIRE(dtype == KRS_BF16 || dtype == KRS_F32, "krs_gemm_cross_bwd: bad dtype");
@@ -2596,7 +2600,7 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
   const bool fused = dtype == KRS_BF16 && gemm_pipe() != 0 && m >= 256 && n >= 256 && k >= 256 && k % 64 == 0 &&
                      ceil_div(m, 256) * ceil_div(n, 256) >= 192 && n % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
                      ldr % 8 == 0 && ldg % 8 == 0 && ld % 8 == 0 && al16(a) && al16(bt) && (!r || al16(r)) && al16(g_out) &&
-                     al16(x0) && al16(u) && al16(dz) && al16(dx0) && (!u_upper || al16(u_upper));
+                     al16(x0) && al16(u) && al16(dz) && (!dx0 || al16(dx0)) && (!u_upper || al16(u_upper));
   if (!fused) {
     // any other shape / dtype: the two calls this entry stands for
     krs_gemm_epilogue ep;
@@ -2642,7 +2646,8 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
     if (dx0_accumulate) KRS_CB_LAUNCH(4)
     else KRS_CB_LAUNCH(3)
   } else {
-    if (dx0_accumulate) KRS_CB_LAUNCH(6)
+    if (!dx0) KRS_CB_LAUNCH(8)
+    else if (dx0_accumulate) KRS_CB_LAUNCH(6)
     else KRS_CB_LAUNCH(5)
   }
 #undef KRS_CB_LAUNCH

@@ -137,12 +137,14 @@ def cross_epilogue_bwd(g, u, x0, x, diag_scale=0.0, *, act: int = L.ACT_NONE,
 
 def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch.Tensor, u: torch.Tensor, *,
                    act: int = L.ACT_NONE, dx0_into: torch.Tensor | None = None, want_dbias: bool = True,
-                   fold_direct: bool = False, beta: float = 1.0, u_upper: torch.Tensor | None = None):
+                   fold_direct: bool = False, beta: float = 1.0, u_upper: torch.Tensor | None = None,
+                   want_dx0: bool = True):
     """krs_gemm_cross_bwd: G = A @ Bt^T + beta * R (the data gradient of a cross layer = dL/dy of the layer below it)
     and, from G as stored, the elementwise backward of that layer below -- dz = G x0 act'(u), dx0 = [dx0_into +] G u,
     dbias = column sums of dz -- in ONE launch (fold_direct: the layer below is fed x0 itself, its direct term G joins
     dx0; u_upper: the saved activation output of the layer ABOVE, whose own term R * u_upper then starts dx0 here instead
-    of in a matrix that layer would have written).  Returns (G, dz, dx0, dbias).  a: [M, K], bt: [N, K] (K-contiguous
+    of in a matrix that layer would have written; want_dx0=False, without R only: no dL/dx0 from this launch -- `u` is
+    handed to the next one as ITS u_upper).  Returns (G, dz, dx0, dbias).  a: [M, K], bt: [N, K] (K-contiguous
     weight), r / x0 / u: [M, N] row-major of a's dtype."""
     a, bt = _rowmajor(a, "gemm_cross_bwd A"), _rowmajor(bt, "gemm_cross_bwd Bt")
     x0, u = (_rowmajor(t, "gemm_cross_bwd operand").contiguous() for t in (x0, u))
@@ -155,8 +157,10 @@ def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch
         raise L.KrsError("gemm_cross_bwd: one dtype for every operand")
     g = torch.empty((m, n), dtype=a.dtype, device=a.device)
     dz = torch.empty_like(g)
-    dx0 = dx0_into if dx0_into is not None else torch.empty_like(g)
-    if not dx0.is_contiguous() or dx0.dtype != a.dtype or tuple(dx0.shape) != (m, n):
+    if not want_dx0 and (r is not None or dx0_into is not None or u_upper is not None or fold_direct):
+        raise L.KrsError("gemm_cross_bwd: want_dx0=False is the form without R, dx0_into, u_upper and fold_direct")
+    dx0 = None if not want_dx0 else (dx0_into if dx0_into is not None else torch.empty_like(g))
+    if dx0 is not None and (not dx0.is_contiguous() or dx0.dtype != a.dtype or tuple(dx0.shape) != (m, n)):
         raise L.KrsError("gemm_cross_bwd: dx0 buffer must be a contiguous [M, N] matrix of the operands' dtype")
     if u_upper is not None:
         u_upper = _rowmajor(u_upper, "gemm_cross_bwd u_upper").contiguous()

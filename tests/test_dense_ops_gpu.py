@@ -473,3 +473,11 @@ def test_fused_data_gradient_and_cross_backward_equals_the_two_calls(acc, fold, 
             #  inside the entry, whose intermediate rounding doubles that)
             scale = float((R.float() * u_up.float()).abs().max() + (G.float() * u.float()).abs().max())
             torch.testing.assert_close(dx03.float(), ref, rtol=2.0 ** -7, atol=2.0 ** -7 * scale)
+            if not fold:
+                # the form without a residual (a Dense layer above the stack) and without dL/dx0 (left to the next launch's
+                # u_upper): G and dz are those of the same call with dx0
+                G4, dz4, dx04, db4 = D.gemm_cross_bwd(A, Bt, None, x0, u, act=a_id)
+                G5, dz5, none5, db5 = D.gemm_cross_bwd(A, Bt, None, x0, u, act=a_id, want_dx0=False)
+                assert none5 is None and torch.equal(G5, G4) and torch.equal(dz5, dz4) and torch.equal(db5, db4)
+                with pytest.raises(L.KrsError):
+                    D.gemm_cross_bwd(A, Bt, R, x0, u, act=a_id, want_dx0=False)
