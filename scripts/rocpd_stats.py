@@ -17,6 +17,6 @@ print("|---|---|---|---|---|---|---|")
 for n, c, s, a, mn, mx in rows[:top]:
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     n = re.sub(r"\(.*", "", n)
-    n = n if len(n) < 90 else n[:87] + "..."
+    n = n if (len(n) < 90 or __import__("os").environ.get("KRS_STATS_FULL_NAMES")) else n[:87] + "..."
     print(f"| {n} | {c} | {s/1e6:.3f} | {a/1e3:.1f} | {mn/1e3:.1f} | {mx/1e3:.1f} | {100*s/total:.1f} |")
 print(f"\ntotal kernel time {total/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
