@@ -1063,6 +1063,9 @@ __device__ __forceinline__ RawRow<N * (int)sizeof(TT) / 4> f32_to_raw(const floa
   return o;
 }
 
+#ifndef KRS_K2_EXP
+#define KRS_K2_EXP 0
+#endif
 constexpr int kFastFirst = 2;   // gradient rows requested with the row itself
 constexpr int kFastMore = 4;    // ... and per trip of the remainder loop
 
@@ -1141,7 +1144,13 @@ __global__ __launch_bounds__(256) void bag_apply_fast_kernel(const ApplyParams p
   auto grad_src = [&](uint32_t bag) {
     const uint32_t f = bag / batch;
     const uint32_t b = bag - f * batch;
+#if KRS_K2_EXP == 1   // timing-only development builds (scripts/exp/k2_gather_exp.py): every gather reads sample 0 (cache hits)
+    return grad + ((int64_t)s_fcol[f]) * (int64_t)sizeof(GT) + 0 * b;
+#elif KRS_K2_EXP == 2 // ... or a feature-major slab [feature][sample][dim]: a table's gradient slice is contiguous
+    return grad + (((int64_t)f * batch + b) * p.dim) * (int64_t)sizeof(GT);
+#else
     return grad + ((int64_t)b * p.grad_ld + s_fcol[f]) * (int64_t)sizeof(GT);
+#endif
   };
   auto coef_of = [&](uint64_t v) {
     float c = 1.0f;
