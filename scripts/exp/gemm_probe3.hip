@@ -167,6 +167,134 @@ __global__ __launch_bounds__(WAVES * 64) void kv(const char* __restrict__ a, con
   if (s == 12345.678f) c[threadIdx.x] = s + smem[tid];
 }
 
+// ---- hand-pipelined form: 8 waves, 64-k blocks (128-byte rows), 32x32x16 MFMA --------------------------------------------
+// Per 16-k step a wave issues, in this order: the fragment reads of the NEXT step (second register set), a quarter of the
+// operand stream's work (steps 0 / 1: ds_write the A / B chunks of block j+1, whose loads were issued one block ago;
+// steps 2 / 3: global loads of block j+2), then the 8 MFMAs of THIS step -- so the LDS latency and the stream's issue slots
+// sit under MFMA time of the same wave.  One barrier per block, before the last step's MFMAs: behind it everybody's
+// ds_writes of block j+1 are visible (first fragment read of the next block) and nobody reads stage j & 1 any more.
+// SPLIT: 1 = waves 4-7 run the stream quarters in the opposite step order (their LDS writes fall where waves 0-3 load)
+template <int SPLIT>
+__global__ __launch_bounds__(512) void kp(const char* __restrict__ a, const char* __restrict__ b, float* c,
+                                          int64_t m, int64_t n, int64_t kk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BKB = 128, NT = 512, CPR = 8, NI = 4, RPI = NT / CPR, PIECE = 256 * BKB, STG = 2 * PIECE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int64_t nt = n / 256;
+  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int64_t m0 = ((slot / nt) * 8 + xcd) * 256, n0 = (slot % nt) * 256;
+  const int ntiles = (int)(kk * 2 / BKB);
+  const char* ab = a + m0 * kk * 2;
+  const char* bb = b + n0 * kk * 2;
+  const uint32_t ldb2 = (uint32_t)(kk * 2);
+  const uint32_t vo = (uint32_t)(tid / CPR) * ldb2 + (uint32_t)(tid % CPR) * 16;
+  const int lo0 = (tid / CPR) * BKB + (((tid % CPR) ^ swz<BKB>(tid / CPR)) << 4);
+  u32x4 ra[NI], rb[NI];
+  auto gload_a = [&](int t) {
+    const uint32_t off = (uint32_t)(t < ntiles ? t : ntiles - 1) * BKB;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ab + ((size_t)(i * RPI) * ldb2 + off) + vo);
+  };
+  auto gload_b = [&](int t) {
+    const uint32_t off = (uint32_t)(t < ntiles ? t : ntiles - 1) * BKB;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) rb[i] = *reinterpret_cast<const u32x4*>(bb + ((size_t)(i * RPI) * ldb2 + off) + vo);
+  };
+  auto lstore_a = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(smem + stage * STG + lo0 + i * RPI * BKB) = ra[i];
+  };
+  auto lstore_b = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(smem + stage * STG + PIECE + lo0 + i * RPI * BKB) = rb[i];
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int frow = lane & 31, fhalf = lane >> 5, key = swz<BKB>(frow);
+  const int a_row = (wm * 128 + frow) * BKB, b_row = PIECE + (wn * 64 + frow) * BKB;
+  u32x4 fa[2][4], fb[2][2];
+  auto rd = [&](int stage, int ks, int buf) {
+    const char* st = smem + stage * STG;
+    const int cho = ((ks * 2 + fhalf) ^ key) << 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[buf][j] = *reinterpret_cast<const u32x4*>(st + b_row + j * 32 * BKB + cho);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[buf][i] = *reinterpret_cast<const u32x4*>(st + a_row + i * 32 * BKB + cho);
+  };
+  auto mm = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][i]),
+                                                            __builtin_bit_cast(bf16x8, fb[buf][j]), acc[i][j], 0, 0, 0);
+  };
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  // prologue: block 0 in LDS, block 1 in flight, first fragments read
+  gload_a(0); gload_b(0);
+  lstore_a(0); lstore_b(0);
+  gload_a(1); gload_b(1);
+  __syncthreads();
+  rd(0, 0, 0);
+  const bool flip = SPLIT == 1 && wave >= 4;
+  for (int j = 0; j < ntiles; ++j) {
+    const int cur = j & 1, nxt = cur ^ 1;
+    SB(); rd(cur, 1, 1); SB();
+    if (!flip) {
+      lstore_a(nxt); SB(); mm(0); SB();
+      rd(cur, 2, 0); SB(); lstore_b(nxt); SB(); mm(1); SB();
+      rd(cur, 3, 1); SB(); gload_a(j + 2); SB(); mm(0); SB();
+      gload_b(j + 2); SB();
+    } else {
+      lstore_b(nxt); SB(); mm(0); SB();
+      rd(cur, 2, 0); SB(); lstore_a(nxt); SB(); mm(1); SB();
+      rd(cur, 3, 1); SB(); gload_b(j + 2); SB(); mm(0); SB();
+      gload_a(j + 2); SB();
+    }
+    __syncthreads();
+    SB(); rd(nxt, 0, 0); SB();
+    mm(1); SB();
+  }
+#undef SB
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) s += (float)(ra[i][0] ^ rb[i][3]);
+  s += (float)(fa[0][0][0] ^ fb[0][1][2]);
+  if (s == 12345.678f) c[threadIdx.x] = s + smem[tid];
+}
+
+template <int SPLIT>
+void runp(const char* name, const char* a, const char* b, float* c, int64_t m, int64_t n, int64_t kk) {
+  const size_t lds = 2 * 2 * 256 * 128;
+  auto kern = kp<SPLIT>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const unsigned grid = (unsigned)((m / 256) * (n / 256));
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, a, b, c, m, n, kk);
+  hipEventRecord(e0);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, a, b, c, m, n, kk);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  printf("%-64s %8.1f us  %7.1f TF/s  (%s)\n", name, ms * 100, 2.0 * m * n * kk / (ms * 1e-4) / 1e12,
+         hipGetErrorString(hipGetLastError()));
+}
+
 template <int MODE, int WAVES, int BKB, int D, int MI, int VAR = 0>
 void run(const char* name, const char* a, const char* b, float* c, int64_t m, int64_t n, int64_t kk) {
   const size_t lds = 2 * 2 * 256 * BKB;
@@ -206,6 +334,9 @@ int main() {
 #define R(MODE, W, BKB, D, MI, NAME) run<MODE, W, BKB, D, MI>(NAME, a, b, c, m, n, kk)
 #define RV(MODE, W, BKB, D, MI, VAR, NAME) run<MODE, W, BKB, D, MI, VAR>(NAME, a, b, c, m, n, kk)
   for (int rep = 0; rep < 2; ++rep) {
+    printf("-- hand-pipelined (8 waves, 64-k blocks, 32x32x16)\n");
+    runp<0>("pipelined: next step's fragment reads + a stream quarter, then 8 MFMAs", a, b, c, m, n, kk);
+    runp<1>("pipelined, waves 4-7 with the stream quarters in the other order", a, b, c, m, n, kk);
     printf("-- operand stream alone (global -> VGPR -> LDS)\n");
     R(1, 8, 64, 2, 32, "stream  8 waves  32-k blocks  2 in flight");
     R(1, 8, 128, 2, 32, "stream  8 waves  64-k blocks  2 in flight");
