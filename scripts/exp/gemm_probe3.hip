@@ -174,13 +174,14 @@ __global__ __launch_bounds__(WAVES * 64) void kv(const char* __restrict__ a, con
 // sit under MFMA time of the same wave.  One barrier per block, before the last step's MFMAs: behind it everybody's
 // ds_writes of block j+1 are visible (first fragment read of the next block) and nobody reads stage j & 1 any more.
 // SPLIT: 1 = waves 4-7 run the stream quarters in the opposite step order (their LDS writes fall where waves 0-3 load)
-template <int SPLIT>
-__global__ __launch_bounds__(512) void kp(const char* __restrict__ a, const char* __restrict__ b, float* c,
+template <int SPLIT, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64) void kp(const char* __restrict__ a, const char* __restrict__ b, float* c,
                                           int64_t m, int64_t n, int64_t kk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BKB = 128, NT = 512, CPR = 8, NI = 4, RPI = NT / CPR, PIECE = 256 * BKB, STG = 2 * PIECE;
+  constexpr int BKB = 128, NT = WAVES * 64, CPR = 8, NI = 256 * CPR / NT, RPI = NT / CPR, PIECE = 256 * BKB, STG = 2 * PIECE;
+  constexpr int FB = WAVES == 8 ? 2 : 4;   // 32-column B fragments per wave: 128x64 | 128x128 per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = WAVES == 8 ? wave >> 2 : wave >> 1, wn = WAVES == 8 ? wave & 3 : wave & 1;
   const int64_t nt = n / 256;
   const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int64_t m0 = ((slot / nt) * 8 + xcd) * 256, n0 = (slot % nt) * 256;
@@ -209,21 +210,21 @@ __global__ __launch_bounds__(512) void kp(const char* __restrict__ a, const char
 #pragma unroll
     for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(smem + stage * STG + PIECE + lo0 + i * RPI * BKB) = rb[i];
   };
-  f32x16 acc[4][2];
+  f32x16 acc[4][FB];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   const int frow = lane & 31, fhalf = lane >> 5, key = swz<BKB>(frow);
-  const int a_row = (wm * 128 + frow) * BKB, b_row = PIECE + (wn * 64 + frow) * BKB;
-  u32x4 fa[2][4], fb[2][2];
+  const int a_row = (wm * 128 + frow) * BKB, b_row = PIECE + (wn * (FB * 32) + frow) * BKB;
+  u32x4 fa[2][4], fb[2][FB];
   auto rd = [&](int stage, int ks, int buf) {
     const char* st = smem + stage * STG;
     const int cho = ((ks * 2 + fhalf) ^ key) << 4;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[buf][j] = *reinterpret_cast<const u32x4*>(st + b_row + j * 32 * BKB + cho);
+    for (int j = 0; j < FB; ++j) fb[buf][j] = *reinterpret_cast<const u32x4*>(st + b_row + j * 32 * BKB + cho);
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[buf][i] = *reinterpret_cast<const u32x4*>(st + a_row + i * 32 * BKB + cho);
   };
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512) void kp(const char* __restrict__ a, const char
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < FB; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[buf][i]),
                                                             __builtin_bit_cast(bf16x8, fb[buf][j]), acc[i][j], 0, 0, 0);
   };
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(512) void kp(const char* __restrict__ a, const char
   gload_a(1); gload_b(1);
   __syncthreads();
   rd(0, 0, 0);
-  const bool flip = SPLIT == 1 && wave >= 4;
+  const bool flip = SPLIT == 1 && wave >= WAVES / 2;
   for (int j = 0; j < ntiles; ++j) {
     const int cur = j & 1, nxt = cur ^ 1;
     SB(); rd(cur, 1, 1); SB();
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(512) void kp(const char* __restrict__ a, const char
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < FB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += acc[i][j][r];
 #pragma unroll
@@ -275,18 +276,18 @@ __global__ __launch_bounds__(512) void kp(const char* __restrict__ a, const char
   if (s == 12345.678f) c[threadIdx.x] = s + smem[tid];
 }
 
-template <int SPLIT>
+template <int SPLIT, int WAVES = 8>
 void runp(const char* name, const char* a, const char* b, float* c, int64_t m, int64_t n, int64_t kk) {
   const size_t lds = 2 * 2 * 256 * 128;
-  auto kern = kp<SPLIT>;
+  auto kern = kp<SPLIT, WAVES>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const unsigned grid = (unsigned)((m / 256) * (n / 256));
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, a, b, c, m, n, kk);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, 0, a, b, c, m, n, kk);
   hipEventRecord(e0);
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, 0, a, b, c, m, n, kk);
+  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, 0, a, b, c, m, n, kk);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -337,23 +338,9 @@ int main() {
     printf("-- hand-pipelined (8 waves, 64-k blocks, 32x32x16)\n");
     runp<0>("pipelined: next step's fragment reads + a stream quarter, then 8 MFMAs", a, b, c, m, n, kk);
     runp<1>("pipelined, waves 4-7 with the stream quarters in the other order", a, b, c, m, n, kk);
-    printf("-- operand stream alone (global -> VGPR -> LDS)\n");
-    R(1, 8, 64, 2, 32, "stream  8 waves  32-k blocks  2 in flight");
-    R(1, 8, 128, 2, 32, "stream  8 waves  64-k blocks  2 in flight");
-    R(1, 8, 128, 1, 32, "stream  8 waves  64-k blocks  1 in flight");
-    printf("-- full loop, 8 waves\n");
-    R(0, 8, 64, 2, 32, "full  32-k blocks  2 in flight  32x32x16");
-    R(0, 8, 64, 1, 32, "full  32-k blocks  1 in flight  32x32x16");
-    R(0, 8, 64, 2, 16, "full  32-k blocks  2 in flight  16x16x32");
-    R(0, 8, 64, 1, 16, "full  32-k blocks  1 in flight  16x16x32");
-    R(0, 8, 128, 1, 32, "full  64-k blocks  1 in flight  32x32x16");
-    R(0, 8, 128, 1, 16, "full  64-k blocks  1 in flight  16x16x32");
-    RV(0, 8, 128, 1, 16, 1, "full  64-k blocks  1 in flight  16x16x32  LDS writes between the halves");
-    RV(0, 8, 128, 1, 16, 2, "full  64-k blocks  1 in flight  16x16x32  LDS writes behind the MFMAs");
-    RV(0, 8, 128, 1, 16, 3, "full  64-k blocks  1 in flight  16x16x32  setprio around the MFMAs");
+    runp<0, 4>("pipelined, FOUR waves of 128x128", a, b, c, m, n, kk);
+    R(0, 8, 128, 1, 32, "full  64-k blocks  1 in flight  32x32x16  (compiler-scheduled reference)");
     RV(0, 8, 128, 1, 32, 1, "full  64-k blocks  1 in flight  32x32x16  LDS writes between the halves");
-    RV(0, 8, 128, 1, 32, 2, "full  64-k blocks  1 in flight  32x32x16  LDS writes behind the MFMAs");
-    RV(0, 8, 128, 2, 16, 2, "full  64-k blocks  2 in flight  16x16x32  LDS writes behind the MFMAs");
   }
   return 0;
 }
