@@ -1196,6 +1196,44 @@ def test_dense_layer_above_a_cross_stack_runs_the_top_layers_elementwise_backwar
         D.gemm_cross_bwd = real
 
 
+def test_dense_above_a_cross_stack_whose_top_output_has_a_second_consumer():
+    """The Dense layer's launch ran the top cross layer's elementwise backward and LEFT its term of dL/dx0 to that layer's
+    own product (deferred); when the top output has another consumer, the gradient autograd hands that layer is not the
+    Dense layer's G: the layer must notice (another tensor / a moved version) and redo its backward from the summed
+    gradient.  Same gradients as the unfused passes, to the rounding of the two ways of summing."""
+    from keras_rs_amd import autograd as A
+    from keras_rs_amd.layers import base as kl_base
+
+    kl = _layers()
+    g = torch.Generator(device=DEV).manual_seed(37)
+    B, d, p = 16384, 768, 256
+    x0 = (torch.randn(B, d, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+
+    def run(fuse):
+        old, A.FUSE_CROSS_BWD = A.FUSE_CROSS_BWD, fuse
+        try:
+            cross = [kl.FeatureCross(projection_dim=p, kernel_initializer=kl_base.GlorotUniform(seed=90 + i),
+                                     bias_initializer=kl_base.RandomUniform(-0.1, 0.1, seed=95 + i),
+                                     dtype="mixed_bfloat16") for i in range(2)]
+            mlp = kl.Dense(64, activation="relu", kernel_initializer=kl_base.GlorotUniform(seed=99), dtype="mixed_bfloat16")
+            x = x0.clone().requires_grad_()
+            xl = x
+            for layer in cross:
+                xl = layer(x, xl)
+            loss = mlp(xl).float().mean() + xl.float().pow(2).mean() * 0.5      # the second consumer of the top output
+            loss.backward()
+            torch.cuda.synchronize()
+            return [(f"{i}.{n}", q.grad.clone()) for i, layer in enumerate(cross + [mlp]) for n, q in layer.named_parameters()] \
+                + [("x", x.grad.clone())]
+        finally:
+            A.FUSE_CROSS_BWD = old
+
+    a, b = run(True), run(False)
+    for (name, u), (_, v) in zip(a, b):
+        scale = float(v.float().abs().max())
+        torch.testing.assert_close(u.float(), v.float(), rtol=2.0 ** -6, atol=2.0 ** -7 * scale, msg=lambda m: f"{name}: {m}")
+
+
 def test_training_step_leaves_no_cyclic_garbage_that_holds_device_tensors():
     """bench.py times its steps with the cyclic collector off: anything a step leaves in a reference cycle then stays
     allocated (round 4: a recursive closure of the output packing held the 453 MB lookup slab of every step, two fresh
