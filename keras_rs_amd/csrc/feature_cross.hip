@@ -64,7 +64,7 @@ struct GemmParams {
   // split-K
   int splits; int64_t k_per_split; float* slabs;
   int ep_vec;  // every epilogue operand allows 8-wide vector access
-  // fused cross-backward epilogue (EPI 3 / 4 of gemm_pp256_kernel, krs_gemm_cross_bwd): operands of the layer below
+  // fused cross-backward epilogue (EPI 3 .. 8 of gemm_pp256_kernel, krs_gemm_cross_bwd): operands of the layer below
   const void* f_x0; const void* f_u; const void* f_uup; void* f_dz; void* f_dx0; float* f_partial; int64_t f_ld; int f_act; int f_fold;
 };
 
