@@ -2195,7 +2195,10 @@ __global__ __launch_bounds__(256) void cross_bwd_vec_kernel(const CrossParams p,
   // two rows of g / x0 / u are kept in flight ahead of the row being processed (clamped row index:
   // the loads are unconditional)
   typedef typename RowVec<T, V>::raw_t raw_t;
-  constexpr int AHEAD = 2;
+#ifndef KRS_CB_AHEAD
+#define KRS_CB_AHEAD 2      // (development builds vary it: 3 and 4 measured equal, profiles/r4y_cross_bwd_ahead.txt)
+#endif
+  constexpr int AHEAD = KRS_CB_AHEAD;
   raw_t rg[AHEAD], rx0[AHEAD], ru[AHEAD], racc[AHEAD];
   const void* usrc = p.u ? p.u : p.g;  // without u the value is ignored below
   // the running dL/dx0 of the layers above is read ahead like the other streams (a template parameter, not a
