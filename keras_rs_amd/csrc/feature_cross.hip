@@ -987,6 +987,9 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // the term of the layer ABOVE computed here from its dL/dy (= R, already loaded) and its saved u, so that the top layer of a
 // stack neither writes nor this launch reads a [M, N] matrix for it (that one sum is rounded once instead of twice);
 // 3: no dL/dx0 at all from this launch (the caller hands u to the NEXT launch as its u_upper: a Dense layer above a stack).
+#ifndef KRS_CBW_PF
+#define KRS_CBW_PF 0
+#endif
 template <int DX0, bool HAS_R>
 __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
                                                                int64_t wm0, int64_t wn0, int64_t group) {
@@ -999,27 +1002,46 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
   float db[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) db[q] = 0.0f;
+  // operand vectors of a chunk, two sets: chunk c + 1's are requested while chunk c is processed -- x0 and u as soon as
+  // chunk c's accumulators are staged (their registers are free from then on), R and the dL/dx0 source too from the second
+  // chunk on (KRS_CBW_PF = 1: x0 / u only, 2: all; with 0 every stream of chunk c + 1 is requested behind chunk c's stores, the round-4 order)
+  uint4 vr2[2][4], vx02[2][4], vu2[2][4], vd2[2][4];
+  auto ld_x0u = [&](int c, int b) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t gmc = min(wm0 + c * 32 + it * 8 + (lane >> 3), p.m - 1);
+      vx02[b][it] = load8_bf16_nt(p.f_x0, gmc * p.f_ld + gnc);
+      vu2[b][it] = load8_bf16_nt(p.f_u, gmc * p.f_ld + gnc);
+    }
+  };
+  auto ld_rd = [&](int c, int b) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t gmc = min(wm0 + c * 32 + it * 8 + (lane >> 3), p.m - 1);
+      if constexpr (HAS_R) vr2[b][it] = load8_bf16_nt(p.ep.r, gmc * p.ep.ldr + gnc);
+      if constexpr (DX0 == 1) vd2[b][it] = load8_bf16_nt(p.f_dx0, gmc * p.f_ld + gnc);
+      else if constexpr (DX0 == 2) vd2[b][it] = load8_bf16_nt(p.f_uup, gmc * p.f_ld + gnc);
+    }
+  };
+  ld_x0u(0, 0);
+  ld_rd(0, 0);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int64_t row0 = wm0 + c * 32;
-    uint4 er[4], ex0[4], eu[4], ed[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int64_t gmc = min(row0 + it * 8 + (lane >> 3), p.m - 1);
-      ex0[it] = load8_bf16_nt(p.f_x0, gmc * p.f_ld + gnc);
-      eu[it] = load8_bf16_nt(p.f_u, gmc * p.f_ld + gnc);
-      if constexpr (HAS_R) er[it] = load8_bf16_nt(p.ep.r, gmc * p.ep.ldr + gnc);
-      else er[it] = ex0[it];
-      if constexpr (DX0 == 1) ed[it] = load8_bf16_nt(p.f_dx0, gmc * p.f_ld + gnc);
-      else if constexpr (DX0 == 2) ed[it] = load8_bf16_nt(p.f_uup, gmc * p.f_ld + gnc);
-      else ed[it] = ex0[it];   // (0, 3: unused)
-    }
+    uint4(&er)[4] = vr2[c & 1];
+    uint4(&ex0)[4] = vx02[c & 1];
+    uint4(&eu)[4] = vu2[c & 1];
+    uint4(&ed)[4] = vd2[c & 1];
     f32x16(&acc2)[2] = acc[c >> 1][c & 1];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc2[j][r];
+    if (KRS_CBW_PF && c < 3) {
+      ld_x0u(c + 1, (c + 1) & 1);
+      if (KRS_CBW_PF >= 2 && c >= 1) ld_rd(c + 1, (c + 1) & 1);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -1045,7 +1067,11 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
       unpack_bf16x8(gq, g);
       unpack_bf16x8(ex0[it], x0v);
       unpack_bf16x8(eu[it], uv);
-      unpack_bf16x8(ed[it], tv);
+      if constexpr (DX0 == 1 || DX0 == 2) unpack_bf16x8(ed[it], tv);
+      else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tv[q] = 0.0f;
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float gx0 = g[q] * x0v[q];
@@ -1060,6 +1086,10 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
       if constexpr (DX0 != 3) store8_bf16_nt(p.f_dx0, gm * p.f_ld + gn, tv);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (c < 3) {
+      if (!KRS_CBW_PF) ld_x0u(c + 1, (c + 1) & 1);
+      if (KRS_CBW_PF < 2 || c < 1) ld_rd(c + 1, (c + 1) & 1);
+    }
   }
   if (p.f_partial) {
     // column sums over the wave's 128 rows: the eight lanes with one (lane & 7) hold the same 8 columns
