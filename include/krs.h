@@ -234,10 +234,9 @@ int krs_embed_bag_bwd_fused_ftrl(const krs_table* tables, int n_tables,
 /* Sparse form: unique global rows and their summed gradients.
  *   unique_rows [nnz] int64 (first *n_unique valid), row_grads [nnz, dim] fp32,
  *   n_unique device int64.
- * Needs the plan of krs_embed_bag_bwd_plan (global sort).  A workspace last written by
- * krs_embed_bag_bwd_plan_tables is refused with KRS_ERR_UNSUPPORTED (the library remembers which call
- * planned into a workspace address; the workspace also carries the fact, so a plan that was moved to
- * another address yields *n_unique = -1 instead of a miscounted list). */
+ * Needs the plan of krs_embed_bag_bwd_plan (global sort).  A workspace holding the plan of
+ * krs_embed_bag_bwd_plan_tables yields *n_unique = -1 (unique_rows / row_grads are then meaningless; the
+ * workspace itself records which sort filled it, so the answer follows a plan copied to another address). */
 int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats,
                              const float* weights, const float* bag_scale,
                              const void* grad, int grad_dtype, int64_t grad_ld,
@@ -319,26 +318,24 @@ int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, int64_t ldb,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tuning / diagnostic switches of krs_gemm (process-wide; results never depend on them).
- *   KRS_GEMM_OPT_PIPELINE: main loop of the 256x256 bf16 tiles -- 0 = two-stage loop that drains the
- *   DMA queue once per K tile, 4 / 5 = ping-pong ring with that many 32-deep stages (default 4, or
- *   the environment variable KRS_GEMM_PIPE at first use); 6 = prefetch schedule, 7 = 4 plus the deep ring on the
- *   128x128 tile for small outputs (both measured no faster, kept for A/B). */
+ *   KRS_GEMM_OPT_PIPELINE: 4 = the big bf16 shapes run the four-stage ping-pong ring on 256x256 tiles (default, or
+ *   the environment variable KRS_GEMM_PIPE at first use); 0 = every shape runs the two-stage 128x128 kernels and
+ *   krs_gemm_cross_bwd its two-call form -- the reference schedule of the bit-for-bit tests and A/B harnesses.
+ *   (Rounds 2-4 also had 5 / 6 / 7: a five-stage ring, a prefetch schedule, a deep ring on 128x128 tiles; measured no
+ *   faster and deleted in round 5.) */
 enum { KRS_GEMM_OPT_PIPELINE = 0 };
 int krs_gemm_set_option(int key, int value);
 
 /* Tuning switches of krs_embed_bag_fwd / krs_embed_bag_bwd_* (process-wide; results never depend on them).
- *   KRS_EMBED_OPT_HOT1: the pure row gather of one-hot bags -- bit 0: 16 instead of 8 row loads in
- *   flight per lane; bit 1: walk the lookups sample-major, so that a wave's stores cover contiguous
- *   bytes of the output slab (default 3, or the environment variable KRS_EMBED_HOT1 at first use).
- *   KRS_EMBED_OPT_APPLY: the per-segment kernel of the backward -- 0 = bag_apply_fast_kernel (batched metadata,
- *   software-pipelined row / gradient loads; default), 1 = the round-1 kernel (kept for A/B).
  *   KRS_EMBED_OPT_PLAN: krs_embed_bag_bwd_plan_tables -- 0 = table-segmented sort where the layout allows it
  *   (default), 1 = always the global sort (A/B).
  *   KRS_EMBED_OPT_HOTROWS: LDS staging of hot embedding rows in the pooled gather -- 0 = off (default), 64 / 128 =
  *   rows 0 .. n-1 of a workgroup's table are copied to LDS and lookups of them are served from there (one flat
  *   16-byte load per lookup, routed to LDS or memory by its address); pays only when ids are relabelled
- *   hot-first and those rows are NOT already cache hits (profiles/r3_k1_hot_rows_lds.txt: they are). */
-enum { KRS_EMBED_OPT_HOT1 = 0, KRS_EMBED_OPT_APPLY = 1, KRS_EMBED_OPT_PLAN = 2, KRS_EMBED_OPT_HOTROWS = 3 };
+ *   hot-first and those rows are NOT already cache hits (profiles/r3_k1_hot_rows_lds.txt: they are).
+ *   (Keys 0 and 1 -- the one-hot gather variants and the round-1 per-segment backward kernel -- were retired in
+ *   round 5 with the kernels they selected; they are refused.) */
+enum { KRS_EMBED_OPT_PLAN = 2, KRS_EMBED_OPT_HOTROWS = 3 };
 int krs_embed_set_option(int key, int value);
 
 /* Elementwise halves of FeatureCross for the host-composed path (arbitrary

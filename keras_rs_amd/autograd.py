@@ -77,6 +77,29 @@ def _wgrad_side_ok(w) -> bool:
     return not hooks or bool(getattr(w, "_krs_hooks_rejoin_wgrad_stream", False))
 
 
+def _release_pending_cross(w_refs, counted) -> None:
+    """Gives back one pending use of each weight of a CrossLayerFn call, once: from its backward, or from the finalizer
+    of its graph node when the graph is dropped without a backward pass."""
+    if not counted[0]:
+        return
+    counted[0] = False
+    for r in w_refs:
+        w = r()
+        if w is not None:
+            w._krs_pending_cross = max(0, getattr(w, "_krs_pending_cross", 1) - 1)
+
+
+def _release_plan_ws(bags_ref, owns) -> None:
+    """The plan workspace kept on a FusedBags is free again (EmbedBagFusedFn: after its backward, or when the graph
+    that borrowed it is dropped without one -- otherwise every later step would allocate a fresh workspace)."""
+    if not owns[0]:
+        return
+    owns[0] = False
+    bags = bags_ref()
+    if bags is not None:
+        bags._plan_ws_busy = False
+
+
 def wgrad_stream_sync() -> None:
     """The current stream waits for the weight-gradient stream(s): before anything reads those gradients (the end of
     the backward pass does it by itself; dp.GradAllReduce calls it before it reduces a gradient)."""
@@ -265,11 +288,15 @@ class CrossLayerFn(torch.autograd.Function):
             relay_in.lower = (u, act, float(diag_scale or 0.0), bias is not None, same, x0c, (ctx.relay_up, x.dtype))
         ctx.w_refs = tuple(weakref.ref(w) for w in (down, kernel) if w is not None)
         # pending uses of each weight (a weight shared by two layer calls gets two gradient contributions)
-        ctx.counted = any(ctx.needs_input_grad[i] for i in (2, 3))
-        if ctx.counted:
+        # (the count is given back by the backward -- or, when no backward ever runs on this graph (a grad-enabled
+        #  validation pass, an exception, a discarded output), by the finalizer of the graph node: a count left above one
+        #  would keep the weight off the second stream for good, silently)
+        ctx.counted = [any(ctx.needs_input_grad[i] for i in (2, 3))]
+        if ctx.counted[0]:
             for w in (down, kernel):
                 if w is not None:
                     w._krs_pending_cross = getattr(w, "_krs_pending_cross", 0) + 1
+            weakref.finalize(ctx, _release_pending_cross, ctx.w_refs, ctx.counted)
         return y
 
     @staticmethod
@@ -355,12 +382,7 @@ class CrossLayerFn(torch.autograd.Function):
             shared = shared or (task != -1 and getattr(w, "_krs_shared_in_task", None) == task)
         side_ok = low_rank and WGRAD_SIDE_STREAM and dz.is_cuda and dz.shape[0] >= WGRAD_SIDE_MIN_ROWS and \
             not shared and all(_wgrad_side_ok(r()) for r in ctx.w_refs)
-        if ctx.counted:
-            ctx.counted = False
-            for r in ctx.w_refs:
-                w = r()
-                if w is not None:
-                    w._krs_pending_cross = max(0, getattr(w, "_krs_pending_cross", 1) - 1)
+        _release_pending_cross(ctx.w_refs, ctx.counted)
         if side_ok:
             # Data-gradient path first; the two weight gradients (off the critical path: only the optimizer reads them)
             # go to a second stream that starts when dx is done -- i.e. beside the HBM-bound kernel that follows on the
@@ -614,7 +636,8 @@ class EmbedBagFusedFn(torch.autograd.Function):
                 done.record(side)
             if not getattr(bags, "_plan_ws_busy", False):
                 bags._plan_ws, bags._plan_ws_busy = ws, True
-                ctx.owns_plan_ws = True
+                ctx.owns_plan_ws = [True]
+                weakref.finalize(ctx, _release_plan_ws, weakref.ref(bags), ctx.owns_plan_ws)
             for t in (ws, ids, offsets):
                 if t is not None:
                     t.record_stream(side)
@@ -647,7 +670,8 @@ class EmbedBagFusedFn(torch.autograd.Function):
         bags.backward_fused(kind, ws, g, ctx.batch, ids.numel(), hots=ctx.hots, weights=weights,
                             bag_scale=scale, hyper=hyper)
         if ctx.owns_plan_ws:
-            bags._plan_ws_busy = False     # (the next forward's plan is ordered behind this apply: it may take the buffer)
+            # (the next forward's plan is ordered behind this apply: it may take the buffer)
+            _release_plan_ws(weakref.ref(bags), ctx.owns_plan_ws)
         return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device), None, None)
 
 

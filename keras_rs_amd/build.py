@@ -36,8 +36,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        # (embed_bag_bwd.hip: ~1000 kernel instantiations -- three objects compiled side by side, see KRS_BWD_PART there)
-        parts = [(f"_p{i}", [f"-DKRS_BWD_PART={i}"]) for i in range(3)] if s == "embed_bag_bwd.hip" else [("", [])]
+        # (embed_bag_bwd.hip: ~590 kernel instantiations -- four objects compiled side by side, see KRS_BWD_PART there)
+        parts = [(f"_p{i}", [f"-DKRS_BWD_PART={i}"]) for i in range(4)] if s == "embed_bag_bwd.hip" else [("", [])]
         for suffix, defs in parts:
             obj = os.path.join(OBJ, s[:-4] + suffix + ".o")
             objs.append(obj)
@@ -52,6 +52,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         return r
 
+    for stale in set(os.path.join(OBJ, f) for f in os.listdir(OBJ) if f.endswith(".o")) - set(objs):
+        os.remove(stale)          # (objects of sources that no longer exist)
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _newer(LIB, objs):

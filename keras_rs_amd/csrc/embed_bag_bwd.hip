@@ -24,16 +24,15 @@
 // Algorithmic bytes: bags*D*s_g + nnz*(4+8) + U*(2*D*s_t [+ 2*D*4 per slot plane]).
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <unordered_map>
 
 #include "krs_common.h"
 #include "krs_scan.h"
 
-// The apply kernels are instantiated per (gradient type, table type, lanes per row, optimizer, weights, scale): ~1000
-// kernels, 160 s of hipcc in one translation unit.  keras_rs_amd/build.py compiles this file three times instead, in
-// parallel: KRS_BWD_PART 0 = the plan + the dense / sparse / SGD forms, 1 = Adagrad and row-wise Adagrad, 2 = Adam and
-// FTRL (entry points outside a part are left out of it).  Undefined = the whole file in one object.
+// The apply kernels are instantiated per (gradient type, table type, lanes per row, optimizer, weights, scale): 3 dtype
+// pairs x 4 widths x 7 kernels x 7 modes = ~590 kernels (round 4: ~1000 -- the round-1 per-segment kernel and the
+// fp32-gradient / bf16-table pair are gone).  keras_rs_amd/build.py compiles this file four times, in parallel:
+// KRS_BWD_PART 0 = the plan + the dense / sparse / SGD forms, 1 = Adagrad and row-wise Adagrad, 2 = Adam, 3 = FTRL
+// (entry points outside a part are left out of it).  Undefined = the whole file in one object.
 #ifndef KRS_BWD_PART
 #define KRS_BWD_PART -1
 #endif
@@ -41,12 +40,10 @@
 
 namespace krs {
 #if KRS_BWD_HAS(0)
-// krs_embed_set_option(KRS_EMBED_OPT_APPLY, v): 0 = bag_apply_fast_kernel (default), 1 = bag_apply_kernel (A/B, fallback)
-int g_apply_variant = 0;
 // krs_embed_set_option(KRS_EMBED_OPT_PLAN, v): 0 = table-segmented sort where the layout allows it (default), 1 = always the global sort
 int g_plan_variant = 0;
 #else
-extern int g_apply_variant, g_plan_variant;
+extern int g_plan_variant;
 #endif
 namespace {
 
@@ -818,8 +815,6 @@ __device__ __forceinline__ int find_table(const krs_table* tables, int n_tables,
   return lo;
 }
 
-constexpr int kApplyUnroll = 2;  // gradient rows in flight per group in the per-segment kernel: segments are short
-                                 // (1-2 lookups on average at C3), a wider unroll only issues clamped duplicates
 constexpr int kLongUnroll = 4;   // ... and per group in the hot-row kernel, whose chunks are long
 constexpr int kSegsPerGroup = 4;  // segments each group walks (amortises the descriptor prologue)
 constexpr int kMaxLdsDesc = 512;  // features / tables whose descriptors are cached in LDS
@@ -828,160 +823,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
 
-// GT: gradient element, TT: table element (fused modes), LPR lanes per row.
-//
-// One group of LPR lanes per SEGMENT (run of equal keys = one table row); the plan's segment
-// list makes the work dense: groups beyond the segment count leave at once.  A group first
-// issues the loads of the table row (and Adagrad accumulator row) it is going to update, so
-// they travel together with the gradient rows it then gathers four at a time; the loop has no
-// predicated loads (positions are clamped to the segment, contributions masked).  Feature /
-// table descriptors are cached in LDS per workgroup, so the dependent chain is
-// seg_start -> vals -> (LDS) -> gradient rows.  Consecutive segments are consecutive table
-// rows (the stream is sorted by row), so a workgroup's row updates are near-sequential in HBM.
-template <typename GT, typename TT, int LPR, int MODE, bool HAS_W>
-__global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
-  constexpr int N = Piece<GT>::N;
-  __shared__ int s_fcol[kMaxLdsDesc];
-  __shared__ int s_ftab[kMaxLdsDesc];
-  __shared__ krs_table s_tab[kMaxLdsDesc];
-  constexpr int GPB = 256 / LPR;         // groups per workgroup
-  const uint32_t n_seg = *p.n_seg;
-  const int64_t u_base = (int64_t)blockIdx.x * (GPB * kSegsPerGroup);
-  if (u_base >= n_seg) return;  // whole workgroup beyond the list
-  const bool lds_desc = p.n_feats <= kMaxLdsDesc && p.n_tables <= kMaxLdsDesc;
-  if (lds_desc) {
-    for (int f = threadIdx.x; f < p.n_feats; f += 256) {
-      s_fcol[f] = p.feats[f].out_col;
-      s_ftab[f] = p.feats[f].table;
-    }
-    if constexpr (MODE != kSparse)
-      for (int t = threadIdx.x; t < p.n_tables; t += 256) s_tab[t] = p.tables[t];
-  }
-  __syncthreads();
-
-  const int sub = threadIdx.x % LPR;
-  const int row_pieces = (int)(((int64_t)p.dim * sizeof(GT)) >> 4);
-  const bool col_live = sub < row_pieces;
-  const int csub = col_live ? sub : 0;
-  auto feat_col = [&](int f) { return lds_desc ? s_fcol[f] : p.feats[f].out_col; };
-  const char* grad = reinterpret_cast<const char*>(p.grad) + (int64_t)csub * 16;
-  const bool g_aligned = ((reinterpret_cast<uintptr_t>(p.grad) | (uintptr_t)(p.grad_ld * sizeof(GT))) & 15) == 0;
-
-  // the workgroup's segments are taken round-robin so that neighbouring groups update neighbouring rows
-#pragma unroll 1
-  for (int it = 0; it < kSegsPerGroup; ++it) {
-  const int64_t u = u_base + (int64_t)it * GPB + threadIdx.x / LPR;
-  if (u >= n_seg) return;
-  const int64_t s0 = p.seg_start[u];
-  const int64_t e0 = u + 1 < n_seg ? (int64_t)p.seg_start[u + 1] : p.nnz;
-  const uint32_t key = p.keys[s0];
-  if (key == kInvalidKey) continue;  // the trailing run of out-of-range lookups (always the last segment)
-  if (e0 - s0 > kLongSeg) continue;  // hot row: summed by a whole workgroup in bag_apply_long_kernel
-
-  // ---- the row this segment updates: issue its loads first ----
-  krs_table tb{};
-  int64_t off = 0;
-  if constexpr (MODE != kSparse) {
-    const uint64_t v0 = p.vals[s0];
-    const int f0 = (int)((uint32_t)(v0 >> 32) / (uint32_t)p.batch);
-    const int t = lds_desc ? s_ftab[f0] : p.feats[f0].table;
-    tb = lds_desc ? s_tab[t] : p.tables[t];
-    off = ((int64_t)key - tb.row_base) * p.dim + csub * N;
-  }
-  float wv[N], av[N], bv[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) { wv[k] = 0.0f; av[k] = 0.0f; bv[k] = 0.0f; }
-  // dim % N == 0, so a 16-byte aligned buffer keeps every lane's piece naturally aligned
-  const bool t_al = ((reinterpret_cast<uintptr_t>(tb.weights) |
-                      (MODE == kAdagradRow ? (uintptr_t)0 : reinterpret_cast<uintptr_t>(tb.slot))) & 15) == 0;
-  const int64_t plane = tb.vocab * p.dim;  // second slot plane (Adam v / FTRL linear)
-  if constexpr (mode_is_fused(MODE)) load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
-  if constexpr (mode_slots(MODE) >= 1) load_elems<float, N>(tb.slot + off, av, t_al);
-  if constexpr (mode_slots(MODE) == 2) load_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
-
-  // ---- gather and sum the segment's gradient rows, four at a time ----
-  float acc[N];
-#pragma unroll
-  for (int k = 0; k < N; ++k) acc[k] = 0.0f;
-  for (int64_t j0 = s0; j0 < e0; j0 += kApplyUnroll) {
-    uint64_t vv[kApplyUnroll];
-#pragma unroll
-    for (int q = 0; q < kApplyUnroll; ++q) vv[q] = p.vals[min(j0 + q, e0 - 1)];
-    float coef[kApplyUnroll];
-    u32x4 raw[kApplyUnroll];
-#pragma unroll
-    for (int q = 0; q < kApplyUnroll; ++q) {
-      const uint32_t bag = (uint32_t)(vv[q] >> 32);
-      const uint32_t pos = (uint32_t)vv[q];
-      const int f = (int)(bag / (uint32_t)p.batch);
-      const int b = (int)(bag - (uint32_t)f * (uint32_t)p.batch);
-      float c = 1.0f;
-      if constexpr (HAS_W) c = p.weights[pos];
-      if (p.bag_scale) c *= p.bag_scale[bag];
-      coef[q] = c;
-      const char* src = grad + ((int64_t)b * p.grad_ld + feat_col(f)) * (int64_t)sizeof(GT);
-      if (g_aligned) {
-        raw[q] = *(gvec_ptr)src;
-      } else {
-        const GT* e = reinterpret_cast<const GT*>(src);
-        if constexpr (sizeof(GT) == 4) {
-          raw[q] = u32x4{__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
-        } else {
-          raw[q] = u32x4{e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16),
-                         e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16)};
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < kApplyUnroll; ++q) {
-      if (j0 + q < e0) {
-        float gv[N];
-        Piece<GT>::unpack(make_uint4(raw[q].x, raw[q].y, raw[q].z, raw[q].w), gv);
-#pragma unroll
-        for (int k = 0; k < N; ++k) acc[k] = fmaf(coef[q], gv[k], acc[k]);
-      }
-    }
-  }
-  if constexpr (MODE == kAdagradRow) {
-    float ss = 0.0f;
-    if (col_live) {
-#pragma unroll
-      for (int k = 0; k < N; ++k) ss = fmaf(acc[k], acc[k], ss);
-    }
-    ss = row_sumsq<LPR>(ss);
-    const int64_t row = (int64_t)key - tb.row_base;
-    const float a_new = tb.slot[row] + ss / (float)p.dim;
-    if (col_live) {
-      const float inv = a_new > 0.0f ? tb.lr / sqrtf(a_new) : 0.0f;  // untouched accumulator + zero gradient: leave the row
-#pragma unroll
-      for (int k = 0; k < N; ++k) wv[k] = wv[k] - inv * acc[k];
-      store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
-      if (sub == 0) tb.slot[row] = a_new;
-    }
-    continue;
-  }
-  if (!col_live) continue;
-
-  // ---- write the finished row once ----
-  if constexpr (MODE == kSparse) {
-    if (sub == 0) p.unique_rows[u] = (int64_t)key;
-    float* dst = p.row_grads + (int64_t)u * p.dim + sub * N;
-#pragma unroll
-    for (int k = 0; k < N; ++k) dst[k] = acc[k];
-  } else if constexpr (MODE == kDense) {
-    store_elems<float, N>(reinterpret_cast<float*>(tb.weights) + off, acc, t_al);
-  } else {
-#pragma unroll
-    for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], acc[k], tb.lr, p.hyper);
-    if constexpr (mode_slots(MODE) >= 1) store_elems<float, N>(tb.slot + off, av, t_al);
-    if constexpr (mode_slots(MODE) == 2) store_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
-    store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
-  }
-  }  // segments of this group
-}
-
 // ---- the per-segment kernel, written for memory-level parallelism (round 3) ---------------------------------
-// bag_apply_kernel above is correct but compiles into a chain of dependent round trips: its run-time branches
+// GT: gradient element, TT: table element (fused modes), LPR lanes per row.  One group of LPR lanes per SEGMENT (run of
+// equal keys = one table row); the plan's segment list makes the work dense.  Feature / table descriptors are cached in
+// LDS per workgroup, so the dependent chain is seg_start -> vals -> (LDS) -> gradient rows; consecutive segments are
+// consecutive table rows (the stream is sorted by row), so a workgroup's row updates are near-sequential in HBM.
+// The round-1 kernel (`bag_apply_kernel`, deleted in round 5 after two rounds of A/B: 2336 -> 2305-2326 us Adagrad,
+// 1383 -> 1312 us SGD, profiles/r3z_k1_k2_multihot.txt; bit-identical) compiled into a chain of dependent round trips: its run-time branches
 // (aligned / unaligned access forms, optional weights and bag scales, descriptors in LDS or in memory) sit
 // AROUND loads, and hipcc closes every such branch with `s_waitcnt vmcnt(0)` -- the ISA of the C3 instance had a
 // full drain between the table-row load, each accumulator load and each gradient row: seven to eight serial
@@ -995,8 +843,9 @@ __global__ __launch_bounds__(256) void bag_apply_kernel(const ApplyParams p) {
 //     the first two values), and the segments are software-pipelined: the table row, accumulator row and the
 //     first two gradient rows of segment i+1 are requested before segment i is consumed.
 // Per group that is 2 + 1 trips for four segments instead of ~8 each.  Segments longer than two lookups finish
-// in a loop of four gradient rows per trip.  Results are bit-identical to bag_apply_kernel (same fmaf chain in
-// ascending position, same row_update); that kernel stays for descriptor counts beyond the LDS cache.
+// in a loop of four gradient rows per trip.  Results are bit-identical to the round-1 kernel (same fmaf chain in
+// ascending position, same row_update).  Descriptor counts beyond the LDS cache (> 512 features or tables) and the
+// one dtype pair no Keras policy produces (fp32 gradients into bf16 tables) take bag_apply_generic.
 typedef u32x4 u32x4_ua __attribute__((aligned(2)));
 typedef u32x2 u32x2_ua __attribute__((aligned(2)));
 
@@ -1063,9 +912,6 @@ __device__ __forceinline__ RawRow<N * (int)sizeof(TT) / 4> f32_to_raw(const floa
   return o;
 }
 
-#ifndef KRS_K2_EXP
-#define KRS_K2_EXP 0
-#endif
 constexpr int kFastFirst = 2;   // gradient rows requested with the row itself
 constexpr int kFastMore = 4;    // ... and per trip of the remainder loop
 
@@ -1144,13 +990,9 @@ __global__ __launch_bounds__(256) void bag_apply_fast_kernel(const ApplyParams p
   auto grad_src = [&](uint32_t bag) {
     const uint32_t f = bag / batch;
     const uint32_t b = bag - f * batch;
-#if KRS_K2_EXP == 1   // timing-only development builds (scripts/exp/k2_gather_exp.py): every gather reads sample 0 (cache hits)
-    return grad + ((int64_t)s_fcol[f]) * (int64_t)sizeof(GT) + 0 * b;
-#elif KRS_K2_EXP == 2 // ... or a feature-major slab [feature][sample][dim]: a table's gradient slice is contiguous
-    return grad + (((int64_t)f * batch + b) * p.dim) * (int64_t)sizeof(GT);
-#else
+    // (timing-only builds of round 4 read sample 0 everywhere / a feature-major slab here: gathers free -10 %, layout -1 %,
+    //  profiles/r4y_k2_gather_cost.txt)
     return grad + ((int64_t)b * p.grad_ld + s_fcol[f]) * (int64_t)sizeof(GT);
-#endif
   };
   auto coef_of = [&](uint64_t v) {
     float c = 1.0f;
@@ -1618,8 +1460,8 @@ __global__ void long_list_kernel(const uint32_t* seg_start, const uint32_t* n_se
 __global__ void count_unique_kernel(const uint32_t* keys, const uint32_t* n_seg, const uint32_t* sort_mode, int64_t nnz,
                                     int64_t* n_unique) {
   // segments minus the trailing run of invalid keys, if any.  A table-segmented plan leaves the out-of-range lookups at
-  // the end of every TABLE's run: the compact form cannot be built from it (-1; the host entry refuses such a plan
-  // when it has seen the plan call, this covers a workspace that was moved)
+  // the end of every TABLE's run: the compact form cannot be built from it (-1, which
+  // the caller turns into an error: embedding_ops.backward_sparse)
   if (*sort_mode != 0) { *n_unique = -1; return; }
   *n_unique = (int64_t)*n_seg - (nnz > 0 && keys[nnz - 1] == kInvalidKey ? 1 : 0);
 }
@@ -1630,24 +1472,18 @@ int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
   const int64_t groups = p.nnz;  // upper bound of the segment count (device-side n_seg trims it)
   const int64_t blocks = ceil_div(groups, (256 / lpr) * kSegsPerGroup);
   if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_bwd: grid too large");
-  const bool fast = p.n_feats <= kMaxLdsDesc && p.n_tables <= kMaxLdsDesc && g_apply_variant == 0;
 #define KRS_LAUNCH_FAST(L, W, SC) \
   hipLaunchKernelGGL((bag_apply_fast_kernel<GT, TT, L, MODE, W, SC>), dim3((unsigned)blocks), dim3(256), 0, st, p)
 #define KRS_LAUNCH_APPLY(L)                                                                             \
-  if (fast) {                                                                                           \
-    if (p.weights) { if (p.bag_scale) KRS_LAUNCH_FAST(L, true, true); else KRS_LAUNCH_FAST(L, true, false); }   \
-    else { if (p.bag_scale) KRS_LAUNCH_FAST(L, false, true); else KRS_LAUNCH_FAST(L, false, false); }           \
-  } else if (p.weights)                                                                                 \
-    hipLaunchKernelGGL((bag_apply_kernel<GT, TT, L, MODE, true>), dim3((unsigned)blocks), dim3(256), 0, st, p); \
-  else                                                                                                  \
-    hipLaunchKernelGGL((bag_apply_kernel<GT, TT, L, MODE, false>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  if (p.weights) { if (p.bag_scale) KRS_LAUNCH_FAST(L, true, true); else KRS_LAUNCH_FAST(L, true, false); }   \
+  else { if (p.bag_scale) KRS_LAUNCH_FAST(L, false, true); else KRS_LAUNCH_FAST(L, false, false); }
   if (lpr == 8) { KRS_LAUNCH_APPLY(8) }
   else if (lpr == 16) { KRS_LAUNCH_APPLY(16) }
   else if (lpr == 32) { KRS_LAUNCH_APPLY(32) }
   else { KRS_LAUNCH_APPLY(64) }
 #undef KRS_LAUNCH_APPLY
 #undef KRS_LAUNCH_FAST
-  KRS_CHECK_LAUNCH("bag_apply_kernel");
+  KRS_CHECK_LAUNCH("bag_apply_fast_kernel");
   // hot rows: upper bound of the item count is nnz / kLongSeg + nnz / kChunk; surplus workgroups leave at once
   const int64_t max_long = p.nnz / kLongSeg;
   if (max_long > 0) {
@@ -1682,11 +1518,13 @@ int run_apply(ApplyParams p, int grad_dtype, int table_dtype, hipStream_t st) {
   if (p.nnz == 0) return KRS_OK;
   const int64_t gbytes = (int64_t)p.dim * (grad_dtype == KRS_BF16 ? 2 : 4);
   // the per-lane piece must also map to whole table / accumulator elements: N elements each
-  if (gbytes % 16 == 0 && gbytes <= 1024) {
+  // (vector kernels: descriptors cached in LDS -- up to kMaxLdsDesc features / tables -- and the dtype pairs the Keras
+  //  policies produce: float32, bfloat16, mixed_bfloat16 = bf16 gradients into fp32 tables; fp32 gradients into bf16
+  //  tables and wider descriptor lists take the any-shape kernel below)
+  const bool vec_pair = !(grad_dtype == KRS_F32 && table_dtype == KRS_BF16 && mode_is_fused(MODE));
+  if (gbytes % 16 == 0 && gbytes <= 1024 && vec_pair && p.n_feats <= kMaxLdsDesc && p.n_tables <= kMaxLdsDesc) {
     const int pieces = (int)(gbytes / 16);
-    if (grad_dtype == KRS_F32)
-      return table_dtype == KRS_F32 ? launch_apply_lpr<float, float, MODE>(p, pieces, st)
-                                    : launch_apply_lpr<float, uint16_t, MODE>(p, pieces, st);
+    if (grad_dtype == KRS_F32) return launch_apply_lpr<float, float, MODE>(p, pieces, st);
     return table_dtype == KRS_F32 ? launch_apply_lpr<uint16_t, float, MODE>(p, pieces, st)
                                   : launch_apply_lpr<uint16_t, uint16_t, MODE>(p, pieces, st);
   }
@@ -1737,20 +1575,10 @@ extern "C" size_t krs_embed_bag_bwd_workspace_bytes(int64_t nnz) {
 }
 #endif
 
-// Which sort produced the plan in a workspace (host side, keyed by the workspace address): krs_embed_bag_bwd_sparse
-// refuses a table-segmented plan.  The same fact is kept in the workspace itself (PlanLayout::sort_mode).
-static std::mutex g_plan_mode_mutex;
-static std::unordered_map<const void*, int> g_plan_modes;
-static void remember_plan_mode(const void* workspace, int by_table) {
-  std::lock_guard<std::mutex> lock(g_plan_mode_mutex);
-  if (g_plan_modes.size() > (1u << 16)) g_plan_modes.clear();
-  g_plan_modes[workspace] = by_table;
-}
-static int recall_plan_mode(const void* workspace) {   // -1 = never seen
-  std::lock_guard<std::mutex> lock(g_plan_mode_mutex);
-  auto it = g_plan_modes.find(workspace);
-  return it == g_plan_modes.end() ? -1 : it->second;
-}
+// Which sort produced the plan is recorded IN the workspace (PlanLayout::sort_mode, written by the plan call on its
+// stream): krs_embed_bag_bwd_sparse reports n_unique = -1 for a table-segmented plan wherever the workspace has been
+// copied to.  (Round 3 also kept a host map keyed by the workspace address; an allocator hands freed addresses out
+// again, so a stale entry could refuse a good plan -- removed)
 
 // Table-segmented sort (rs::scatter_seg_kernel) when the host descriptors are given and the lookups are laid out for
 // it: dense bags, the features of a table neighbours, tables (and their row bases) ascending with the features.
@@ -1914,7 +1742,6 @@ static int plan_impl(const krs_table* tables, const krs_table* tables_host, int 
   // segments too long for one lane group (at most nnz / kLongSeg of them)
   KRS_HIP(hipMemsetAsync(l.n_long, 0, 3 * sizeof(uint32_t), st));
   KRS_HIP(hipMemsetAsync(l.sort_mode, by_table ? 1 : 0, sizeof(uint32_t), st));
-  remember_plan_mode(workspace, by_table ? 1 : 0);
   hipLaunchKernelGGL(long_list_kernel, dim3(nb), dim3(256), 0, st, l.seg_start, l.n_seg, nnz, l.n_long, l.long_list,
                      l.multi_list);
   KRS_CHECK_LAUNCH("long_list_kernel");
@@ -2002,7 +1829,7 @@ extern "C" int krs_embed_bag_bwd_fused_adam(const krs_table* tables, int n_table
 }
 #endif
 
-#if KRS_BWD_HAS(2)
+#if KRS_BWD_HAS(3)
 extern "C" int krs_embed_bag_bwd_fused_ftrl(const krs_table* tables, int n_tables, const krs_feature* feats,
                                             int n_feats, const float* weights, const float* bag_scale,
                                             const void* grad, int grad_dtype, int64_t grad_ld, int batch,
@@ -2027,9 +1854,6 @@ extern "C" int krs_embed_bag_bwd_sparse(const krs_feature* feats, int n_feats, c
     KRS_HIP(hipMemsetAsync(n_unique, 0, sizeof(int64_t), st));
     return KRS_OK;
   }
-  if (recall_plan_mode(workspace) == 1)
-    return fail(KRS_ERR_UNSUPPORTED, "embed_bag_bwd_sparse: the workspace holds a table-segmented plan "
-                "(krs_embed_bag_bwd_plan_tables): the compact form needs the global sort of krs_embed_bag_bwd_plan");
   const PlanLayout l = plan_layout(const_cast<void*>(workspace), nnz);
   hipLaunchKernelGGL(count_unique_kernel, dim3(1), dim3(1), 0, st, l.keys_sorted, l.n_seg, l.sort_mode, nnz, n_unique);
   KRS_CHECK_LAUNCH("count_unique_kernel");

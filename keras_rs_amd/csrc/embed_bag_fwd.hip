@@ -574,39 +574,29 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_generic(const EmbedFwdParam
   if (oob && p.err_flag && sub == 0) atomicOr(p.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
 }
 
-// One-hot gather variant (krs_embed_set_option(KRS_EMBED_OPT_HOT1, v) / environment KRS_EMBED_HOT1, read once):
-// bit 0: 16 instead of 8 row loads in flight per lane; bit 1: sample-major walk (embed_gather_hot1_rows).
+// One-hot gather: 16 row loads in flight per lane, sample-major walk (embed_gather_hot1_rows) where the output rows allow it.
+// Round 2 kept four variants behind KRS_EMBED_OPT_HOT1 (8 / 16 loads x feature-major / sample-major walk: 172.7 / 170.1 /
+// 164.8 / 159.3 us at the C3 L = 1 launch, profiles/r2_k1_hot1_variants_and_lds_hotrows.txt); round 5 keeps the winner only.
 int g_hot_rows = 0;   // krs_embed_set_option(KRS_EMBED_OPT_HOTROWS, rows): 0 = no LDS staging (default), 64, 128
-int g_hot1 = -1;
-int hot1_variant() {
-  if (g_hot1 < 0) {
-    const char* e = getenv("KRS_EMBED_HOT1");
-    g_hot1 = e ? (atoi(e) & 3) : 3;   // measured at C3: 172.7 / 170.1 / 164.8 / 159.3 us for variants 0..3
-  }
-  return g_hot1;
-}
 
 template <typename TT, typename OT, int LPR>
 int launch_vec(const EmbedFwdParams& p, bool one_hot, bool stream, hipStream_t st) {
   constexpr int G = 64 / LPR;
   if (one_hot) {
-    const int v = hot1_variant();
     if constexpr (sizeof(TT) == sizeof(OT)) {
-      bool rows_ok = (v & 2) && p.n_feats <= kRowsMaxFeats &&
-                     ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)(p.out_ld * sizeof(OT))) & 15) == 0;
+      const bool rows_ok = p.n_feats <= kRowsMaxFeats &&
+                           ((reinterpret_cast<uintptr_t>(p.out) | (uintptr_t)(p.out_ld * sizeof(OT))) & 15) == 0;
       if (rows_ok) {
         const int64_t blocks = ceil_div(ceil_div((int64_t)p.batch * p.n_feats, 64), 4);
         if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_fwd: grid too large");
-        if (v & 1) hipLaunchKernelGGL((embed_gather_hot1_rows<TT, LPR, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((embed_gather_hot1_rows<TT, LPR, 8>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((embed_gather_hot1_rows<TT, LPR, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
         KRS_CHECK_LAUNCH("embed_gather_hot1_rows");
         return KRS_OK;
       }
     }
     const int64_t blocks = ceil_div(ceil_div(p.batch, 64) * p.n_feats, 4);
     if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_fwd: grid too large");
-    if (v & 1) hipLaunchKernelGGL((embed_gather_hot1<TT, OT, LPR, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((embed_gather_hot1<TT, OT, LPR, 8>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((embed_gather_hot1<TT, OT, LPR, 16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     KRS_CHECK_LAUNCH("embed_gather_hot1");
     return KRS_OK;
   }
@@ -648,14 +638,9 @@ int dispatch_lpr(const EmbedFwdParams& p, int row_pieces, bool one_hot, bool str
 }  // namespace
 }  // namespace krs
 
-namespace krs { extern int g_apply_variant, g_plan_variant; }   // embed_bag_bwd.hip
+namespace krs { extern int g_plan_variant; }   // embed_bag_bwd.hip
 
 extern "C" int krs_embed_set_option(int key, int value) {
-  if (key == KRS_EMBED_OPT_APPLY) {
-    KRS_REQUIRE(value == 0 || value == 1, "krs_embed_set_option: apply variant must be 0 or 1");
-    krs::g_apply_variant = value;
-    return KRS_OK;
-  }
   if (key == KRS_EMBED_OPT_PLAN) {
     KRS_REQUIRE(value == 0 || value == 1, "krs_embed_set_option: plan variant must be 0 or 1");
     krs::g_plan_variant = value;
@@ -664,11 +649,6 @@ extern "C" int krs_embed_set_option(int key, int value) {
   if (key == KRS_EMBED_OPT_HOTROWS) {
     KRS_REQUIRE(value == 0 || value == 64 || value == 128, "krs_embed_set_option: hot rows must be 0, 64 or 128");
     krs::g_hot_rows = value;
-    return KRS_OK;
-  }
-  if (key == KRS_EMBED_OPT_HOT1) {
-    KRS_REQUIRE(value >= 0 && value <= 3, "krs_embed_set_option: one-hot gather variant must be 0..3");
-    krs::g_hot1 = value;
     return KRS_OK;
   }
   return krs::fail(KRS_ERR_INVALID, "krs_embed_set_option: unknown key %d", key);

@@ -10,15 +10,15 @@
 // the layer needs (forward, data gradient, weight gradient).  MFMA throughout:
 // v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, exact fmaf chain), fp32
 // accumulators in registers, a lane's operand = 16 bytes of LDS.  Kernels, by shape:
-//   * gemm_pp256_kernel     what the big bf16 shapes dispatch to (both operand layouts): the 256x256 tile on a
-//                           four-stage LDS-DMA ring, ping-pong wave groups, counted vmcnt, epilogue operands fetched
-//                           under the tail of the main loop; bit-identical to the two-stage kernels below, which stay
-//                           as pipeline 0 of krs_gemm_set_option;
-//   * gemm_glds256_kernel   both operands K-contiguous, K % 64 == 0, M, N >= 256: 256x256 tile,
-//                           8 waves, two 64 KB stages filled by LDS-DMA (global_load_lds), XOR
-//                           swizzle on the source side;
-//   * gemm_glds_kernel      the same pipeline on a 128x128 tile for smaller M / N (K >= 1024);
-//   * gemm_tn_glds256_kernel / gemm_tn_glds_kernel
+//   * gemm_pp256_kernel     what the big bf16 shapes dispatch to (both operand layouts): the 256x256 tile (8 waves as
+//                           2(M) x 4(N), 128x64 per wave) on a four-stage LDS-DMA ring (global_load_lds, XOR swizzle on
+//                           the source side), ping-pong wave groups, counted vmcnt, epilogue operands fetched under the
+//                           tail of the main loop; bit-identical to the 128x128 two-stage kernels below, which every
+//                           shape takes under pipeline 0 of krs_gemm_set_option.  (The 256x256 two-stage kernels of
+//                           round 1, gemm_glds256_kernel / gemm_tn_glds256_kernel, were deleted in round 5: 222-230 ->
+//                           204 us and 276 -> 208-220 us against the ring, profiles/r2_gemm_ab.txt.)
+//   * gemm_glds_kernel      two 32 KB stages filled by LDS-DMA on a 128x128 tile for smaller M / N (K >= 1024);
+//   * gemm_tn_glds_kernel
 //                           bf16 weight gradients (both operands K-strided): tiles DMA'd as they
 //                           lie in memory, fragments by the transposing ds_read_b64_tr_b16,
 //                           split along K into fp32 slabs (one split per XCD at a time) that are
@@ -39,7 +39,7 @@
 #include <cstring>
 #include <initializer_list>
 
-#include "krs_common.h"
+#include "krs_dense_common.h"
 
 namespace krs {
 namespace {
@@ -67,24 +67,6 @@ struct GemmParams {
   // fused cross-backward epilogue (EPI 3 .. 8 of gemm_pp256_kernel, krs_gemm_cross_bwd): operands of the layer below
   const void* f_x0; const void* f_u; const void* f_uup; void* f_dz; void* f_dx0; float* f_partial; int64_t f_ld; int f_act; int f_fold;
 };
-
-__device__ __forceinline__ float apply_act(int act, float v) {
-  switch (act) {
-    case KRS_ACT_RELU: return v > 0.0f ? v : 0.0f;
-    case KRS_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
-    case KRS_ACT_TANH: return tanhf(v);
-    default: return v;
-  }
-}
-
-__device__ __forceinline__ float act_grad_from_output(int act, float u) {
-  switch (act) {
-    case KRS_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
-    case KRS_ACT_SIGMOID: return u * (1.0f - u);
-    case KRS_ACT_TANH: return 1.0f - u * u;
-    default: return 1.0f;
-  }
-}
 
 // epilogue of one element; `odt` = dtype of C, x0, x, u_out, r
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int64_t i, int64_t j, float v) {
@@ -638,117 +620,6 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const GemmParams p) {
   gemm_epilogue<EPI>(p, acc, smem, m0, n0, 0);
 }
 
-// Long-K forward / data-gradient shapes with M, N >= 256: the same LDS-DMA pipeline on a 256x256
-// workgroup tile (8 waves as 2(M) x 4(N), 128x64 per wave = 4x2 MFMA fragments, 128 accumulator
-// registers).  A 128x128 tile at full MFMA rate would need 64 B/clk/CU from L2 -- the whole L1
-// fill path -- and measures ~30 % MFMA utilisation; the 256x256 tile halves the operand bytes per
-// flop (and the LDS reads per MFMA drop from 1 to 3/4).  One workgroup per CU: two 64 KB stages.
-template <int ES, int EPI>
-__global__ __launch_bounds__(512) void gemm_glds256_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TM = 256, TN = 256;
-  constexpr int BK = ROW_BYTES / ES;
-  constexpr int OPA_BYTES = TM * ROW_BYTES;   // 32 KB
-  constexpr int STAGE_BYTES = (TM + TN) * ROW_BYTES;
-  typedef const __attribute__((address_space(1))) void* gptr;
-  typedef __attribute__((address_space(3))) void* lptr;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  // the N tiles of one M panel run back to back on one XCD (workgroup id % 8), sharing A in its L2
-  const int64_t nt = (p.n + TN - 1) / TN;
-  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int64_t m_tile = (slot / nt) * 8 + xcd;
-  if (m_tile * TM >= p.m) return;
-  const int64_t m0 = m_tile * TM;
-  const int64_t n0 = (slot % nt) * TN;
-  const int64_t ntiles = p.k / BK;
-
-  // per-lane source rows / chunks of the 4 DMA pieces (8 rows x 128 B each) this wave issues per
-  // operand and tile; source-side XOR swizzle as in gemm_glds_kernel
-  const char* asrc[4];
-  const char* bsrc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (wave * 4 + i) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    const int64_t ar = min(m0 + r, p.m - 1);
-    const int64_t br = min(n0 + r, p.n - 1);
-    asrc[i] = p.a + (ar * p.lda) * ES + c * 16;
-    bsrc[i] = p.b + (br * p.ldb) * ES + c * 16;
-  }
-  auto issue = [&](int64_t t, int stage) {
-    char* sa = smem + stage * STAGE_BYTES + (wave * 4) * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr)(asrc[i] + t * ROW_BYTES), (lptr)(sa + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr)(bsrc[i] + t * ROW_BYTES), (lptr)(sa + OPA_BYTES + i * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][2][2];  // [upper / lower 64 rows][m fragment][n fragment]
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
-
-  if (ntiles > 0) issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int frow = lane & 31;
-  const int fhalf = lane >> 5;
-  int aoff[4], boff[2], akey[4], bkey[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 128 + i * 32 + frow;
-    aoff[i] = ra * ROW_BYTES; akey[i] = (ra >> 1) & 7;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int rb = wn * 64 + j * 32 + frow;
-    boff[j] = OPA_BYTES + rb * ROW_BYTES; bkey[j] = (rb >> 1) & 7;
-  }
-  for (int64_t t = 0; t < ntiles; ++t) {
-    const int cur = (int)(t & 1);
-    if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
-    const char* st = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < ROW_BYTES / 32; ++ks) {
-      const int c = ks * 2 + fhalf;
-      u32x4 fa[4], fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(st + boff[j] + ((c ^ bkey[j]) << 4));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + aoff[i] + ((c ^ akey[i]) << 4));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16& d = acc[i >> 1][i & 1][j];
-          if constexpr (ES == 2) {
-            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                       __builtin_bit_cast(bf16x8, fb[j]), d, 0, 0, 0);
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              d = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(fa[i][q]), __uint_as_float(fb[j][q]), d, 0, 0, 0);
-          }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
-    __syncthreads();                                   // and every wave is done with tile t
-  }
-  lds_dma_retired<0>();
-  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  gemm_epilogue_wave128<EPI>(p, acc, stage, m0 + wm * 128, n0 + wn * 64, 0);
-}
-
 // Weight-gradient shapes in bf16 (C = A^T B with BOTH operands K-strided in HBM: activations
 // contracted over the batch).  The operand tiles go to LDS by DMA exactly as they lie in memory --
 // rows of K, 16-byte chunks of 8 columns -- and the MFMA fragments (8 consecutive K per lane) are
@@ -863,116 +734,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmParams p
   gemm_epilogue<EPI>(p, acc, smem, m0, n0, split);
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p, int mt, int nt) {
-  // 256 x 256 tile, 8 waves as 2(M) x 4(N); each operand tile is two 128-column halves with the 128-column image
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BK = 64;
-  constexpr int TM = 256, TN = 256;
-  constexpr int HALF_BYTES = BK * 128 * 2;   // 16 KB
-  constexpr int OP_BYTES = 2 * HALF_BYTES;   // 32 KB
-  constexpr int STAGE_BYTES = 2 * OP_BYTES;
-  typedef const __attribute__((address_space(1))) void* gptr;
-  typedef __attribute__((address_space(3))) void* lptr;
-  typedef short s16x4 __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) s16x4* trptr;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  // One K split = one XCD at a time (workgroup id % 8 picks the XCD): all mt*nt tiles of a split walk
-  // the same K rows together, so a row of A / B is consumed whole (by the tiles side by side) while
-  // its DRAM page and TLB entry are hot, and the operand tiles are shared through that XCD's L2.
-  const int64_t tiles = (int64_t)mt * nt, items = tiles * p.splits, q = (items + 7) / 8;
-  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int64_t w = xcd * q + slot;   // contiguous runs of (split, tile) items per XCD, see gemm_pp256_kernel
-  if (slot >= q || w >= items) return;
-  const int split = (int)(w / tiles);
-  const int64_t tile = w % tiles;
-  const int64_t m0 = (tile % mt) * TM;
-  const int64_t n0 = (tile / mt) * TN;
-  const int64_t kbeg = (int64_t)split * p.k_per_split;
-  const int64_t kend = min(p.k, kbeg + p.k_per_split);
-  const int64_t ntiles = (kend - kbeg) / BK;   // K extents are multiples of 64 (checked on the host)
-
-  // DMA: this wave fills blocks kb = (wave & 3)*4 + j of half wave >> 2 of each operand;
-  // lane = (quarter*4 + k-row)*4 + chunk
-  const int dkr = (lane >> 2) & 3, dcol = (wave >> 2) * 128 + (lane >> 4) * 32 + (lane & 3) * 8;
-  const int64_t acol = min(m0 + dcol, p.m - 8);   // clamped: surplus columns are never stored
-  const int64_t bcol = min(n0 + dcol, p.n - 8);
-  const char* asrc = p.a + ((kbeg + (wave & 3) * 16 + dkr) * p.lda + acol) * 2;
-  const char* bsrc = p.b + ((kbeg + (wave & 3) * 16 + dkr) * p.ldb + bcol) * 2;
-  const int64_t astep = p.lda * 8, bstep = p.ldb * 8;   // 4 k-rows, in bytes
-  auto issue = [&](int64_t t, int stage) {
-    char* sa = smem + stage * STAGE_BYTES + (wave >> 2) * HALF_BYTES + ((wave & 3) * 4) * 1024;
-    const char* at = asrc + t * BK * p.lda * 2;
-    const char* bt = bsrc + t * BK * p.ldb * 2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr)(at + j * astep), (lptr)(sa + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr)(bt + j * bstep), (lptr)(sa + OP_BYTES + j * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][2][2];  // [upper / lower 64 rows][m fragment][n fragment]
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
-
-  if (ntiles > 0) issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // transposing-read addresses: group g = lane >> 4 (columns (g & 1) * 16 .., k half g >> 1),
-  // lane-in-group ii: k-row ii >> 2, 4-column quad ii & 3
-  const int g = lane >> 4, ii = lane & 15;
-  const int lane_off = (ii >> 2) * 64 + (g & 1) * 32 + (ii & 3) * 8 + (g >> 1) * 2048;
-  int aoff[4], boff[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) aoff[i] = wm * HALF_BYTES + i * 256 + lane_off;  // a fragment = one 32-column quarter
-#pragma unroll
-  for (int j = 0; j < 2; ++j) boff[j] = OP_BYTES + (wn >> 1) * HALF_BYTES + ((wn & 1) * 2 + j) * 256 + lane_off;
-  for (int64_t t = 0; t < ntiles; ++t) {
-    const int cur = (int)(t & 1);
-    if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
-    char* st = smem + cur * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      u32x4 fa[4], fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const uint2 b0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + boff[j] + ks * 4096)));
-        const uint2 b1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + boff[j] + ks * 4096 + 1024)));
-        fb[j] = u32x4{b0.x, b0.y, b1.x, b1.y};
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint2 a0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + aoff[i] + ks * 4096)));
-        const uint2 a1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((trptr)(st + aoff[i] + ks * 4096 + 1024)));
-        fa[i] = u32x4{a0.x, a0.y, a1.x, a1.y};
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16& d = acc[i >> 1][i & 1][j];
-          d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                     d, 0, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has landed
-    __syncthreads();                                   // and every wave is done with tile t
-  }
-  lds_dma_retired<0>();
-  float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
-}
-
 // ---- fused epilogue of krs_gemm_cross_bwd (round 4) ----------------------------------------------------------------
 // The data-gradient product of a cross layer, G = A B^T + beta R, is dL/dy of the layer BELOW it in a stack on one x0,
 // whose elementwise backward (cross_bwd_vec_kernel) starts by re-reading G.  This epilogue does that pass on the tile
@@ -987,9 +748,6 @@ __global__ __launch_bounds__(512) void gemm_tn_glds256_kernel(const GemmParams p
 // the term of the layer ABOVE computed here from its dL/dy (= R, already loaded) and its saved u, so that the top layer of a
 // stack neither writes nor this launch reads a [M, N] matrix for it (that one sum is rounded once instead of twice);
 // 3: no dL/dx0 at all from this launch (the caller hands u to the NEXT launch as its u_upper: a Dense layer above a stack).
-#ifndef KRS_CBW_PF
-#define KRS_CBW_PF 0
-#endif
 template <int DX0, bool HAS_R>
 __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
                                                                int64_t wm0, int64_t wn0, int64_t group) {
@@ -1004,7 +762,8 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
   for (int q = 0; q < 8; ++q) db[q] = 0.0f;
   // operand vectors of a chunk, two sets: chunk c + 1's are requested while chunk c is processed -- x0 and u as soon as
   // chunk c's accumulators are staged (their registers are free from then on), R and the dL/dx0 source too from the second
-  // chunk on (KRS_CBW_PF = 1: x0 / u only, 2: all; with 0 every stream of chunk c + 1 is requested behind chunk c's stores, the round-4 order)
+  // chunk on.  (Requesting them earlier -- right behind the staging of chunk c's accumulators -- measured equal,
+  // profiles/r4y_cross_bwd_fused_prefetch.txt: every stream of chunk c + 1 is requested behind chunk c's stores.)
   uint4 vr2[2][4], vx02[2][4], vu2[2][4], vd2[2][4];
   auto ld_x0u = [&](int c, int b) {
 #pragma unroll
@@ -1038,10 +797,6 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         stage[((r & 3) + 8 * (r >> 2) + 4 * fhalf) * SST + j * 32 + frow] = acc2[j][r];
-    if (KRS_CBW_PF && c < 3) {
-      ld_x0u(c + 1, (c + 1) & 1);
-      if (KRS_CBW_PF >= 2 && c >= 1) ld_rd(c + 1, (c + 1) & 1);
-    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -1087,8 +842,8 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (c < 3) {
-      if (!KRS_CBW_PF) ld_x0u(c + 1, (c + 1) & 1);
-      if (KRS_CBW_PF < 2 || c < 1) ld_rd(c + 1, (c + 1) & 1);
+      ld_x0u(c + 1, (c + 1) & 1);
+      ld_rd(c + 1, (c + 1) & 1);
     }
   }
   if (p.f_partial) {
@@ -1136,19 +891,11 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
 // products with heavy epilogues, 256 x 128 tiles on a three-stage ring at TWO workgroups per CU, so that one's
 // epilogue runs under the other's main loop (467 / 344 us against 450 / 323: 1.5x the operand bytes per flop cost
 // more than the overlap returns).
-// cache policy of the ring's LDS-DMA loads (development builds: scripts/exp/build_variants.sh): 0 = default, 2 = nt, 16 = sc1
-#ifndef KRS_PP_A_AUX
-#define KRS_PP_A_AUX 0
-#endif
-#ifndef KRS_PP_B_AUX
-#define KRS_PP_B_AUX 0
-#endif
-#ifndef KRS_PP_LAYOUT_EXP
-#define KRS_PP_LAYOUT_EXP 0
-#endif
-#ifndef KRS_PP_PROBE
-#define KRS_PP_PROBE 0  // development builds only (scripts/exp): 1 = DMA stream alone, 2 = LDS reads + MFMA alone, 3 = DMA + LDS reads, 4 = epilogue alone
-#endif
+// (Rounds 2-4 carried timing-only build switches in this kernel -- KRS_PP_PROBE: DMA stream alone / LDS reads + MFMA alone /
+//  epilogue alone; KRS_PP_LAYOUT_EXP: operands read as if pre-tiled; KRS_PP_{A,B}_AUX: cache policy of the LDS-DMA loads -- and
+//  two more schedules behind krs_gemm_set_option: a five-stage ring and a prefetch schedule.  What they measured is in
+//  profiles/r2_pp_probe_dma_lds_mfma.txt, r4_gemm_layout_waves_clock_probe.txt, r2_gemm_ab.txt; round 5 removed them from
+//  the product source: the default cache policy, four stages and the ping-pong schedule are what ships.)
 namespace pp {
 constexpr int PIECE = 16384;
 constexpr int STAGE = 2 * PIECE;
@@ -1177,141 +924,21 @@ __device__ __forceinline__ void pp_lgkm_wait(u32x4 (&fa)[4], u32x4 (&fb)[2]) {
                : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1])
                : "n"(N));
 }
-// fragment Q of a phase (0, 1: the B fragments, 2..5: the A fragments) from the stage/half addresses sa / sb
-template <bool TN, int Q>
-__device__ __forceinline__ void pp_read_frag(uint32_t sa, uint32_t sb, u32x4 (&fa)[4], u32x4 (&fb)[2]) {
-  constexpr int idx = Q < 2 ? Q : Q - 2;
-  const uint32_t base = Q < 2 ? sb : sa;
-  u32x4 v;
-  if constexpr (TN) {
-    const u32x2 lo = pp_read_tr16<idx * 256>(base), hi = pp_read_tr16<idx * 256 + 1024>(base);
-    v = u32x4{lo.x, lo.y, hi.x, hi.y};
-  } else {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(idx * 2048));
-  }
-  if constexpr (Q < 2) fb[idx] = v;
-  else fa[idx] = v;
-}
 template <int N>
 __device__ __forceinline__ void pp_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// Round 4: the 128x128 tile on a DEEP ring, for outputs too small to fill the chip with 256x256 tiles (the per-rank
-// step of a strongly-scaled job: M = 8192 against N = 512 is 64 such tiles, 256 tiles of 128x128).  A 128x128 tile moves
-// twice the operand bytes per flop of the 256x256 one, so this kernel is bound by the L2 -> LDS request path four to
-// one (16 LDS-DMA instructions of ~40-60 clocks against 8 MFMA of 32 clocks per wave and 32-k block): what matters is
-// that the DMA queue never drains.  The two-stage kernel above issues one 32 KB tile, computes, and waits for
-// `vmcnt(0)` once per tile; here K advances in blocks of 32 (A piece + B piece = 16 KB), NSTG stages (8 = 128 KB with
-// one workgroup per CU, 4 = 64 KB with two), NSTG-1 blocks in flight behind a COUNTED `vmcnt`, one barrier per block.
-// Same fragment layout, same k order per accumulator as gemm_glds_kernel: bit-identical results.
-template <int NSTG, int EPI>
-__global__ __launch_bounds__(256, (NSTG <= 4 ? 2 : 1)) void gemm_ring128_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int PIECE = 128 * 64, STAGE = 2 * PIECE;
-  typedef const __attribute__((address_space(1))) void* gptr;
-  typedef __attribute__((address_space(3))) void* lptr;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t nt = (p.n + BN - 1) / BN;
-  const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int64_t m_tile = (slot / nt) * 8 + xcd;
-  if (m_tile * BM >= p.m) return;
-  const int64_t m0 = m_tile * BM, n0 = (slot % nt) * BN;
-  const int nkb = (int)(p.k / 32);   // (the host guarantees nkb >= NSTG)
-
-  // instruction q = wave*2 + i of a piece fills rows q*16 .. q*16+15 (64 B each): lane = row*4 + physical chunk, which
-  // holds the logical 16-byte chunk pc ^ ((row >> 2) & 3) -- the image of gemm_pp256_kernel
-  const char* ap[2];
-  const char* bp[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (wave * 2 + i) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((r >> 2) & 3);
-    ap[i] = p.a + min(m0 + r, p.m - 1) * p.lda * 2 + c * 16;
-    bp[i] = p.b + min(n0 + r, p.n - 1) * p.ldb * 2 + c * 16;
-  }
-  const int dma_off = wave * 2048;
-  auto issue = [&](int stage) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr)ap[i], (lptr)(smem + stage * STAGE + dma_off + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr)bp[i], (lptr)(smem + stage * STAGE + PIECE + dma_off + i * 1024), 16, 0, 0);
-      ap[i] += 64;
-      bp[i] += 64;
-    }
-  };
-  const int frow = lane & 31, fhalf = lane >> 5, key = (frow >> 2) & 3;
-  const int a_lane = (wm * 64 + frow) * 64 + ((fhalf ^ key) << 4);
-  const int b_lane = PIECE + (wn * 64 + frow) * 64 + ((fhalf ^ key) << 4);
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-#pragma unroll
-  for (int j = 0; j < NSTG - 1; ++j) issue(j);
-  int rd = 0, wr = NSTG - 1;
-  const int last = nkb - 1;
-  for (int kb = 0; kb <= last; ++kb) {
-    // block kb has landed when at most the blocks behind it (4 instructions each) are still in flight
-    const int rem = min(last - kb, NSTG - 2);
-    if constexpr (NSTG == 8) {
-      switch (rem) {
-        case 6: pp_vmcnt<24>(); break;
-        case 5: pp_vmcnt<20>(); break;
-        case 4: pp_vmcnt<16>(); break;
-        case 3: pp_vmcnt<12>(); break;
-        case 2: pp_vmcnt<8>(); break;
-        case 1: pp_vmcnt<4>(); break;
-        default: pp_vmcnt<0>(); break;
-      }
-    } else {
-      switch (rem) {
-        case 2: pp_vmcnt<8>(); break;
-        case 1: pp_vmcnt<4>(); break;
-        default: pp_vmcnt<0>(); break;
-      }
-    }
-    pp_barrier();   // block kb visible to every wave; every wave is done with block kb-1 (its MFMAs consumed the reads)
-    if (kb + NSTG - 1 <= last) issue(wr);
-    const char* st = smem + rd * STAGE;
-#pragma unroll
-    for (int hk = 0; hk < 2; ++hk) {
-      const int x = hk * 32;
-      u32x4 fa[2], fb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(st + (b_lane ^ x) + j * 2048);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + (a_lane ^ x) + i * 2048);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                            __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
-    }
-    rd = rd + 1 == NSTG ? 0 : rd + 1;
-    wr = wr + 1 == NSTG ? 0 : wr + 1;
-  }
-  pp_barrier();      // the staging of the epilogue re-uses the ring
-  lds_dma_retired<0>();
-  gemm_epilogue<EPI>(p, acc, smem, m0, n0, 0);
-}
-
-template <bool TN, int NSTG, int EPI, int SCHED = 0>
+// (Round 4 also built the 128x128 tile on a deep ring -- gemm_ring128_kernel, KRS_GEMM_OPT_PIPELINE = 7 -- for the per-rank
+//  shapes of a strongly-scaled job; it measured equal or slower than gemm_glds_kernel (47.2 against 44.9 us at M = 8192,
+//  profiles/r4_gemm_ring128_b8192.txt: one 128x128 tile per CU already draws the ~40 GB/s per CU of the L2 -> LDS path) and
+//  was deleted in round 5.)
+template <bool TN, int NSTG, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int mt, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TM = 256, TN_ = 256;
   typedef const __attribute__((address_space(1))) void* gptr;
   typedef __attribute__((address_space(3))) void* lptr;
-  typedef short s16x4 __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) s16x4* trptr;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1334,7 +961,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     kbeg = (int64_t)split * p.k_per_split;
     nkb = (min(p.k, kbeg + p.k_per_split) - kbeg) / 32;
   } else {
-    // the N tiles of one M panel run back to back on one XCD, as in gemm_glds256_kernel
+    // the N tiles of one M panel run back to back on one XCD (workgroup id % 8) and share A in its L2
     const int64_t m_tile = (slot / nt) * 8 + xcd;
     if (m_tile * TM >= p.m) return;
     m0 = m_tile * TM;
@@ -1357,16 +984,6 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
       bp[i] = p.b + min(n0 + r, p.n - 1) * p.ldb * 2 + c * 16;
     }
     astep = bstep = 64;
-#if KRS_PP_LAYOUT_EXP  // development builds (timing only, results are garbage): operands read as if pre-tiled [K/32][rows][32]
-    if (KRS_PP_LAYOUT_EXP & 1) {
-      for (int i = 0; i < 2; ++i) bp[i] = p.b + (min(n0 + (wave * 2 + i) * 16 + (lane >> 2), p.n - 1)) * 64 + (lane & 3) * 16;
-      bstep = p.n * 64;
-    }
-    if (KRS_PP_LAYOUT_EXP & 2) {
-      for (int i = 0; i < 2; ++i) ap[i] = p.a + (min(m0 + (wave * 2 + i) * 16 + (lane >> 2), p.m - 1)) * 64 + (lane & 3) * 16;
-      astep = p.m * 64;
-    }
-#endif
   } else {
     // instruction q fills the 1 KB block (128-column half q >> 3, k-rows (q & 7)*4 .. +3) with the image of
     // gemm_tn_glds_kernel: lane = (quarter*4 + k-row)*4 + chunk
@@ -1380,32 +997,20 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     }
     astep = p.lda * 64;
     bstep = p.ldb * 64;
-#if KRS_PP_LAYOUT_EXP  // (timing only) K-strided operands read as if pre-tiled [cols/256][K][256]
-    if (KRS_PP_LAYOUT_EXP & 4) {
-      for (int i = 0; i < 2; ++i) bp[i] = p.b + ((min(n0 >> 8, (p.n >> 8) - 1) * p.k + kbeg + ((wave & 3) * 2 + i) * 4 + kr) * 256 + (col & 255)) * 2;
-      bstep = 32 * 512;
-    }
-    if (KRS_PP_LAYOUT_EXP & 8) {
-      for (int i = 0; i < 2; ++i) ap[i] = p.a + ((min(m0 >> 8, (p.m >> 8) - 1) * p.k + kbeg + ((wave & 3) * 2 + i) * 4 + kr) * 256 + (col & 255)) * 2;
-      astep = 32 * 512;
-    }
-#endif
   }
   const int dma_off = wave * 2048;  // + i*1024: where instruction q = wave*2 + i lands inside a piece
   auto issue_a = [&](int stage) {
-    if constexpr (KRS_PP_PROBE == 2) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr)ap[i], (lptr)(smem + stage * pp::STAGE + dma_off + i * 1024), 16, 0, KRS_PP_A_AUX);
+      __builtin_amdgcn_global_load_lds((gptr)ap[i], (lptr)(smem + stage * pp::STAGE + dma_off + i * 1024), 16, 0, 0);
       ap[i] += astep;
     }
   };
   auto issue_b = [&](int stage) {
-    if constexpr (KRS_PP_PROBE == 2) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       __builtin_amdgcn_global_load_lds((gptr)bp[i], (lptr)(smem + stage * pp::STAGE + pp::PIECE + dma_off + i * 1024), 16,
-                                       0, KRS_PP_B_AUX);
+                                       0, 0);
       bp[i] += bstep;
     }
   };
@@ -1427,7 +1032,6 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   auto load_frags = [&](int stage, int hk, u32x4(&fa)[4], u32x4(&fb)[2]) {
-    if constexpr (KRS_PP_PROBE == 1) return;
     const char* st = smem + stage * pp::STAGE;
     if constexpr (!TN) {
       const int x = hk * 32;
@@ -1462,15 +1066,10 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
   // epilogue operands fetched under the tail of the main loop (ping-pong schedule): chunks, load instructions
-  constexpr int NPFC = SCHED != 0 ? 0 : EPI == 2 ? 4 : EPI == 1 ? 2 : 0;
+  constexpr int NPFC = EPI == 2 ? 4 : EPI == 1 ? 2 : 0;
   constexpr int NPF = NPFC * (EPI == 1 ? 8 : 4);
   EpiOperands opf[4];
   auto mfma8 = [&](const u32x4(&fa)[4], const u32x4(&fb)[2]) {
-    if constexpr (KRS_PP_PROBE == 1) return;
-    if constexpr (KRS_PP_PROBE == 3) {  // keep the fragment reads alive without the matrix pipes
-      asm volatile("" ::"v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "v"(fb[0]), "v"(fb[1]));
-      return;
-    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1483,84 +1082,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     __builtin_amdgcn_s_setprio(0);
   };
 
-  if constexpr (KRS_PP_PROBE == 4) {
-    // (probe: no main loop at all)
-  } else if constexpr (SCHED == 1) {
-    // PREFETCH schedule: no group stagger, one barrier per phase.  The fragments of phase p+1 are read into a
-    // second register set WHILE the MFMAs of phase p issue -- one fragment read behind each of the first six
-    // MFMAs (all reads opaque assembly, every step pinned with sched_barrier) -- so LDS latency and the low
-    // per-wave issue rate of the 8-byte transposing reads run under matrix work, and both waves of a SIMD keep
-    // reads in flight at the same time.  Pieces: A(kb+NSTG-1) is issued at the head of phase 2kb, B(kb+NSTG-1)
-    // at the head of phase 2kb+1 (the slot held block kb-1, whose last fragments every wave consumed before the
-    // barrier that closed phase 2kb-1); block kb+1 is waited for at the end of phase 2kb (counted vmcnt).
-    static_assert(SCHED != 1 || NSTG == 4, "the tail of the prefetch schedule is written for four stages");
-    const int64_t last = nkb - 1;
-#pragma unroll
-    for (int j = 0; j < NSTG - 1; ++j) {
-      issue_a(j);
-      issue_b(j);
-    }
-    pp_vmcnt<4 * (NSTG - 2)>();
-    pp_barrier();
-    auto frag_addr = [&](int stage, int hk, uint32_t& sa, uint32_t& sb) {
-      if constexpr (!TN) {
-        sa = lds_base + stage * pp::STAGE + (a_lane ^ (hk * 32));
-        sb = lds_base + stage * pp::STAGE + (b_lane ^ (hk * 32));
-      } else {
-        sa = lds_base + stage * pp::STAGE + hk * 4096 + a_lane;
-        sb = lds_base + stage * pp::STAGE + hk * 4096 + b_lane;
-      }
-    };
-    auto mfma1 = [&](int i, int j, const u32x4(&fa)[4], const u32x4(&fb)[2]) {
-      f32x16& d = acc[i >> 1][i & 1][j];
-      d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), d, 0, 0, 0);
-    };
-#define KRS_PF_STEP(I, J, CA, CB, READ) \
-  mfma1(I, J, CA, CB);                 \
-  READ;                                \
-  __builtin_amdgcn_sched_barrier(0);
-#define KRS_PF_PHASE(CA, CB, NA, NB)                                   \
-  pp_lgkm_wait<0>(CA, CB);                                             \
-  KRS_PF_STEP(0, 0, CA, CB, (pp_read_frag<TN, 0>(sa, sb, NA, NB)))     \
-  KRS_PF_STEP(0, 1, CA, CB, (pp_read_frag<TN, 1>(sa, sb, NA, NB)))     \
-  KRS_PF_STEP(1, 0, CA, CB, (pp_read_frag<TN, 2>(sa, sb, NA, NB)))     \
-  KRS_PF_STEP(1, 1, CA, CB, (pp_read_frag<TN, 3>(sa, sb, NA, NB)))     \
-  KRS_PF_STEP(2, 0, CA, CB, (pp_read_frag<TN, 4>(sa, sb, NA, NB)))     \
-  KRS_PF_STEP(2, 1, CA, CB, (pp_read_frag<TN, 5>(sa, sb, NA, NB)))     \
-  KRS_PF_STEP(3, 0, CA, CB, (void)0)                                   \
-  KRS_PF_STEP(3, 1, CA, CB, (void)0)
-    u32x4 fa0[4], fb0[2], fa1[4], fb1[2];
-    uint32_t sa, sb;
-    frag_addr(0, 0, sa, sb);
-    pp_read_frag<TN, 0>(sa, sb, fa0, fb0);
-    pp_read_frag<TN, 1>(sa, sb, fa0, fb0);
-    pp_read_frag<TN, 2>(sa, sb, fa0, fb0);
-    pp_read_frag<TN, 3>(sa, sb, fa0, fb0);
-    pp_read_frag<TN, 4>(sa, sb, fa0, fb0);
-    pp_read_frag<TN, 5>(sa, sb, fa0, fb0);
-    int rd = 0, wr = NSTG - 1;
-    for (int64_t kb = 0; kb <= last; ++kb) {
-      const int nx = rd + 1 == NSTG ? 0 : rd + 1;
-      const bool more = kb + NSTG - 1 <= last;
-      // ---- phase 2kb ----
-      if (more) issue_a(wr);
-      frag_addr(rd, 1, sa, sb);
-      KRS_PF_PHASE(fa0, fb0, fa1, fb1)
-      if (more) pp_vmcnt<4 * NSTG - 10>();
-      else if (last - kb - 1 == 1) pp_vmcnt<4>();
-      else pp_vmcnt<0>();
-      pp_barrier();
-      // ---- phase 2kb+1 ----
-      if (more) issue_b(wr);
-      frag_addr(nx, 0, sa, sb);   // (behind the last block: a stale slot, read into registers nobody uses)
-      KRS_PF_PHASE(fa1, fb1, fa0, fb0)
-      pp_barrier();
-      rd = nx;
-      wr = wr + 1 == NSTG ? 0 : wr + 1;
-    }
-#undef KRS_PF_PHASE
-#undef KRS_PF_STEP
-  } else {
+  {
     // prologue (the host guarantees nkb >= NSTG): A(0), B(0), ..., A(NSTG-3), B(NSTG-3), A(NSTG-2)
   #pragma unroll
     for (int j = 0; j < NSTG - 2; ++j) {
@@ -1642,7 +1164,7 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
         p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
     return;
   }
-  if constexpr (NPFC > 0 && SCHED == 0 && KRS_PP_PROBE != 4)
+  if constexpr (NPFC > 0)
     gemm_epilogue_wave128_pre<EPI, NPFC>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split, opf);
   else
     gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
@@ -1855,15 +1377,16 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmParams p, i
   epilogue_store(p, i, j, acc);
 }
 
-// Main-loop choice for the 256x256 bf16 tiles: 0 = two-stage loops (gemm_glds256_kernel /
-// gemm_tn_glds256_kernel), 4 / 5 = ping-pong ring with that many stages (gemm_pp256_kernel).
+// Main loop of the big bf16 shapes: 4 = the four-stage ping-pong ring on 256x256 tiles (gemm_pp256_kernel, default);
+// 0 = the two-stage 128x128 kernels for every shape (gemm_glds_kernel / gemm_tn_glds_kernel / gemm_mfma_kernel) and the
+// two-call form of krs_gemm_cross_bwd -- the reference schedule for A/B and bit-for-bit tests.
 // krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, v) / environment KRS_GEMM_PIPE (read once).
 int g_pipe = -1;
 int gemm_pipe() {
   if (g_pipe < 0) {
     const char* e = getenv("KRS_GEMM_PIPE");
     g_pipe = e ? atoi(e) : 4;
-    if (g_pipe != 0 && g_pipe != 4 && g_pipe != 5 && g_pipe != 6 && g_pipe != 7) g_pipe = 4;
+    if (g_pipe != 0) g_pipe = 4;
   }
   return g_pipe;
 }
@@ -1951,92 +1474,33 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   // ... provided its 4x larger tiles still cover most of the 256 CUs (a per-rank batch of 8192 rows against
   // N = 512 is 64 such tiles: the 128x128 kernels below launch 256 workgroups instead)
   const bool fills256 = ceil_div(p.m, 256) * ceil_div(p.n, 256) >= 192;
-  if (dma_ok && p.k >= 256 && p.m >= 256 && p.n >= 256 && fills256 && !force128) {
-    const size_t lds256 = 2 * 512 * ROW_BYTES;  // 2 stages x (256 A rows + 256 B rows) x 128 B
-    const dim3 grid256((unsigned)(ceil_div(ceil_div(p.m, 256), 8) * 8 * ceil_div(p.n, 256)));
-    if constexpr (ES == 2) {
-      const int pipe = gemm_pipe();
-      // (the residual-add form with a short K -- dx = dh U^T + g -- was 4 % faster on the two-stage loop until its R
+  if constexpr (ES == 2) {
+    // the ring kernel (gemm_pp256_kernel); krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, 0) sends these shapes to the 128x128
+    // two-stage kernels below instead (same fragment layout, same k order per accumulator: bit-identical results -- the
+    // reference schedule of tests/test_dense_ops_gpu.py and scripts/exp/gemm_bench)
+    if (dma_ok && gemm_pipe() != 0 && p.k >= 256 && p.k % 32 == 0 && p.m >= 256 && p.n >= 256 && fills256 && !force128) {
+      const dim3 grid256((unsigned)(ceil_div(ceil_div(p.m, 256), 8) * 8 * ceil_div(p.n, 256)));
+      const int nt_ = (int)ceil_div(p.n, 256);
+      // (the residual-add form with a short K -- dx = dh U^T + g -- was 4 % faster on a two-stage loop until its R
       // operands were fetched under the ring's tail: 340 -> 301 us)
-      if (pipe && p.k % 32 == 0) {
-        const int nt_ = (int)ceil_div(p.n, 256);
-#define KRS_PP_LAUNCH(NS, EP, SC)                                                                    \
+#define KRS_PP_LAUNCH(EP)                                                                            \
   {                                                                                                  \
-    auto kern = gemm_pp256_kernel<false, NS, EP, SC>;                                                \
+    auto kern = gemm_pp256_kernel<false, 4, EP>;                                                     \
     static bool attr_set = false;                                                                    \
     if (!attr_set) {                                                                                 \
       KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, NS * pp::STAGE));      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * pp::STAGE));       \
       attr_set = true;                                                                               \
     }                                                                                                \
-    hipLaunchKernelGGL(kern, grid256, dim3(512), NS * pp::STAGE, st, p, 0, nt_);                     \
+    hipLaunchKernelGGL(kern, grid256, dim3(512), 4 * pp::STAGE, st, p, 0, nt_);                      \
   }
-#define KRS_PP_CASE(NS, SC)                                                                          \
-  {                                                                                                  \
-    if (epi == 1) KRS_PP_LAUNCH(NS, 1, SC)                                                           \
-    else if (epi == 2) KRS_PP_LAUNCH(NS, 2, SC)                                                      \
-    else KRS_PP_LAUNCH(NS, 0, SC)                                                                    \
-  }
-        if (pipe == 5) KRS_PP_CASE(5, 0)
-        else if (pipe == 6) KRS_PP_CASE(4, 1)
-        else KRS_PP_CASE(4, 0)
-#undef KRS_PP_CASE
+      if (epi == 1) KRS_PP_LAUNCH(1)
+      else if (epi == 2) KRS_PP_LAUNCH(2)
+      else KRS_PP_LAUNCH(0)
 #undef KRS_PP_LAUNCH
-        KRS_CHECK_LAUNCH("gemm_pp256_kernel");
-        return KRS_OK;
-      }
+      KRS_CHECK_LAUNCH("gemm_pp256_kernel");
+      return KRS_OK;
     }
-#define KRS_GLDS256_LAUNCH(EP)                                                                       \
-  {                                                                                                  \
-    auto kern = gemm_glds256_kernel<ES, EP>;                                                         \
-    static bool attr_set = false;                                                                    \
-    if (!attr_set) {                                                                                 \
-      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds256));         \
-      attr_set = true;                                                                               \
-    }                                                                                                \
-    hipLaunchKernelGGL(kern, grid256, dim3(512), lds256, st, p);                                     \
-  }
-    if (epi == 1) KRS_GLDS256_LAUNCH(1)
-    else if (epi == 2) KRS_GLDS256_LAUNCH(2)
-    else KRS_GLDS256_LAUNCH(0)
-#undef KRS_GLDS256_LAUNCH
-    KRS_CHECK_LAUNCH("gemm_glds256_kernel");
-    return KRS_OK;
-  }
-  if (use_glds && ES == 2 && gemm_pipe() == 7 && p.k % 32 == 0 && p.k / 32 >= 8) {
-    // (krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, 7): A/B only.)  The deep ring on the 128x128 tile -- one workgroup per
-    // CU with eight stages while the tiles fit one round of the 256 CUs, two per CU with four stages beyond -- measured
-    // EQUAL or slower than the two-stage kernel below (profiles/r4_gemm_ring128_b8192.txt: h = x U at M = 8192 47.2 us
-    // against 44.9, at M = 16384 77.8 against 64.7): a CU with one 128x128 tile already draws its operands at the
-    // ~40 GB/s per CU of the L2 -> LDS path that bounds the 256x256 kernels too, and the two-stage kernel's 128-byte
-    // row pieces are whole cache lines where the ring's 64-byte pieces are halves.  Not dispatched.
-    const int64_t tiles = ceil_div(p.m, BM) * ceil_div(p.n, BN);
-#define KRS_RING128_LAUNCH(NS, EP)                                                                   \
-  {                                                                                                  \
-    auto kern = gemm_ring128_kernel<NS, EP>;                                                         \
-    static bool attr_set = false;                                                                    \
-    if (!attr_set) {                                                                                 \
-      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, NS * 16384));          \
-      attr_set = true;                                                                               \
-    }                                                                                                \
-    hipLaunchKernelGGL(kern, grid, dim3(256), NS * 16384, st, p);                                    \
-  }
-#define KRS_RING128_CASE(NS)                                                                         \
-  {                                                                                                  \
-    if (epi == 1) KRS_RING128_LAUNCH(NS, 1)                                                          \
-    else if (epi == 2) KRS_RING128_LAUNCH(NS, 2)                                                     \
-    else KRS_RING128_LAUNCH(NS, 0)                                                                   \
-  }
-    if constexpr (ES == 2) {
-      if (tiles <= 320) KRS_RING128_CASE(8)
-      else KRS_RING128_CASE(4)
-    }
-#undef KRS_RING128_CASE
-#undef KRS_RING128_LAUNCH
-    KRS_CHECK_LAUNCH("gemm_ring128_kernel");
-    return KRS_OK;
   }
   if (use_glds) {
     const size_t glds_lds = 4 * BM * ROW_BYTES;  // 2 stages x (A + B) x 16 KB
@@ -2063,39 +1527,18 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
       p.m % 8 == 0 && p.n % 8 == 0) {
     // development switch: the 128 x 128 twin (4 waves, <= 128 VGPRs, 64 KB of LDS: half a CU) for every shape
     static const bool tn128 = getenv("KRS_GEMM_TN128") != nullptr;
-    if (p.m >= 256 && p.n >= 256 && !tn128) {
+    if (p.m >= 256 && p.n >= 256 && !tn128 && gemm_pipe() != 0 && p.k_per_split >= 256) {
       const int mt_ = (int)ceil_div(p.m, 256), nt_ = (int)ceil_div(p.n, 256);
       const dim3 grid_tn((unsigned)(ceil_div((int64_t)p.splits * mt_ * nt_, 8) * 8));
-      const int pipe = gemm_pipe();
-      if (pipe && p.k_per_split >= 256) {
-#define KRS_PP_TN_LAUNCH(NS, SC)                                                                     \
-  {                                                                                                  \
-    auto kern = gemm_pp256_kernel<true, NS, 0, SC>;                                                  \
-    static bool attr_set = false;                                                                    \
-    if (!attr_set) {                                                                                 \
-      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, NS * pp::STAGE));      \
-      attr_set = true;                                                                               \
-    }                                                                                                \
-    hipLaunchKernelGGL(kern, grid_tn, dim3(512), NS * pp::STAGE, st, p, mt_, nt_);                   \
-  }
-        if (pipe == 5) KRS_PP_TN_LAUNCH(5, 0)
-        else if (pipe == 6) KRS_PP_TN_LAUNCH(4, 1)
-        else KRS_PP_TN_LAUNCH(4, 0)
-#undef KRS_PP_TN_LAUNCH
-        KRS_CHECK_LAUNCH("gemm_pp256_kernel (K-strided operands)");
-        return KRS_OK;
-      }
-      const size_t lds_tn = 2 * 2 * 64 * 256 * 2;  // 2 stages x (A + B) x 32 KB
-      auto kern = gemm_tn_glds256_kernel<0>;
+      auto kern = gemm_pp256_kernel<true, 4, 0>;
       static bool attr_set = false;
       if (!attr_set) {
         KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_tn));
+                                    4 * pp::STAGE));
         attr_set = true;
       }
-      hipLaunchKernelGGL(kern, grid_tn, dim3(512), lds_tn, st, p, mt_, nt_);
-      KRS_CHECK_LAUNCH("gemm_tn_glds256_kernel");
+      hipLaunchKernelGGL(kern, grid_tn, dim3(512), 4 * pp::STAGE, st, p, mt_, nt_);
+      KRS_CHECK_LAUNCH("gemm_pp256_kernel (K-strided operands)");
       return KRS_OK;
     }
     const int mt_ = (int)ceil_div(p.m, BM), nt_ = (int)ceil_div(p.n, BN);
@@ -2121,298 +1564,6 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   return KRS_OK;
 }
 
-// ---- elementwise kernels ------------------------------------------------------
-struct CrossParams {
-  const void* g; const void* u; const void* x0; const void* x;
-  void* y; void* du; void* dx0; void* dxd; float* dbias;
-  float* partial;   // [row groups][n] partial column sums (workspace) -> colsum_finish_kernel; null: fp32 atomics on dbias
-  int dx0_acc;
-  int64_t m, n, ld;
-  float diag;
-  int act;
-  int dtype;
-};
-
-
-// one thread per 8 columns; rows strided by gridDim.y*ROWS_PER_BLOCK
-template <typename T, int V>
-struct RowVec;  // V contiguous elements <-> fp32
-template <>
-struct RowVec<float, 4> {
-  typedef float4 raw_t;
-  static __device__ __forceinline__ raw_t load_raw(const void* p, int64_t o) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + o);
-  }
-  static __device__ __forceinline__ void unpack(const raw_t& v, float (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
-  static __device__ __forceinline__ void load(const void* p, int64_t o, float (&f)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + o);
-    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-  }
-  static __device__ __forceinline__ void store(void* p, int64_t o, const float (&f)[4]) {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p) + o) = make_float4(f[0], f[1], f[2], f[3]);
-  }
-};
-template <>
-struct RowVec<uint16_t, 8> {
-  typedef uint4 raw_t;
-  static __device__ __forceinline__ raw_t load_raw(const void* p, int64_t o) {
-    return *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + o);
-  }
-  static __device__ __forceinline__ void unpack(const raw_t& r, float (&f)[8]) {
-    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
-    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
-    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
-    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
-  }
-  static __device__ __forceinline__ void load(const void* p, int64_t o, float (&f)[8]) {
-    const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p) + o);
-    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
-    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
-    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
-    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
-  }
-  // (plain accesses: non-temporal ones made these streaming passes 10-15 % slower)
-  static __device__ __forceinline__ void store(void* p, int64_t o, const float (&f)[8]) {
-    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p) + o) =
-        make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
-                   pack_bf16x2(f[6], f[7]));
-  }
-};
-
-template <typename T, int V>
-__global__ __launch_bounds__(256) void cross_fwd_vec_kernel(const CrossParams p) {
-  const int64_t nv = p.n / V;
-  const int64_t total = p.m * nv;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int64_t i = idx / nv, o = i * p.ld + (idx - i * nv) * V;
-    float u[V], x0[V], x[V], y[V];
-    RowVec<T, V>::load(p.u, o, u);
-    RowVec<T, V>::load(p.x0, o, x0);
-    RowVec<T, V>::load(p.x, o, x);
-#pragma unroll
-    for (int k = 0; k < V; ++k) y[k] = x0[k] * (u[k] + p.diag * x[k]) + x[k];
-    RowVec<T, V>::store(p.y, o, y);
-  }
-}
-
-__global__ __launch_bounds__(256) void cross_fwd_scalar_kernel(const CrossParams p) {
-  const int64_t total = p.m * p.n;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int64_t i = idx / p.n, o = i * p.ld + (idx - i * p.n);
-    const float xv = ld_elem(p.x, p.dtype, o);
-    st_elem(p.y, p.dtype, o, ld_elem(p.x0, p.dtype, o) * (ld_elem(p.u, p.dtype, o) + p.diag * xv) + xv);
-  }
-}
-
-// Backward: grid = (column strips of 64*V, groups of four row chunks).  Each thread owns V columns
-// and walks the rows of its wave's chunk, so the bias gradient is a per-thread register sum; the four
-// waves of a workgroup add theirs in LDS and issue one lane-contiguous atomic per column (with one
-// atomic per thread and chunk, ~600 chunks queued on the same cache lines of dbias and the kernel took
-// 156 us for 8192 rows where the rows themselves need 60).
-template <typename T, int V, bool ACC>  // ACC: dx0 already holds the terms of the layers above (dx0_accumulate)
-__global__ __launch_bounds__(256) void cross_bwd_vec_kernel(const CrossParams p, int rows_per_block) {
-  __shared__ float red[4][64 * V];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool live = ((int64_t)blockIdx.x * 64 + lane) * V < p.n;
-  const int64_t col = live ? ((int64_t)blockIdx.x * 64 + lane) * V : 0;  // idle lanes prefetch column 0, store nothing
-  const int64_t r0 = ((int64_t)blockIdx.y * 4 + wave) * rows_per_block;
-  const int64_t r1 = min(p.m, r0 + rows_per_block);
-  const int64_t rend = live ? r1 : r0;
-  const bool fold = p.dxd == p.dx0;  // x is x0: the direct term lands in dx0 as well
-  float db[V];
-#pragma unroll
-  for (int k = 0; k < V; ++k) db[k] = 0.0f;
-  // two rows of g / x0 / u are kept in flight ahead of the row being processed (clamped row index:
-  // the loads are unconditional)
-  typedef typename RowVec<T, V>::raw_t raw_t;
-#ifndef KRS_CB_AHEAD
-#define KRS_CB_AHEAD 2      // (development builds vary it: 3 and 4 measured equal, profiles/r4y_cross_bwd_ahead.txt)
-#endif
-  constexpr int AHEAD = KRS_CB_AHEAD;
-  raw_t rg[AHEAD], rx0[AHEAD], ru[AHEAD], racc[AHEAD];
-  const void* usrc = p.u ? p.u : p.g;  // without u the value is ignored below
-  // the running dL/dx0 of the layers above is read ahead like the other streams (a template parameter, not a
-  // branch: a load behind a run-time condition makes hipcc drain the load queue, 454 -> 550 us)
-#pragma unroll
-  for (int a = 0; a < AHEAD; ++a) {
-    const int64_t oa = min(r0 + a, r1 - 1) * p.ld + col;
-    rg[a] = RowVec<T, V>::load_raw(p.g, oa);
-    rx0[a] = RowVec<T, V>::load_raw(p.x0, oa);
-    ru[a] = RowVec<T, V>::load_raw(usrc, oa);
-    if constexpr (ACC) racc[a] = RowVec<T, V>::load_raw(p.dx0, oa);
-    else racc[a] = rg[a];
-  }
-  for (int64_t i = r0; i < rend; ++i) {
-    const int64_t o = i * p.ld + col;
-    float g[V], u[V], x0[V], x[V], gx0[V], dz[V], t[V];
-    RowVec<T, V>::unpack(rg[0], g);
-    RowVec<T, V>::unpack(rx0[0], x0);
-    RowVec<T, V>::unpack(ru[0], u);
-    RowVec<T, V>::unpack(racc[0], t);
-    if (!p.u) {
-#pragma unroll
-      for (int k = 0; k < V; ++k) u[k] = 0.0f;
-    }
-#pragma unroll
-    for (int a = 0; a + 1 < AHEAD; ++a) { rg[a] = rg[a + 1]; rx0[a] = rx0[a + 1]; ru[a] = ru[a + 1]; racc[a] = racc[a + 1]; }
-    {
-      const int64_t on = min(i + AHEAD, r1 - 1) * p.ld + col;
-      rg[AHEAD - 1] = RowVec<T, V>::load_raw(p.g, on);
-      rx0[AHEAD - 1] = RowVec<T, V>::load_raw(p.x0, on);
-      ru[AHEAD - 1] = RowVec<T, V>::load_raw(usrc, on);
-      if constexpr (ACC) racc[AHEAD - 1] = RowVec<T, V>::load_raw(p.dx0, on);
-      else racc[AHEAD - 1] = rg[AHEAD - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      gx0[k] = g[k] * x0[k];
-      dz[k] = gx0[k] * act_grad_from_output(p.act, u[k]);
-      db[k] += dz[k];
-    }
-    if (p.du) RowVec<T, V>::store(p.du, o, dz);
-    if (p.dx0) {
-      if (p.diag != 0.0f) {  // x only enters through diag_scale: do not read 2 bytes per element for a zero
-        RowVec<T, V>::load(p.x, o, x);
-      } else {
-#pragma unroll
-        for (int k = 0; k < V; ++k) x[k] = 0.0f;
-      }
-#pragma unroll
-      for (int k = 0; k < V; ++k) {
-        t[k] = __builtin_fmaf(g[k], __builtin_fmaf(p.diag, x[k], u[k]), ACC ? t[k] : 0.0f);
-        if (fold) t[k] += g[k] + p.diag * gx0[k];
-      }
-      RowVec<T, V>::store(p.dx0, o, t);
-    }
-    if (p.dxd && !fold) {
-#pragma unroll
-      for (int k = 0; k < V; ++k) t[k] = g[k] + p.diag * gx0[k];
-      RowVec<T, V>::store(p.dxd, o, t);
-    }
-  }
-  if (p.dbias) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) red[wave][lane * V + k] = db[k];
-    __syncthreads();
-    for (int c = threadIdx.x; c < 64 * V; c += 256) {
-      const int64_t cc = (int64_t)blockIdx.x * 64 * V + c;
-      const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-      if (cc < p.n) {
-        if (p.partial) p.partial[(int64_t)blockIdx.y * p.n + cc] = s;
-        else atomicAdd(p.dbias + cc, s);
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(64) void cross_bwd_scalar_kernel(const CrossParams p, int rows_per_block) {
-  const int64_t col = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (col >= p.n) return;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-  const int64_t r1 = min(p.m, r0 + rows_per_block);
-  float db = 0.0f;
-  for (int64_t i = r0; i < r1; ++i) {
-    const int64_t o = i * p.ld + col;
-    const float g = ld_elem(p.g, p.dtype, o);
-    const float gx0 = g * ld_elem(p.x0, p.dtype, o);
-    const float uv = p.u ? ld_elem(p.u, p.dtype, o) : 0.0f;
-    const float dz = gx0 * act_grad_from_output(p.act, uv);
-    db += dz;
-    if (p.du) st_elem(p.du, p.dtype, o, dz);
-    const bool fold = p.dxd == p.dx0;
-    if (p.dx0) {
-      const float uf = uv + p.diag * ld_elem(p.x, p.dtype, o);
-      float t = (p.dx0_acc ? ld_elem(p.dx0, p.dtype, o) : 0.0f) + g * uf;
-      if (fold) t += g + p.diag * gx0;
-      st_elem(p.dx0, p.dtype, o, t);
-    }
-    if (p.dxd && !fold) st_elem(p.dxd, p.dtype, o, g + p.diag * gx0);
-  }
-  if (p.dbias) {
-    if (p.partial) p.partial[(int64_t)blockIdx.y * p.n + col] = db;
-    else atomicAdd(p.dbias + col, db);
-  }
-}
-
-__global__ __launch_bounds__(64) void colsum_kernel(const void* a, int64_t lda, int64_t m, int64_t n, int dtype,
-                                                    float* out, float* partial, int rows_per_block) {
-  const int64_t col = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (col >= n) return;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-  const int64_t r1 = min(m, r0 + rows_per_block);
-  float s = 0.0f;
-  for (int64_t i = r0; i < r1; ++i) s += ld_elem(a, dtype, i * lda + col);
-  if (partial) partial[(int64_t)blockIdx.y * n + col] = s;
-  else atomicAdd(out + col, s);
-}
-
-// Second half of the deterministic column sums (bias gradients): out[c] = sum over the row groups of partial[g][c] in a
-// FIXED order -- the grouping depends on (m, n) alone, so the fp32 result is the same bits on every run (with the atomics
-// of the workspace-free form the order of the additions, and the last bits, varied from run to run).  A workgroup owns 32
-// columns; its 32 slices (one half wave each) sum contiguous runs of groups in ascending order, four independent loads
-// in flight, and the slice sums are added in slice order.  (One thread per column walking all groups -- the first
-// version -- took 40-500 us: up to 1024 dependent loads per thread and a handful of workgroups.)
-__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* partial, int64_t groups, int64_t n, float* out) {
-  __shared__ float red[32][33];
-  const int c = threadIdx.x & 31, s = threadIdx.x >> 5;
-  const int64_t col = (int64_t)blockIdx.x * 32 + c;
-  float acc = 0.0f;
-  if (col < n) {
-    const int64_t per = (groups + 31) / 32;
-    const int64_t g0 = (int64_t)s * per, g1 = min(groups, g0 + per);
-    int64_t g = g0;
-    for (; g + 4 <= g1; g += 4) {
-      const float a0 = partial[g * n + col], a1 = partial[(g + 1) * n + col];
-      const float a2 = partial[(g + 2) * n + col], a3 = partial[(g + 3) * n + col];
-      acc += a0; acc += a1; acc += a2; acc += a3;
-    }
-    for (; g < g1; ++g) acc += partial[g * n + col];
-  }
-  red[s][c] = acc;
-  __syncthreads();
-  if (s == 0 && col < n) {
-    float t = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) t += red[i][c];
-    out[col] = t;
-  }
-}
-
-// row chunks of the column-sum walks: enough to fill the chip, few enough to keep the second stage cheap
-struct ColChunks {
-  int rows_per_block;
-  int64_t chunks;      // = grid.y of the scalar kernels
-  int64_t groups4;     // = grid.y of the vector kernels (four chunks, one per wave, per workgroup)
-};
-ColChunks col_chunks(int64_t m, int64_t cols) {
-  const int64_t strips = ceil_div(cols, 64);
-  int64_t chunks = ceil_div(4096, strips);
-  if (chunks > m) chunks = m;
-  ColChunks c;
-  c.rows_per_block = (int)ceil_div(m, chunks);
-  c.chunks = ceil_div(m, c.rows_per_block);
-  c.groups4 = ceil_div(c.chunks, 4);
-  return c;
-}
-// groups of partial sums the launch will write for an [m, n] operand walked V columns per thread
-int64_t colsum_groups(int64_t m, int64_t n, int v) {
-  if (m <= 0 || n <= 0) return 0;
-  const ColChunks c = col_chunks(m, v > 1 ? n / v : n);
-  return v > 1 ? c.groups4 : c.chunks;
-}
-int finish_colsum(float* partial, int64_t groups, int64_t n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)ceil_div(n, 32)), dim3(1024), 0, st, partial, groups, n, out);
-  KRS_CHECK_LAUNCH("colsum_finish_kernel");
-  return KRS_OK;
-}
-
-bool vec_ok(const CrossParams& p, int v, std::initializer_list<const void*> ptrs) {
-  if (p.n % v || p.ld % v) return false;
-  for (const void* q : ptrs)
-    if (q && (reinterpret_cast<uintptr_t>(q) & 15)) return false;
-  return true;
-}
-
 }  // namespace
 }  // namespace krs
 
@@ -2420,7 +1571,7 @@ using namespace krs;
 
 extern "C" int krs_gemm_set_option(int key, int value) {
   if (key == KRS_GEMM_OPT_PIPELINE) {
-    KRS_REQUIRE(value == 0 || (value >= 4 && value <= 7), "krs_gemm_set_option: pipeline must be 0, 4, 5, 6 or 7");
+    KRS_REQUIRE(value == 0 || value == 4, "krs_gemm_set_option: pipeline must be 0 or 4");
     g_pipe = value;
     return KRS_OK;
   }
@@ -2536,76 +1687,6 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
   return KRS_OK;
 }
 
-extern "C" int krs_cross_epilogue_fwd(const void* u, const void* x0, const void* x, void* y, int64_t m,
-                                      int64_t n, int64_t ld, float diag_scale, int dtype, void* stream) {
-  KRS_REQUIRE(u && x0 && x && y, "cross_epilogue_fwd: null operand");
-  KRS_REQUIRE(m >= 0 && n >= 0 && ld >= n, "cross_epilogue_fwd: bad sizes");
-  if (m == 0 || n == 0) return KRS_OK;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  CrossParams p{};
-  p.u = u; p.x0 = x0; p.x = x; p.y = y; p.m = m; p.n = n; p.ld = ld; p.diag = diag_scale; p.dtype = dtype;
-  const int v = dtype == KRS_BF16 ? 8 : 4;
-  const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(m * n / (vec_ok(p, v, {u, x0, x, y}) ? v : 1), 256), 16384);
-  if (vec_ok(p, v, {u, x0, x, y})) {
-    if (dtype == KRS_BF16)
-      hipLaunchKernelGGL((cross_fwd_vec_kernel<uint16_t, 8>), dim3(blocks), dim3(256), 0, st, p);
-    else
-      hipLaunchKernelGGL((cross_fwd_vec_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, p);
-  } else {
-    hipLaunchKernelGGL(cross_fwd_scalar_kernel, dim3(blocks), dim3(256), 0, st, p);
-  }
-  KRS_CHECK_LAUNCH("cross_fwd_kernel");
-  return KRS_OK;
-}
-
-extern "C" size_t krs_colsum_workspace_bytes(int64_t m, int64_t n) {
-  if (m <= 0 || n <= 0) return 0;
-  int64_t g = colsum_groups(m, n, 1);
-  if (n % 4 == 0) g = std::max(g, colsum_groups(m, n, 4));
-  if (n % 8 == 0) g = std::max(g, colsum_groups(m, n, 8));
-  return (size_t)g * (size_t)n * sizeof(float);
-}
-
-extern "C" int krs_cross_epilogue_bwd(const void* g, const void* u, const void* x0, const void* x, void* du,
-                                      void* dx0, int dx0_accumulate, void* dxd, float* dbias, int64_t m,
-                                      int64_t n, int64_t ld, float diag_scale, int act, int dtype,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
-  KRS_REQUIRE(g && x0, "cross_epilogue_bwd: null g/x0");
-  KRS_REQUIRE(act == KRS_ACT_NONE || u, "cross_epilogue_bwd: an activation needs the saved u");
-  KRS_REQUIRE(!dx0 || (u && x), "cross_epilogue_bwd: dx0 needs u and x");
-  KRS_REQUIRE(m >= 0 && n >= 0 && ld >= n, "cross_epilogue_bwd: bad sizes");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool two_stage = dbias && workspace && m > 0 && n > 0;
-  if (two_stage) KRS_REQUIRE(workspace_bytes >= krs_colsum_workspace_bytes(m, n), "cross_epilogue_bwd: workspace too small");
-  if (dbias && !two_stage) KRS_HIP(hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), st));
-  if (m == 0 || n == 0) return KRS_OK;
-  CrossParams p{};
-  p.g = g; p.u = u; p.x0 = x0; p.x = x; p.du = du; p.dx0 = dx0; p.dxd = dxd; p.dbias = dbias;
-  p.partial = two_stage ? reinterpret_cast<float*>(workspace) : nullptr;
-  p.dx0_acc = dx0_accumulate; p.m = m; p.n = n; p.ld = ld; p.diag = diag_scale; p.act = act; p.dtype = dtype;
-  const int v = dtype == KRS_BF16 ? 8 : 4;
-  const bool vec = vec_ok(p, v, {g, u, x0, x, du, dx0, dxd});
-  const ColChunks cc = col_chunks(m, vec ? n / v : n);
-  const int64_t strips = ceil_div(vec ? n / v : n, 64);
-  const int rows_per_block = cc.rows_per_block;
-  if (vec) {
-    const dim3 grid4((unsigned)strips, (unsigned)cc.groups4);  // four chunks per workgroup
-    const bool acc = p.dx0 && p.dx0_acc;
-    if (dtype == KRS_BF16) {
-      if (acc) hipLaunchKernelGGL((cross_bwd_vec_kernel<uint16_t, 8, true>), grid4, dim3(256), 0, st, p, rows_per_block);
-      else hipLaunchKernelGGL((cross_bwd_vec_kernel<uint16_t, 8, false>), grid4, dim3(256), 0, st, p, rows_per_block);
-    } else {
-      if (acc) hipLaunchKernelGGL((cross_bwd_vec_kernel<float, 4, true>), grid4, dim3(256), 0, st, p, rows_per_block);
-      else hipLaunchKernelGGL((cross_bwd_vec_kernel<float, 4, false>), grid4, dim3(256), 0, st, p, rows_per_block);
-    }
-  } else {
-    hipLaunchKernelGGL(cross_bwd_scalar_kernel, dim3((unsigned)strips, (unsigned)cc.chunks), dim3(64), 0, st, p, rows_per_block);
-  }
-  KRS_CHECK_LAUNCH("cross_bwd_kernel");
-  if (two_stage) return finish_colsum(p.partial, vec ? cc.groups4 : cc.chunks, n, dbias, st);
-  return KRS_OK;
-}
-
 // ---- krs_gemm_cross_bwd: data-gradient product + the elementwise backward of the layer below, one launch ---------------
 extern "C" size_t krs_gemm_cross_bwd_workspace_bytes(int64_t m, int64_t n) {
   if (m <= 0 || n <= 0) return 0;
@@ -2665,7 +1746,7 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
   const dim3 grid256((unsigned)(ceil_div(ceil_div(m, 256), 8) * 8 * nt_));
 #define KRS_CB_LAUNCH(EP)                                                                              \
   {                                                                                                    \
-    auto kern = gemm_pp256_kernel<false, 4, EP, 0>;                                                    \
+    auto kern = gemm_pp256_kernel<false, 4, EP>;                                                       \
     static bool attr_set = false;                                                                      \
     if (!attr_set) {                                                                                   \
       KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
@@ -2686,316 +1767,5 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
 #undef KRS_CB_LAUNCH
   KRS_CHECK_LAUNCH("gemm_pp256_kernel (fused cross backward)");
   if (dbias) return finish_colsum(p.f_partial, 2 * ceil_div(m, 256), n, dbias, st);
-  return KRS_OK;
-}
-
-// Backward of a Dense layer's bias + activation epilogue: dz = g * act'(y) from the saved OUTPUT y, and
-// dbias = column sums of dz (fp32, of the unrounded products), in one pass (it was a compare, a cast, a multiply
-// and a separate column-sum launch per layer).  Same walk as cross_bwd_vec_kernel: a thread owns V columns and
-// walks the rows of its wave's chunk with two rows of loads in flight.
-struct DenseBwdParams {
-  const void* g;
-  const void* y;
-  void* dz;
-  float* dbias;
-  float* partial;   // as CrossParams::partial
-  int64_t m, n, ldg, ldy, ldz;
-  int act, dtype;
-};
-template <typename T, int V>
-__global__ __launch_bounds__(256) void dense_act_bwd_vec_kernel(const DenseBwdParams p, int rows_per_block) {
-  __shared__ float red[4][64 * V];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool live = ((int64_t)blockIdx.x * 64 + lane) * V < p.n;
-  const int64_t col = live ? ((int64_t)blockIdx.x * 64 + lane) * V : 0;
-  const int64_t r0 = ((int64_t)blockIdx.y * 4 + wave) * rows_per_block;
-  const int64_t r1 = min(p.m, r0 + rows_per_block);
-  const int64_t rend = live ? r1 : r0;
-  float db[V];
-#pragma unroll
-  for (int k = 0; k < V; ++k) db[k] = 0.0f;
-  typedef typename RowVec<T, V>::raw_t raw_t;
-  constexpr int AHEAD = 2;
-  raw_t rg[AHEAD], ry[AHEAD];
-  const void* ysrc = p.y ? p.y : p.g;   // no activation: the value is ignored
-  const int64_t ldy = p.y ? p.ldy : p.ldg;
-#pragma unroll
-  for (int a = 0; a < AHEAD; ++a) {
-    const int64_t ra = max(min(r0 + a, r1 - 1), (int64_t)0);
-    rg[a] = RowVec<T, V>::load_raw(p.g, ra * p.ldg + col);
-    ry[a] = RowVec<T, V>::load_raw(ysrc, ra * ldy + col);
-  }
-  for (int64_t i = r0; i < rend; ++i) {
-    float g[V], y[V], dz[V];
-    RowVec<T, V>::unpack(rg[0], g);
-    RowVec<T, V>::unpack(ry[0], y);
-#pragma unroll
-    for (int a = 0; a + 1 < AHEAD; ++a) { rg[a] = rg[a + 1]; ry[a] = ry[a + 1]; }
-    {
-      const int64_t rn = min(i + AHEAD, r1 - 1);
-      rg[AHEAD - 1] = RowVec<T, V>::load_raw(p.g, rn * p.ldg + col);
-      ry[AHEAD - 1] = RowVec<T, V>::load_raw(ysrc, rn * ldy + col);
-    }
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      dz[k] = g[k] * act_grad_from_output(p.act, y[k]);
-      db[k] += dz[k];
-    }
-    if (p.dz) RowVec<T, V>::store(p.dz, i * p.ldz + col, dz);
-  }
-  if (p.dbias) {
-#pragma unroll
-    for (int k = 0; k < V; ++k) red[wave][lane * V + k] = db[k];
-    __syncthreads();
-    for (int c = threadIdx.x; c < 64 * V; c += 256) {
-      const int64_t cc = (int64_t)blockIdx.x * 64 * V + c;
-      const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-      if (cc < p.n) {
-        if (p.partial) p.partial[(int64_t)blockIdx.y * p.n + cc] = s;
-        else atomicAdd(p.dbias + cc, s);
-      }
-    }
-  }
-}
-__global__ __launch_bounds__(64) void dense_act_bwd_scalar_kernel(const DenseBwdParams p, int rows_per_block) {
-  const int64_t col = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (col >= p.n) return;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(p.m, r0 + rows_per_block);
-  float db = 0.0f;
-  for (int64_t i = r0; i < r1; ++i) {
-    const float yv = p.y ? ld_elem(p.y, p.dtype, i * p.ldy + col) : 0.0f;
-    const float dz = ld_elem(p.g, p.dtype, i * p.ldg + col) * act_grad_from_output(p.act, yv);
-    db += dz;
-    if (p.dz) st_elem(p.dz, p.dtype, i * p.ldz + col, dz);
-  }
-  if (p.dbias) {
-    if (p.partial) p.partial[(int64_t)blockIdx.y * p.n + col] = db;
-    else atomicAdd(p.dbias + col, db);
-  }
-}
-
-extern "C" int krs_dense_act_bwd(const void* g, int64_t ld_g, const void* y, int64_t ld_y, void* dz, int64_t ld_dz,
-                                 float* dbias, int64_t m, int64_t n, int act, int dtype, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-  KRS_REQUIRE(g && (dz || dbias), "dense_act_bwd: null operand");
-  KRS_REQUIRE(act == KRS_ACT_NONE || y, "dense_act_bwd: an activation needs the saved output y");
-  KRS_REQUIRE(m >= 0 && n >= 0 && ld_g >= n && (!y || ld_y >= n) && (!dz || ld_dz >= n), "dense_act_bwd: bad sizes");
-  KRS_REQUIRE(dtype == KRS_F32 || dtype == KRS_BF16, "dense_act_bwd: dtype must be f32 or bf16");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool two_stage = dbias && workspace && m > 0 && n > 0;
-  if (two_stage) KRS_REQUIRE(workspace_bytes >= krs_colsum_workspace_bytes(m, n), "dense_act_bwd: workspace too small");
-  if (dbias && !two_stage) KRS_HIP(hipMemsetAsync(dbias, 0, (size_t)n * sizeof(float), st));
-  if (m == 0 || n == 0) return KRS_OK;
-  DenseBwdParams p{g, y, dz, dbias, two_stage ? reinterpret_cast<float*>(workspace) : nullptr, m, n, ld_g, ld_y, ld_dz, act, dtype};
-  const int v = dtype == KRS_BF16 ? 8 : 4;
-  bool vec = n % v == 0 && ld_g % v == 0 && (!y || ld_y % v == 0) && (!dz || ld_dz % v == 0);
-  for (const void* q : {g, y, (const void*)dz}) vec = vec && reinterpret_cast<uintptr_t>(q) % 16 == 0;
-  const ColChunks cc = col_chunks(m, vec ? n / v : n);
-  const int64_t strips = ceil_div(vec ? n / v : n, 64);
-  if (vec) {
-    const dim3 grid4((unsigned)strips, (unsigned)cc.groups4);
-    if (dtype == KRS_BF16) hipLaunchKernelGGL((dense_act_bwd_vec_kernel<uint16_t, 8>), grid4, dim3(256), 0, st, p, cc.rows_per_block);
-    else hipLaunchKernelGGL((dense_act_bwd_vec_kernel<float, 4>), grid4, dim3(256), 0, st, p, cc.rows_per_block);
-  } else {
-    hipLaunchKernelGGL(dense_act_bwd_scalar_kernel, dim3((unsigned)strips, (unsigned)cc.chunks), dim3(64), 0, st, p,
-                       cc.rows_per_block);
-  }
-  KRS_CHECK_LAUNCH("dense_act_bwd_kernel");
-  if (two_stage) return finish_colsum(p.partial, vec ? cc.groups4 : cc.chunks, n, dbias, st);
-  return KRS_OK;
-}
-
-// Weight preparation of a Dense / FeatureCross step: dst = cast(src) and dst_t = cast(src)^T in one pass over
-// a 64 x 64 tile staged in LDS (padded rows: conflict-free in both directions).  The weights are a few MB, so
-// the separate cast + transposed copy of every step were launch-bound (four ~16 us launches per cross layer).
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const void* src, int64_t rows, int64_t cols, int64_t lds_,
-                                                             int src_dtype, void* dst, int64_t ldd, void* dst_t,
-                                                             int64_t ldt, int dst_dtype) {
-  __shared__ float tile[64][65];
-  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int64_t r = r0 + ty * 16 + k, c = c0 + tx;
-    if (r < rows && c < cols) {
-      const float v = ld_elem(src, src_dtype, r * lds_ + c);
-      tile[ty * 16 + k][tx] = v;
-      if (dst) st_elem(dst, dst_dtype, r * ldd + c, v);
-    }
-  }
-  if (!dst_t) return;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int64_t c = c0 + ty * 16 + k, r = r0 + tx;   // dst_t[c][r] = src[r][c]
-    if (r < rows && c < cols) st_elem(dst_t, dst_dtype, c * ldt + r, tile[tx][ty * 16 + k]);
-  }
-}
-
-// Several weights in ONE launch (the per-step bf16 copies of every dense kernel, refreshed right behind the optimizer
-// step: six launch-bound 15 us kernels per FeatureCross stack become one).  Contiguous sources and outputs.
-constexpr int kCastMax = 32;
-struct CastManyArgs {
-  const void* src[kCastMax];
-  void* dst[kCastMax];
-  void* dst_t[kCastMax];
-  int32_t rows[kCastMax], cols[kCastMax];
-  int32_t tile_end[kCastMax];    // inclusive prefix of the tensors' 64 x 64 tile counts
-  int count, src_dtype, dst_dtype;
-};
-__global__ __launch_bounds__(256) void cast_transpose_many_kernel(const CastManyArgs a) {
-  __shared__ float tile[64][65];
-  int t = 0;
-  while (t + 1 < a.count && (int)blockIdx.x >= a.tile_end[t]) ++t;
-  const void* src = nullptr; void* dst = nullptr; void* dst_t = nullptr; int64_t rows = 0, cols = 0; int first = 0;
-#pragma unroll
-  for (int i = 0; i < kCastMax; ++i)   // static kernarg indices
-    if (i == t) { src = a.src[i]; dst = a.dst[i]; dst_t = a.dst_t[i]; rows = a.rows[i]; cols = a.cols[i]; first = i ? a.tile_end[i - 1] : 0; }
-  const int tiles_x = (int)ceil_div(cols, 64);
-  const int tid = (int)blockIdx.x - first;
-  const int64_t r0 = (int64_t)(tid / tiles_x) * 64, c0 = (int64_t)(tid % tiles_x) * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int64_t r = r0 + ty * 16 + k, c = c0 + tx;
-    if (r < rows && c < cols) {
-      const float v = ld_elem(src, a.src_dtype, r * cols + c);
-      tile[ty * 16 + k][tx] = v;
-      if (dst) st_elem(dst, a.dst_dtype, r * cols + c, v);
-    }
-  }
-  if (!dst_t) return;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int64_t c = c0 + ty * 16 + k, r = r0 + tx;   // dst_t[c][r] = src[r][c]
-    if (r < rows && c < cols) st_elem(dst_t, a.dst_dtype, c * rows + r, tile[tx][ty * 16 + k]);
-  }
-}
-
-extern "C" int krs_cast_transpose_many(int count, const void* const* srcs, const int64_t* rows, const int64_t* cols,
-                                       int src_dtype, void* const* dsts, void* const* dst_ts, int dst_dtype, void* stream) {
-  KRS_REQUIRE(count >= 0 && (count == 0 || (srcs && rows && cols && dsts && dst_ts)), "cast_transpose_many: null list");
-  KRS_REQUIRE((src_dtype == KRS_F32 || src_dtype == KRS_BF16) && (dst_dtype == KRS_F32 || dst_dtype == KRS_BF16),
-              "cast_transpose_many: dtype must be f32 or bf16");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  for (int lo = 0; lo < count; lo += kCastMax) {
-    CastManyArgs a{};
-    a.count = std::min(kCastMax, count - lo);
-    a.src_dtype = src_dtype; a.dst_dtype = dst_dtype;
-    int tiles = 0;
-    for (int i = 0; i < a.count; ++i) {
-      KRS_REQUIRE(srcs[lo + i] && (dsts[lo + i] || dst_ts[lo + i]) && rows[lo + i] > 0 && cols[lo + i] > 0 &&
-                      rows[lo + i] < 0x7fffffff && cols[lo + i] < 0x7fffffff, "cast_transpose_many: bad tensor %d", lo + i);
-      a.src[i] = srcs[lo + i]; a.dst[i] = dsts[lo + i]; a.dst_t[i] = dst_ts[lo + i];
-      a.rows[i] = (int32_t)rows[lo + i]; a.cols[i] = (int32_t)cols[lo + i];
-      tiles += (int)(ceil_div(rows[lo + i], 64) * ceil_div(cols[lo + i], 64));
-      a.tile_end[i] = tiles;
-    }
-    hipLaunchKernelGGL(cast_transpose_many_kernel, dim3((unsigned)tiles), dim3(256), 0, st, a);
-    KRS_CHECK_LAUNCH("cast_transpose_many_kernel");
-  }
-  return KRS_OK;
-}
-
-extern "C" int krs_cast_transpose(const void* src, int64_t rows, int64_t cols, int64_t ld_src, int src_dtype,
-                                  void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t, int dst_dtype,
-                                  void* stream) {
-  KRS_REQUIRE(src && (dst || dst_t), "cast_transpose: null operand");
-  KRS_REQUIRE(rows >= 0 && cols >= 0 && ld_src >= cols, "cast_transpose: bad sizes");
-  KRS_REQUIRE((src_dtype == KRS_F32 || src_dtype == KRS_BF16) && (dst_dtype == KRS_F32 || dst_dtype == KRS_BF16),
-              "cast_transpose: dtype must be f32 or bf16");
-  KRS_REQUIRE((!dst || ld_dst >= cols) && (!dst_t || ld_dst_t >= rows), "cast_transpose: bad output strides");
-  if (rows == 0 || cols == 0) return KRS_OK;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(cast_transpose_kernel, dim3((unsigned)ceil_div(cols, 64), (unsigned)ceil_div(rows, 64)), dim3(256),
-                     0, st, src, rows, cols, ld_src, src_dtype, dst, ld_dst, dst_t, ld_dst_t, dst_dtype);
-  KRS_CHECK_LAUNCH("cast_transpose_kernel");
-  return KRS_OK;
-}
-
-// Dense Adagrad over a LIST of fp32 tensors in one launch (the FeatureCross / Dense weights of a step):
-//   acc += g*g;  p -= lr * g / (sqrt(acc) + eps)      -- torch.optim.Adagrad / keras Adagrad with eps outside the root
-// One workgroup per 4096-element chunk of one tensor; the (tensor, chunk) of a workgroup comes from the
-// cumulative chunk counts in the argument block (<= 32 tensors per launch).
-constexpr int kOptMax = 32, kOptChunk = 4096;
-struct DenseOptArgs {
-  float* p[kOptMax];
-  const float* g[kOptMax];
-  float* acc[kOptMax];
-  int64_t n[kOptMax];
-  int32_t chunk_end[kOptMax];   // inclusive prefix of the tensors' chunk counts
-  int count;
-  float lr, eps;
-};
-__global__ __launch_bounds__(256) void dense_adagrad_kernel(const DenseOptArgs a) {
-  int t = 0;
-  while (t + 1 < a.count && (int)blockIdx.x >= a.chunk_end[t]) ++t;
-  float* p = nullptr; const float* g = nullptr; float* acc = nullptr; int64_t n = 0; int first = 0;
-#pragma unroll
-  for (int i = 0; i < kOptMax; ++i)   // static kernarg indices
-    if (i == t) { p = a.p[i]; g = a.g[i]; acc = a.acc[i]; n = a.n[i]; first = i ? a.chunk_end[i - 1] : 0; }
-  const int64_t base = (int64_t)(blockIdx.x - first) * kOptChunk;
-  const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(acc)) & 15) == 0;
-#pragma unroll
-  for (int k = 0; k < kOptChunk / 1024; ++k) {
-    const int64_t i0 = base + k * 1024 + threadIdx.x * 4;
-    if (vec && i0 + 4 <= n) {
-      const float4 gv = *reinterpret_cast<const float4*>(g + i0);
-      float4 av = *reinterpret_cast<const float4*>(acc + i0), pv = *reinterpret_cast<const float4*>(p + i0);
-      av.x = fmaf(gv.x, gv.x, av.x); av.y = fmaf(gv.y, gv.y, av.y); av.z = fmaf(gv.z, gv.z, av.z); av.w = fmaf(gv.w, gv.w, av.w);
-      pv.x -= a.lr * gv.x / (sqrtf(av.x) + a.eps); pv.y -= a.lr * gv.y / (sqrtf(av.y) + a.eps);
-      pv.z -= a.lr * gv.z / (sqrtf(av.z) + a.eps); pv.w -= a.lr * gv.w / (sqrtf(av.w) + a.eps);
-      *reinterpret_cast<float4*>(acc + i0) = av;
-      *reinterpret_cast<float4*>(p + i0) = pv;
-    } else {
-      for (int q = 0; q < 4 && i0 + q < n; ++q) {
-        const float gq = g[i0 + q], aq = fmaf(gq, gq, acc[i0 + q]);
-        acc[i0 + q] = aq;
-        p[i0 + q] -= a.lr * gq / (sqrtf(aq) + a.eps);
-      }
-    }
-  }
-}
-
-extern "C" int krs_dense_adagrad(float* const* params, const float* const* grads, float* const* accs,
-                                 const int64_t* sizes, int count, float lr, float eps, void* stream) {
-  KRS_REQUIRE(count >= 0 && (count == 0 || (params && grads && accs && sizes)), "dense_adagrad: null tensor list");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  for (int lo = 0; lo < count; lo += kOptMax) {
-    DenseOptArgs a{};
-    a.count = std::min(kOptMax, count - lo);
-    a.lr = lr; a.eps = eps;
-    int chunks = 0;
-    for (int i = 0; i < a.count; ++i) {
-      KRS_REQUIRE(sizes[lo + i] >= 0 && (sizes[lo + i] == 0 || (params[lo + i] && grads[lo + i] && accs[lo + i])),
-                  "dense_adagrad: null tensor");
-      a.p[i] = params[lo + i]; a.g[i] = grads[lo + i]; a.acc[i] = accs[lo + i]; a.n[i] = sizes[lo + i];
-      chunks += (int)ceil_div(sizes[lo + i], kOptChunk);
-      a.chunk_end[i] = chunks;
-    }
-    if (chunks == 0) continue;
-    hipLaunchKernelGGL(dense_adagrad_kernel, dim3((unsigned)chunks), dim3(256), 0, st, a);
-    KRS_CHECK_LAUNCH("dense_adagrad_kernel");
-  }
-  return KRS_OK;
-}
-
-extern "C" int krs_colsum(const void* a, int64_t lda, int64_t m, int64_t n, int dtype, float* out,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-  KRS_REQUIRE(a && out, "colsum: null operand");
-  KRS_REQUIRE(m >= 0 && n >= 0, "colsum: bad sizes");
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (n == 0) return KRS_OK;
-  const bool two_stage = workspace && m > 0;
-  if (two_stage) KRS_REQUIRE(workspace_bytes >= krs_colsum_workspace_bytes(m, n), "colsum: workspace too small");
-  if (!two_stage) KRS_HIP(hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st));
-  if (m == 0) return KRS_OK;
-  const ColChunks cc = col_chunks(m, n);
-  float* partial = two_stage ? reinterpret_cast<float*>(workspace) : nullptr;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)cc.chunks), dim3(64), 0, st, a, lda, m, n, dtype,
-                     out, partial, cc.rows_per_block);
-  KRS_CHECK_LAUNCH("colsum_kernel");
-  if (two_stage) return finish_colsum(partial, cc.chunks, n, out, st);
   return KRS_OK;
 }

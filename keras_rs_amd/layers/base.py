@@ -300,6 +300,119 @@ def serialize_regularizer(reg):
 
 
 # --------------------------------------------------------------------------- #
+# weight constraints (keras.constraints): projections applied to a variable AFTER each optimizer update.  Keras optimizers
+# do that themselves for variables created with `constraint=`; here `keras_rs_amd.optim.Adagrad.step()` does it for the
+# parameters it updates, and `Layer.apply_constraints()` is the explicit call for training loops on another optimizer.
+# (Tables on the fused `sparsecore` placement are updated inside K2 and take no constraint -- the reference's SparseCore
+# path has none either; EmbedReduce's table is an ordinary weight.)
+# --------------------------------------------------------------------------- #
+class Constraint:
+    def __call__(self, w: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def get_config(self) -> dict:
+        return {}
+
+    def serialize(self) -> dict:
+        return {"class_name": type(self).__name__, "config": self.get_config()}
+
+
+def _axis_norm(w, axis):
+    return w.float().square().sum(dim=axis, keepdim=True).sqrt()
+
+
+class MaxNorm(Constraint):
+    """keras.constraints.MaxNorm: w * clip(norm, 0, max_value) / (eps + norm) along `axis`."""
+
+    def __init__(self, max_value: float = 2.0, axis=0):
+        self.max_value, self.axis = float(max_value), axis
+
+    def __call__(self, w):
+        n = _axis_norm(w, self.axis)
+        return (w.float() * (n.clamp(0.0, self.max_value) / (1e-7 + n))).to(w.dtype)
+
+    def get_config(self):
+        return {"max_value": self.max_value, "axis": self.axis}
+
+
+class NonNeg(Constraint):
+    def __call__(self, w):
+        return w * (w >= 0).to(w.dtype)
+
+
+class UnitNorm(Constraint):
+    def __init__(self, axis=0):
+        self.axis = axis
+
+    def __call__(self, w):
+        return (w.float() / (1e-7 + _axis_norm(w, self.axis))).to(w.dtype)
+
+    def get_config(self):
+        return {"axis": self.axis}
+
+
+class MinMaxNorm(Constraint):
+    def __init__(self, min_value: float = 0.0, max_value: float = 1.0, rate: float = 1.0, axis=0):
+        self.min_value, self.max_value, self.rate, self.axis = float(min_value), float(max_value), float(rate), axis
+
+    def __call__(self, w):
+        n = _axis_norm(w, self.axis)
+        desired = self.rate * n.clamp(self.min_value, self.max_value) + (1.0 - self.rate) * n
+        return (w.float() * (desired / (1e-7 + n))).to(w.dtype)
+
+    def get_config(self):
+        return {"min_value": self.min_value, "max_value": self.max_value, "rate": self.rate, "axis": self.axis}
+
+
+class CallableConstraint(Constraint):
+    def __init__(self, fn: Callable):
+        self.fn = fn
+
+    def __call__(self, w):
+        return self.fn(w)
+
+    def get_config(self):
+        return {"fn": getattr(self.fn, "__name__", repr(self.fn))}
+
+
+_CONSTRAINTS = {"max_norm": MaxNorm, "non_neg": NonNeg, "unit_norm": UnitNorm, "min_max_norm": MinMaxNorm,
+                "MaxNorm": MaxNorm, "NonNeg": NonNeg, "UnitNorm": UnitNorm, "MinMaxNorm": MinMaxNorm}
+
+
+def get_constraint(identifier):
+    """None | Constraint | "max_norm" / "non_neg" / "unit_norm" / "min_max_norm" | serialized dict | callable
+    (keras.constraints.get)."""
+    if identifier is None or isinstance(identifier, Constraint):
+        return identifier
+    if isinstance(identifier, str):
+        if identifier not in _CONSTRAINTS:
+            raise ValueError(f"Unknown constraint '{identifier}'")
+        return _CONSTRAINTS[identifier]()
+    if isinstance(identifier, dict):
+        if identifier.get("class_name") not in _CONSTRAINTS:
+            raise ValueError(f"Unknown constraint {identifier!r}")
+        return _CONSTRAINTS[identifier["class_name"]](**identifier.get("config", {}))
+    if callable(identifier):
+        return CallableConstraint(identifier)
+    raise ValueError(f"Cannot interpret constraint {identifier!r}")
+
+
+def serialize_constraint(c):
+    return None if c is None else c.serialize()
+
+
+def apply_constraint(p: torch.Tensor) -> bool:
+    """Projects a parameter through the constraint attached by `Layer.add_weight(constraint=...)`, in place (the
+    version counter moves, so cached casts of the weight are rebuilt).  True when there was one."""
+    c = getattr(p, "_krs_constraint", None)
+    if c is None:
+        return False
+    with torch.no_grad():
+        p.copy_(c(p.detach()))
+    return True
+
+
+# --------------------------------------------------------------------------- #
 # activations fused in the GEMM epilogue
 # --------------------------------------------------------------------------- #
 def relu(x):
@@ -461,10 +574,14 @@ class Layer(torch.nn.Module):
     def dtype(self):
         return self.dtype_policy.variable_dtype
 
-    def add_weight(self, shape, initializer, name: str, dtype=None, trainable=True, regularizer=None) -> torch.nn.Parameter:
+    def add_weight(self, shape, initializer, name: str, dtype=None, trainable=True, regularizer=None,
+                   constraint=None) -> torch.nn.Parameter:
         init = get_initializer(initializer)
         value = init(tuple(shape), dtype or self.variable_dtype, self._device)
         p = torch.nn.Parameter(value, requires_grad=trainable and self.trainable)
+        con = get_constraint(constraint)
+        if con is not None:
+            p._krs_constraint = con     # applied after an update: optim.Adagrad.step() / Layer.apply_constraints()
         reg = get_regularizer(regularizer)
         if reg is not None:
             self._regularized.append((p, reg))
@@ -479,13 +596,38 @@ class Layer(torch.nn.Module):
         self._weight_order.append(p)
         return p
 
+    def _sublayers(self) -> list:
+        """Direct sublayers: registered module children AND Layers kept in plain Python lists / tuples / dicts of this
+        object (keras tracks those too; nn.Module.children() does not see them)."""
+        out, seen = [], set()
+
+        def add(m):
+            if isinstance(m, Layer) and id(m) not in seen and m is not self:
+                seen.add(id(m))
+                out.append(m)
+
+        for m in self.children():
+            add(m)
+        for v in self.__dict__.values():
+            if isinstance(v, (list, tuple)):
+                for m in v:
+                    add(m)
+            elif isinstance(v, dict) and v is not self._modules and v is not self._parameters and v is not self._buffers:
+                for m in v.values():
+                    add(m)
+        return out
+
     @property
     def weights(self) -> list[torch.nn.Parameter]:
         out = list(self._weight_order)
-        for m in self.children():
-            if isinstance(m, Layer):
-                out += m.weights
+        for m in self._sublayers():
+            out += m.weights
         return out
+
+    def apply_constraints(self) -> int:
+        """Projects every weight of this layer and its sublayers that was created with a constraint (what a Keras
+        optimizer does after each update).  Returns the number of weights projected."""
+        return sum(int(apply_constraint(w)) for w in self.weights)
 
     @property
     def trainable_weights(self):
@@ -500,9 +642,8 @@ class Layer(torch.nn.Module):
         """Weight-regularisation penalties of this layer and its sublayers, evaluated on the current weights
         (keras.layers.Layer.losses): add `sum(layer.losses)` to the training loss, as `Model.fit` does."""
         out = [reg(w) for w, reg in self._regularized if w.requires_grad]
-        for m in self.children():
-            if isinstance(m, Layer):
-                out += m.losses
+        for m in self._sublayers():
+            out += m.losses
         return out
 
     def build(self, *input_shapes) -> None:

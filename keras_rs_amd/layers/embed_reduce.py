@@ -77,14 +77,10 @@ class EmbedReduce(base.Layer):
         self.output_dim = int(output_dim)
         self.embeddings_initializer = base.get_initializer(embeddings_initializer)
         # keras.layers.Embedding under the reference's EmbedReduce (embed_reduce.py:138-150) hands both to its variable:
-        # the regulariser's penalty appears in `layer.losses`; a constraint is a projection the KERAS optimizer applies
-        # after its update, which no optimizer here does -- rejected loudly rather than stored and dropped
+        # the regulariser's penalty appears in `layer.losses`; the constraint is a projection the optimizer applies after
+        # its update -- keras_rs_amd.optim.Adagrad.step() does, other training loops call `layer.apply_constraints()`
         self.embeddings_regularizer = base.get_regularizer(embeddings_regularizer)
-        if embeddings_constraint is not None:
-            raise NotImplementedError("EmbedReduce(embeddings_constraint=...) needs an optimizer that applies variable "
-                                      "constraints after each update (keras optimizers do); the optimizers of this "
-                                      "package do not -- project the table in the training loop instead")
-        self.embeddings_constraint = None
+        self.embeddings_constraint = base.get_constraint(embeddings_constraint)
         self.mask_zero = mask_zero
         self.combiner = combiner
         self._initial_weights = weights
@@ -94,7 +90,8 @@ class EmbedReduce(base.Layer):
     def build(self, *_) -> None:
         if self.embeddings is None:
             self.embeddings = self.add_weight((self.input_dim, self.output_dim), self.embeddings_initializer,
-                                              "embeddings", regularizer=self.embeddings_regularizer)
+                                              "embeddings", regularizer=self.embeddings_regularizer,
+                                              constraint=self.embeddings_constraint)
             if self._initial_weights is not None:
                 with torch.no_grad():
                     self.embeddings.copy_(torch.as_tensor(np.asarray(self._initial_weights)))
@@ -204,7 +201,7 @@ class EmbedReduce(base.Layer):
             "output_dim": self.output_dim,
             "embeddings_initializer": self.embeddings_initializer.serialize(),
             "embeddings_regularizer": base.serialize_regularizer(self.embeddings_regularizer),
-            "embeddings_constraint": self.embeddings_constraint,
+            "embeddings_constraint": base.serialize_constraint(self.embeddings_constraint),
             "mask_zero": self.mask_zero,
             "combiner": self.combiner,
         })

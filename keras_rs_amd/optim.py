@@ -57,6 +57,12 @@ class Adagrad(torch.optim.Optimizer):
             rc = L.lib().krs_dense_adagrad(arr(ps), arr(gs), arr(accs), sizes, C.c_int(n), C.c_float(group["lr"]),
                                            C.c_float(group["eps"]), L.stream_ptr())
             L.check(rc, "krs_dense_adagrad")
+            # weights created with a constraint (Layer.add_weight(constraint=...)) are projected behind their update, as
+            # a Keras optimizer does; the in-place copy moves the version counter, so their cached casts are rebuilt
+            from keras_rs_amd.layers.base import apply_constraint
+
+            for p in ps:
+                apply_constraint(p)
             # the bf16 copies (plain + K-contiguous) the GEMMs of the next step want, for every weight a layer has asked
             # for, in one launch: the weights have just changed, and the C-ABI update is invisible to torch's versions
             if self.prepare_casts:

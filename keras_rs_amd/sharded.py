@@ -313,7 +313,7 @@ class ShardedDistributedEmbedding(base.Layer):
     def __init__(self, feature_configs: dict[str, FeatureConfig], *, process_group=None, kernels=None,
                  slab_lead_cols: int = 0, replicate_below: int = 0, grad_average: bool = False,
                  partial_dtype=None, exchange: str = "exact", capacity="auto", capacity_headroom: float = 1.25,
-                 update_stats: bool = True, capacity_settle_steps: int = 16, **kwargs: Any):
+                 update_stats: bool = True, capacity_settle_steps: int = 0, **kwargs: Any):
         super().__init__(**kwargs)
         # (base_distributed_embedding.py:461-464: whether the per-partition limits follow the running statistics; here
         #  the capacities of the static exchange.  False = they stay what they were sized to, overflows are only counted)
@@ -341,7 +341,12 @@ class ShardedDistributedEmbedding(base.Layer):
         self.exchange = exchange
         self._capacity_spec = capacity
         self.capacity_headroom = float(capacity_headroom)
-        self.capacity_settle_steps = int(capacity_settle_steps)   # 0 = never shrink
+        # Shrinking the blocks to the settled statistics is OPT-IN (0 = never shrink, the default): a heavier or more
+        # skewed batch arriving after a shrink overflows -- its lookups are dropped for the two steps the statistics take
+        # to react -- while the padding it saves only matters on the links.  Steps replayed from a graph never shrink
+        # (poll_exchange_stats): the captured buffers keep their size, a smaller `_caps` would only turn a later need
+        # that still fits the captured blocks into a false overflow.
+        self.capacity_settle_steps = int(capacity_settle_steps)
         self.capacity_shrinks = 0
         self._settle: dict = {}          # caps key -> [steps that fit in a row, their largest need_l, need_s]
         self._caps: dict = {}            # (group, batch, hots) -> [cap_lookups, cap_segments]
@@ -738,8 +743,9 @@ class ShardedDistributedEmbedding(base.Layer):
                 ev0.synchronize()
             self._apply_stats(h0, key0)
 
-    def _apply_stats(self, h0, key0) -> bool:
-        """One step's statistics (host copy) against the capacity they ran with; True when the capacity grew."""
+    def _apply_stats(self, h0, key0, allow_shrink: bool = True) -> bool:
+        """One step's statistics (host copy) against the capacity they ran with; True when the capacity grew.
+        `allow_shrink=False` (statistics of a replayed graph): fitting steps never resize."""
         need_l, need_s = int(h0[0]), int(h0[1])
         cap = self._caps.get(key0)
         self.last_exchange.update(need=(need_l, need_s), received=(int(h0[2]), int(h0[3])))
@@ -749,7 +755,7 @@ class ShardedDistributedEmbedding(base.Layer):
             # Settled statistics shrink the blocks (every slot of a block crosses the link, padding included): once
             # `capacity_settle_steps` steps in a row fit, the capacity drops to the largest need they showed + 6 % + 64
             # (rounded to 64) -- every rank sees the same maxima at the same step, so all ranks resize together.
-            if self.update_stats and self.capacity_settle_steps > 0 and self._capacity_spec == "auto":
+            if allow_shrink and self.update_stats and self.capacity_settle_steps > 0 and self._capacity_spec == "auto":
                 w = self._settle.setdefault(key0, [0, 0, 0])
                 w[0], w[1], w[2] = w[0] + 1, max(w[1], need_l), max(w[2], need_s)
                 if w[0] >= self.capacity_settle_steps:
@@ -791,7 +797,7 @@ class ShardedDistributedEmbedding(base.Layer):
         torch.cuda.current_stream(self._device).synchronize()
         grew = False
         for host, key in self._graph_stats.values():
-            grew = self._apply_stats(host, key) or grew
+            grew = self._apply_stats(host, key, allow_shrink=False) or grew
         return grew
 
     def _route_exchange(self, g, cap_l, cap_s, ids, batch, hots, offsets, weights, emit_w):

@@ -116,19 +116,15 @@ if not a.fmajor_out:
         print(json.dumps({"plan_variant": pv, "k2_plan_us": timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots, global_order=False)) * 1e6}))
     t_plan = timeit(lambda: fb.plan_backward(ids, a.batch, hots=hots, global_order=False))
     ws = fb.plan_backward(ids, a.batch, hots=hots, global_order=False)
-    for variant in (0, 1, 0, 1):     # KRS_EMBED_OPT_APPLY: 0 = bag_apply_fast_kernel, 1 = the round-1 kernel
-        L.check(L.lib().krs_embed_set_option(C.c_int(1), C.c_int(variant)), "set_option")
+    for _ in range(2):
         t_ada = timeit(lambda: fb.backward_fused("adagrad", ws, grad, a.batch, nnz, hots=hots))
         t_sgd = timeit(lambda: fb.backward_fused("sgd", ws, grad, a.batch, nnz, hots=hots))
-        print(json.dumps({"apply_variant": variant, "k2_plan_us": t_plan * 1e6, "k2_adagrad_us": t_ada * 1e6,
-                          "k2_sgd_us": t_sgd * 1e6}))
-    L.lib().krs_embed_set_option(C.c_int(1), C.c_int(0))
+        print(json.dumps({"k2_plan_us": t_plan * 1e6, "k2_adagrad_us": t_ada * 1e6, "k2_sgd_us": t_sgd * 1e6}))
 
-# ---- does the plan hide under the apply kernel?  (two streams; KRS_EMBED_OPT_APPLY 0 / 1) ----
+# ---- does the plan hide under the apply kernel?  (two streams) ----
 if not a.fmajor_out:
     sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
-    for variant in (0, 1):
-        L.lib().krs_embed_set_option(C.c_int(1), C.c_int(variant))
+    for variant in (0,):
         for order in ("apply_first", "plan_first"):
             ts = []
             for rep in range(6):
@@ -150,4 +146,3 @@ if not a.fmajor_out:
             ts = np.array(ts[2:])
             print(json.dumps({"overlap": order, "apply_variant": variant, "apply_done_us": float(np.median(ts[:, 0]) * 1e3),
                               "plan_done_us": float(np.median(ts[:, 1]) * 1e3)}))
-    L.lib().krs_embed_set_option(C.c_int(1), C.c_int(0))

@@ -158,6 +158,22 @@ def main():
             assert layer.capacity_shrinks >= 1 and layer.overflow_steps == 0, (layer.capacity_shrinks, cap1)
             need = layer.last_exchange["need"]
             assert need[0] <= cap1[0] < 0.8 * 4.0 * (B * sum(hots) / world) and need[1] <= cap1[1], (cap0, cap1, need)
+            # a HEAVIER batch behind the shrink (every id on owner 0): its lookups beyond the shrunken blocks are dropped
+            # and counted for the two steps the statistics take to react, then the capacity has grown to the need on every
+            # rank and nothing is dropped any more (why shrinking is opt-in: ADVICE r4)
+            skew = {k: (v // world) * world for k, v in ids.items()}
+            with torch.no_grad():
+                for _ in range(4):
+                    layer(skew, w if use_w else None)
+                layer.flush_exchange_stats()
+            cap2 = list(next(iter(layer._caps.values())))
+            assert layer.overflow_steps >= 1 and cap2[0] > cap1[0], (cap1, cap2, layer.overflow_steps)
+            assert layer.last_exchange["need"][0] <= cap2[0] and layer.last_exchange["need"][1] <= cap2[1]
+            layer.kernels.flags = 0
+            with torch.no_grad():
+                layer(skew, w if use_w else None)
+            assert not layer.kernels.flags & ko.FLAG_CAPACITY_OVERFLOW
+            layer.capacity_settle_steps = 0      # (the checked call below runs on the grown blocks)
         if mode == "static_prefetch":
             # the id side of the call (route -> id all-to-all -> unpack) issued ahead of it: same result, one hit
             pre = layer.preprocess(ids, w if use_w else None)

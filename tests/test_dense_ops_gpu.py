@@ -481,3 +481,90 @@ def test_fused_data_gradient_and_cross_backward_equals_the_two_calls(acc, fold, 
                 assert none5 is None and torch.equal(G5, G4) and torch.equal(dz5, dz4) and torch.equal(db5, db4)
                 with pytest.raises(L.KrsError):
                     D.gemm_cross_bwd(A, Bt, R, x0, u, act=a_id, want_dx0=False)
+
+
+@pytest.mark.parametrize("m,n,k", [(16384 + 72, 768 + 40, 256), (24576, 512, 320)])
+def test_fused_cross_backward_every_epilogue_form_against_the_two_call_form_at_ragged_shapes(m, n, k):
+    """krs_gemm_cross_bwd's fused ring kernel (EPI 3 .. 8) against the documented two-call form, which
+    krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, 0) forces inside the same entry: m and n that are NOT multiples of the
+    256-wide tile (partial tiles on both edges), with / without the residual, accumulating dx0, fold_direct, u_upper
+    (EPI 7) and dx0 = NULL (EPI 8), with and without an activation.  G, dz and dx0 bit for bit (EPI 7's dx0: the fused form
+    rounds R*u_upper + G*u once, the two calls twice -- one ulp of the larger term); dbias to fp32 summation order."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd import dense_ops as D
+
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(23)
+    rnd = lambda *sh: ((torch.rand(*sh, device=dev, generator=gen) - 0.5)).to(torch.bfloat16)  # noqa: E731
+    A, Bt, R, x0, u, told, u_up = rnd(m, k), rnd(n, k) * 0.2, rnd(m, n), rnd(m, n), rnd(m, n), rnd(m, n), rnd(m, n)
+    forms = [dict(r=R), dict(r=R, acc=True), dict(r=R, fold=True), dict(r=R, acc=True, fold=True), dict(r=None),
+             dict(r=None, acc=True), dict(r=R, u_upper=u_up), dict(r=R, u_upper=u_up, fold=True), dict(r=None, want_dx0=False)]
+
+    def run(form, act):
+        buf = told.clone() if form.get("acc") else None
+        return D.gemm_cross_bwd(A, Bt, form["r"], x0, u, act=act, dx0_into=buf, fold_direct=form.get("fold", False),
+                                u_upper=form.get("u_upper"), want_dx0=form.get("want_dx0", True))
+
+    def set_pipe(v):
+        L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(v)), "krs_gemm_set_option")
+
+    try:
+        for act in (L.ACT_NONE, L.ACT_RELU):
+            for form in forms:
+                set_pipe(4)
+                G, dz, dx0, db = run(form, act)
+                set_pipe(0)
+                G2, dz2, dx02, db2 = run(form, act)
+                tag = (act, {k_: (v is not None if k_ in ("r", "u_upper") else v) for k_, v in form.items()})
+                assert torch.equal(G, G2), tag
+                assert torch.equal(dz, dz2), tag
+                if dx0 is None:
+                    assert dx02 is None
+                elif form.get("u_upper") is not None:
+                    scale = float((R.float() * u_up.float()).abs().max() + (G.float() * u.float()).abs().max()) + \
+                        (float(G.float().abs().max()) if form.get("fold") else 0.0)
+                    torch.testing.assert_close(dx0.float(), dx02.float(), rtol=2.0 ** -7, atol=2.0 ** -7 * scale)
+                else:
+                    assert torch.equal(dx0, dx02), tag
+                torch.testing.assert_close(db, db2, rtol=1e-5, atol=2e-4)
+    finally:
+        set_pipe(4)
+
+
+def test_ring_gemm_equals_the_two_stage_kernels_bit_for_bit():
+    """krs_gemm's ring kernel (256 x 256 tiles, pipeline 4) against the 128 x 128 two-stage kernels (pipeline 0) on the
+    three operand layouts of a cross layer at shapes with partial tiles: same fragment layout, same k order per
+    accumulator -> identical bits (plain, cross-epilogue and residual forms; the weight gradient through split-K)."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd import dense_ops as D
+
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(29)
+    rnd = lambda *sh: ((torch.rand(*sh, device=dev, generator=gen) - 0.5)).to(torch.bfloat16)  # noqa: E731
+    m, d, p = 24576 + 64, 1024 + 64, 512      # (>= 192 tiles of 256 x 256 for every product; partial tiles on both edges)
+    x, x0, g = rnd(m, d), rnd(m, d), rnd(m, d)
+    Ut, Vt = rnd(p, d) * 0.1, rnd(d, p) * 0.1      # K-contiguous weights
+
+    def products():
+        h, _ = D.gemm(x, Ut, b_is_nk=True)                                   # [m, p], K = d
+        y, uo = D.gemm(h, Vt, b_is_nk=True, x0=x0, x=x, want_u=True)         # cross epilogue, K = p
+        dx, _ = D.gemm(h, Ut.t().contiguous(), b_is_nk=True, r=g, beta=1.0)  # residual form
+        dk, _ = D.gemm(h, g, a_is_km=True, out_dtype=torch.float32)          # weight gradient [p, d], K = m
+        return h, y, uo, dx, dk
+
+    try:
+        L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(4)), "krs_gemm_set_option")
+        ring = products()
+        L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(0)), "krs_gemm_set_option")
+        ref = products()
+    finally:
+        L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(4))
+    for name, a, b in zip(("h", "y", "u", "dx", "dK"), ring, ref):
+        if name == "dK":     # split-K slabs: the split count is a function of the shape alone, but the tile kernels differ
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
+        else:
+            assert torch.equal(a, b), name

@@ -268,17 +268,13 @@ def test_hot_rows_take_the_workgroup_path(tdt, gdt, dim, batch):
 
 
 @pytest.mark.parametrize("kind", ["sgd", "adagrad", "adam", "adagrad_rowwise"])
-@pytest.mark.parametrize("tdt,gdt,dim,misaligned", [("bf16", "bf16", 128, False), ("bf16", "bf16", 128, True),
-                                                    ("f32", "f32", 64, True), ("bf16", "f32", 32, True),
-                                                    ("f32", "bf16", 24, False)])
-def test_pipelined_apply_kernel_equals_round1_kernel_bit_for_bit(kind, tdt, gdt, dim, misaligned):
-    """bag_apply_fast_kernel (batched metadata, pipelined row / gradient loads, one under-aligned wide access form)
-    against bag_apply_kernel (KRS_EMBED_OPT_APPLY = 1): same fmaf chain, same row update -> identical bits, with
-    table / slot base pointers that are NOT 16-byte aligned too (the memory pipeline runs in unaligned-access mode;
-    the fast kernel has no aligned / unaligned switch), segments of 1 .. ~40 lookups, weights and bag scales."""
-    import ctypes as C
-
-    from keras_rs_amd import _lib as L
+@pytest.mark.parametrize("tdt,gdt,dim", [("bf16", "bf16", 128), ("f32", "f32", 64), ("bf16", "f32", 32), ("f32", "bf16", 24)])
+def test_apply_kernel_gives_the_same_bits_on_misaligned_table_and_slot_bases(kind, tdt, gdt, dim):
+    """bag_apply_fast_kernel has ONE access form -- under-aligned wide vector accesses, the memory pipeline runs in
+    unaligned-access mode -- so table / slot base pointers that are NOT 16-byte aligned (2 or 4 bytes off) must give the
+    bits of aligned ones: segments of 1 .. ~40 lookups, weights and bag scales, every fused optimizer.  (Round 3 / 4 also
+    compared it bit for bit with the round-1 kernel behind KRS_EMBED_OPT_APPLY; that kernel was deleted in round 5.  The
+    bf16-table / fp32-gradient pair runs bag_apply_generic.)"""
     from keras_rs_amd.embedding_ops import FusedBags
 
     rng = np.random.default_rng(11)
@@ -288,28 +284,27 @@ def test_pipelined_apply_kernel_equals_round1_kernel_bit_for_bit(kind, tdt, gdt,
     hots = [3, 9, 2, 1]
     tix = [0, 1, 2, 1]
 
-    def alloc(shape, dt, fill=None):
+    def alloc(shape, dt, fill, misaligned):
         # a view that starts one element into a larger buffer when `misaligned` (2 or 4 bytes off 16-byte alignment)
         n = int(np.prod(shape))
         big = torch.empty(n + 8, dtype=dt, device=dev)
         v = big[1:1 + n].view(shape) if misaligned else big[:n].view(shape)
-        if fill is not None:
-            v.copy_(fill)
+        v.copy_(fill)
         return v
 
-    def build():
+    def build(misaligned):
         g = np.random.default_rng(5)
-        tables = [alloc((v, dim), TORCH_DT[tdt], torch.from_numpy(g.uniform(-1, 1, (v, dim)).astype(np.float32)).to(dev))
-                  for v in vocabs]
+        tables = [alloc((v, dim), TORCH_DT[tdt], torch.from_numpy(g.uniform(-1, 1, (v, dim)).astype(np.float32)).to(dev),
+                        misaligned) for v in vocabs]
         planes = {"sgd": None, "adagrad": 1, "adam": 2, "adagrad_rowwise": 0}[kind]
         if planes is None:
             slots = [None] * n_tables
         elif planes == 0:
-            slots = [alloc((v,), torch.float32, torch.full((v,), 0.1, device=dev)) for v in vocabs]
+            slots = [alloc((v,), torch.float32, torch.full((v,), 0.1, device=dev), misaligned) for v in vocabs]
         elif planes == 1:
-            slots = [alloc((v, dim), torch.float32, torch.full((v, dim), 0.1, device=dev)) for v in vocabs]
+            slots = [alloc((v, dim), torch.float32, torch.full((v, dim), 0.1, device=dev), misaligned) for v in vocabs]
         else:
-            slots = [alloc((2, v, dim), torch.float32, torch.zeros((2, v, dim), device=dev)) for v in vocabs]
+            slots = [alloc((2, v, dim), torch.float32, torch.zeros((2, v, dim), device=dev), misaligned) for v in vocabs]
         fb = FusedBags(tables, [(tix[f], ["sum", "mean", "sqrtn", "sum"][f], 3 + f * dim) for f in range(4)],
                        slots=slots, lrs=[0.01, 0.02, 0.03])
         return tables, slots, fb
@@ -320,23 +315,42 @@ def test_pipelined_apply_kernel_equals_round1_kernel_bit_for_bit(kind, tdt, gdt,
     cols = 3 + 4 * dim + 1
     grad = torch.from_numpy(rng.uniform(-1, 1, (batch, cols)).astype(np.float32)).to(TORCH_DT[gdt]).to(dev)
     res = []
-    try:
-        for variant in (0, 1):
-            L.check(L.lib().krs_embed_set_option(C.c_int(1), C.c_int(variant)), "krs_embed_set_option")
-            tables, slots, fb = build()
-            out = torch.empty((batch, cols), dtype=TORCH_DT[tdt], device=dev)
-            _, scale = fb.forward(ids, batch, hots=hots, weights=w, out=out, want_scale=True)
-            ws = fb.plan_backward(ids, batch, hots=hots, global_order=False)
-            hyper = (0.9, 0.999, 1e-7, 0.3) if kind == "adam" else None
-            fb.backward_fused(kind, ws, grad, batch, ids.numel(), hots=hots, weights=w, bag_scale=scale, hyper=hyper)
-            torch.cuda.synchronize()
-            res.append(([t.clone() for t in tables], [None if x is None else x.clone() for x in slots]))
-    finally:
-        L.lib().krs_embed_set_option(C.c_int(1), C.c_int(0))
+    for misaligned in (False, True):
+        tables, slots, fb = build(misaligned)
+        before = [t.clone() for t in tables]
+        out = torch.empty((batch, cols), dtype=TORCH_DT[tdt], device=dev)
+        _, scale = fb.forward(ids, batch, hots=hots, weights=w, out=out, want_scale=True)
+        ws = fb.plan_backward(ids, batch, hots=hots, global_order=False)
+        hyper = (0.9, 0.999, 1e-7, 0.3) if kind == "adam" else None
+        fb.backward_fused(kind, ws, grad, batch, ids.numel(), hots=hots, weights=w, bag_scale=scale, hyper=hyper)
+        torch.cuda.synchronize()
+        assert any(not torch.equal(x, y) for x, y in zip(before, tables)), "the update did not run"
+        res.append(([t.clone() for t in tables], [None if x is None else x.clone() for x in slots]))
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b)
     for a, b in zip(res[0][1], res[1][1]):
         assert (a is None and b is None) or torch.equal(a, b)
+
+
+def test_more_features_than_the_descriptor_cache_take_the_any_shape_kernel():
+    """The vector apply kernels cache feature / table descriptors in LDS (512 of each); a wider model -- the reference
+    has no limit on the number of features -- runs bag_apply_generic: same dense gradient and fused SGD update as the
+    oracle."""
+    s = _setup(8, "f32", "f32", False, use_w=True, combiners=["sum", "mean", "sqrtn"], n_tables=520, batch=7, max_hot=3,
+               shared=True, vocab_hi=12)
+    assert len(s["fb"].features) > 512
+    got = s["fb"].backward_dense(s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                                 bag_scale=s["scale"])
+    torch.cuda.synchronize()
+    for g, e in zip(got, s["de"]):
+        np.testing.assert_allclose(g.cpu().numpy(), e, rtol=1e-6, atol=1e-6)
+    before = [t.clone() for t in s["tables"]]
+    s["fb"].backward_fused("sgd", s["ws"], s["grad"], s["batch"], s["nnz"], hots=s["hots"], weights=s["w"],
+                           bag_scale=s["scale"])
+    torch.cuda.synchronize()
+    for t, (b, e) in enumerate(zip(before, s["de"])):
+        exp = b.cpu().numpy() - np.float32(s["fb"].lrs[t]) * e
+        np.testing.assert_allclose(s["tables"][t].cpu().numpy(), exp, rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("csr", [False, True])
@@ -439,8 +453,9 @@ def test_table_segmented_plan_equals_global_plan(vocabs, dim, with_bad):
 def test_compact_form_refuses_a_table_segmented_plan_and_default_plan_serves_it():
     """the table-segmented sort leaves out-of-range ids at the end of every TABLE's run, the compact
     (sparse) form counts ONE trailing invalid run.  `plan_backward` defaults to the global sort (every apply form accepts
-    it); a plan made with global_order=False is refused by backward_sparse (KRS_ERR_UNSUPPORTED from the host registry of
-    workspaces, and n_unique = -1 from the mode word inside a workspace that was copied elsewhere)."""
+    it); a plan made with global_order=False is refused by backward_sparse (n_unique = -1 from the mode word inside the
+    workspace -- also when the workspace was copied elsewhere; the round-3 host registry of workspace addresses is gone,
+    ADVICE r4: a re-used address could refuse a good plan)."""
     from keras_rs_amd import _lib as L
     from keras_rs_amd.embedding_ops import FusedBags
 
@@ -468,6 +483,9 @@ def test_compact_form_refuses_a_table_segmented_plan_and_default_plan_serves_it(
         assert torch.equal(a, b)
     with pytest.raises(L.KrsError):
         fb.backward_sparse(ws_t, grad, batch, ids.numel(), hots=hots)
-    moved = ws_t.clone()                                                 # an address the library has not seen
+    moved = ws_t.clone()                                                 # the fact travels with the bytes
     with pytest.raises(L.KrsError):
         fb.backward_sparse(moved, grad, batch, ids.numel(), hots=hots)
+    ws_t.copy_(ws)                       # a GLOBAL plan copied over the address that held the table-segmented one is served
+    rows2, vals2 = fb.backward_sparse(ws_t, grad, batch, ids.numel(), hots=hots)
+    assert torch.equal(rows2, rows) and torch.equal(vals2, vals)

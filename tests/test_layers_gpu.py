@@ -1291,3 +1291,42 @@ def test_training_step_leaves_no_cyclic_garbage_that_holds_device_tensors():
         gc.set_debug(old_flags)
         gc.garbage.clear()
         gc.enable()
+
+
+def test_a_forward_without_a_backward_leaves_no_stale_bookkeeping():
+    """per-weight `_krs_pending_cross` and the per-bags plan-workspace flag were undone in backward only.
+    A grad-enabled forward whose graph is dropped (a validation pass without no_grad, an exception) must give them back:
+    otherwise the weight stays off the second stream for good and every later step allocates a fresh plan workspace."""
+    import gc
+
+    kl = _layers()
+    B, D = 256, 32
+    tc = kl.TableConfig(name="t", vocabulary_size=400, embedding_dim=D, optimizer=kl.Adagrad(0.05, 0.1), combiner="sum",
+                        placement="sparsecore")
+    emb = kl.DistributedEmbedding({"f": kl.FeatureConfig("f", tc, (B, 2), (B, D))}, dtype="bfloat16")
+    cross = kl.FeatureCross(projection_dim=16, dtype="mixed_bfloat16")
+    g = torch.Generator(device=DEV).manual_seed(3)
+    ids = {"f": torch.randint(0, 400, (B, 2), device=DEV, generator=g, dtype=torch.int32)}
+    pre = emb.preprocess(ids)
+    bags = emb._groups["sparsecore"][0].bags
+
+    def forward():
+        x0 = emb(pre)["f"]
+        return cross(x0, x0)
+
+    y = forward()
+    y.float().sum().backward()          # builds the weights, one ordinary step
+    assert getattr(cross.kernel, "_krs_pending_cross", 0) == 0 and not getattr(bags, "_plan_ws_busy", False)
+    ws0 = bags._plan_ws.data_ptr()
+    for _ in range(3):                  # validation-style passes: grad mode on, no backward, outputs dropped
+        y = forward()
+        assert cross.kernel._krs_pending_cross == 1 and bags._plan_ws_busy
+        del y
+        gc.collect()
+        assert cross.kernel._krs_pending_cross == 0 and cross.down_kernel._krs_pending_cross == 0
+        assert not bags._plan_ws_busy
+    y = forward()                       # the next training step re-uses the kept workspace and counts from zero
+    assert cross.kernel._krs_pending_cross == 1 and bags._plan_ws.data_ptr() == ws0
+    y.float().sum().backward()
+    assert cross.kernel._krs_pending_cross == 0 and not bags._plan_ws_busy
+    torch.cuda.synchronize()
