@@ -76,7 +76,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_is_km: bool = False, b_is_nk: bo
         ep.r, ep.ldr, ep.beta = r.data_ptr(), r.stride(0), float(beta)
     wsb = L.lib().krs_gemm_workspace_bytes(C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int(int(a_is_km)))
     ws = torch.empty(int(wsb), dtype=torch.uint8, device=a.device) if wsb else None
-    with probe.span("gemm", 2.0 * m * n * k):
+    # (bench.py's per-product roofline: one span name per product FAMILY -- operand layout, epilogue form, dtype, shape)
+    name = "gemm"
+    if probe.ACTIVE is not None:
+        name = "gemm[%s%s %s] %dx%dx%d" % ("tn" if a_is_km else ("nt" if b_is_nk else "nn"),
+                                           ":cross" if x0 is not None else (":res" if r is not None else ""),
+                                           "bf16" if a.dtype == torch.bfloat16 else "f32", m, n, k)
+    with probe.span(name, 2.0 * m * n * k):
         rc = L.lib().krs_gemm(
             L.ptr(a), C.c_int64(a.stride(0)), C.c_int(int(a_is_km)),
             L.ptr(b), C.c_int64(b.stride(0)), C.c_int(int(b_is_nk)),

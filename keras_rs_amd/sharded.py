@@ -51,7 +51,9 @@ from __future__ import annotations
 import ctypes as C
 import dataclasses
 import math
+import os
 import time
+import weakref
 from typing import Any
 
 import numpy as np
@@ -216,15 +218,33 @@ class HipShardKernels:
                                                           out_dtype=out_dtype)
         return out
 
-    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None, grad_scale=1.0):
-        """Owner side: fused optimizer step; lookup i of segment s carries weights[i] * grad_scale * seg_grads[s]."""
+    def plan_segments(self, table, slot, rows, offsets, ws=None):
+        """Owner side: the backward plan (sort of the received rows + segment list) of a later apply_segments call.  It
+        depends on the rows alone, so the layer runs it at FORWARD time on a side stream, under the dense part of the step
+        (as autograd.EmbedBagFusedFn does for the single-GPU layer).  Returns the workspace, or None for nothing to do."""
+        n_seg = offsets.numel() - 1
+        if rows.numel() == 0 or n_seg == 0:
+            return None
+        return self._bags_for(table, slot, 0.0).plan_backward(rows, n_seg, offsets=offsets, ws=ws)
+
+    def prepare_plan(self, table, slot, rows, offsets):
+        """Uploads (and caches) the descriptor blocks plan_segments will read -- called on the MAIN stream before the side
+        stream forks, so that a cold cache cannot race the two streams."""
+        fb = self._bags_for(table, slot, 0.0)
+        fb.table_desc()
+        fb.feature_desc(offsets.numel() - 1, None, rows.device)
+
+    def apply_segments(self, table, slot, rows, offsets, weights, seg_grads, lr, kind, hyper=None, grad_scale=1.0, ws=None):
+        """Owner side: fused optimizer step; lookup i of segment s carries weights[i] * grad_scale * seg_grads[s].
+        ws: the plan of plan_segments for these rows (None: planned here)."""
         n_seg = offsets.numel() - 1
         if rows.numel() == 0 or n_seg == 0:
             return
         fb = self._bags_for(table, slot, 0.0)
         fb.slots = [slot]
         fb.lrs = [float(lr)]   # scheduled rates change per step: the descriptor is re-uploaded when it does
-        ws = fb.plan_backward(rows, n_seg, offsets=offsets)
+        if ws is None:
+            ws = fb.plan_backward(rows, n_seg, offsets=offsets)
         scale = None
         if grad_scale != 1.0:
             scale = torch.full((n_seg,), float(grad_scale), dtype=torch.float32, device=rows.device)
@@ -269,6 +289,12 @@ class _ShardGroup:
     sname: str = ""
 
 
+def _release_plan_of(layer_ref, gi, owns) -> None:
+    layer = layer_ref()
+    if layer is not None:
+        layer._release_plan(gi, owns)
+
+
 class _ShardedLookupFn(torch.autograd.Function):
     """Outputs: the slab [B, lead + n*dim] (see DistributedEmbedding.slab_lead_cols) and its n feature views."""
 
@@ -277,8 +303,17 @@ class _ShardedLookupFn(torch.autograd.Function):
         from keras_rs_amd.autograd import _split_columns
 
         ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero tensors
-        slab, saved = layer._forward_impl(gi, ids, batch, hots, offsets, weights, lead)
+        # (grad mode is off inside a Function's forward: whether a backward will follow is what the anchor says)
+        layer._backward_follows = bool(ctx.needs_input_grad[8])
+        try:
+            slab, saved = layer._forward_impl(gi, ids, batch, hots, offsets, weights, lead)
+        finally:
+            layer._backward_follows = False
         ctx.layer, ctx.gi, ctx.saved, ctx.lead = layer, gi, saved, lead
+        if saved.get("plan") is not None:
+            # a graph that is dropped without a backward gives the kept plan workspace back (else every later step
+            # would allocate a fresh one on the side stream)
+            weakref.finalize(ctx, _release_plan_of, weakref.ref(layer), gi, saved["plan"][2])
         g = layer._sgroups[gi]
         return (slab,) + _split_columns(slab, len(g.paths), g.dim, lead)
 
@@ -412,6 +447,14 @@ class ShardedDistributedEmbedding(base.Layer):
                                                     name=f"{self.name}_replicated")
         self._anchor = None
         self._xstream = None              # exchange stream of prefetch()
+        # The owner-side backward plan (sort of the received rows) depends on the ids alone: on the GPU it runs at FORWARD
+        # time on a side stream, under the pool / all-to-all / dense part of the step, instead of in front of the table
+        # update in the backward (KRS_SHARD_PLAN_AHEAD=0 for an A/B).  One workspace per group is kept across steps.
+        self.plan_ahead = bool(int(os.environ.get("KRS_SHARD_PLAN_AHEAD", "1")))
+        self._plan_stream = None
+        self._plan_ws: dict = {}          # group -> workspace tensor kept across steps
+        self._plan_busy: dict = {}        # group -> a pending backward still owns that workspace
+        self.plans_ahead = 0              # lookups whose plan ran ahead (tests / diagnostics)
         self._prefetched: dict = {}       # group -> what prefetch() ran ahead for the next call
         self.prefetch_hits = 0
         self.slab_grad_gathers = 0        # backward passes that gathered the segment gradients out of the slab gradient
@@ -858,6 +901,41 @@ class ShardedDistributedEmbedding(base.Layer):
                                         stats=stats, event=ev)
         return inputs
 
+    def _plan_ahead(self, gi, g, rows, off, saved) -> None:
+        """Starts the backward plan of this lookup on the plan stream (see `plan_ahead`); the backward joins it."""
+        k = self.kernels
+        if not (self.plan_ahead and rows.is_cuda and getattr(self, "_backward_follows", False) and hasattr(k, "plan_segments")
+                and rows.numel() and off.numel() > 1):
+            return
+        dev = rows.device
+        shard, slot = getattr(self, g.pname).data, self._slot(g)
+        k.prepare_plan(shard, slot, rows, off)                 # descriptor uploads on the main stream, before the fork
+        main = torch.cuda.current_stream(dev)
+        side = self._plan_stream
+        if side is None:
+            side = self._plan_stream = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        busy = self._plan_busy.get(gi, False)
+        keep = None if busy else self._plan_ws.get(gi)
+        with torch.cuda.stream(side):
+            ws = k.plan_segments(shard, slot, rows, off, ws=keep)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        owns = [False]
+        if not busy and ws is not None:
+            self._plan_ws[gi], self._plan_busy[gi] = ws, True
+            owns[0] = True
+        for t in (ws, rows, off):
+            if t is not None:
+                t.record_stream(side)
+        saved["plan"] = (ws, ev, owns)
+        self.plans_ahead += 1
+
+    def _release_plan(self, gi, owns) -> None:
+        if owns[0]:
+            owns[0] = False
+            self._plan_busy[gi] = False
+
     def _forward_static(self, gi, g, cap, key, ids, batch, hots, offsets, weights, lead, emit_w):
         k, n = self.kernels, self.world
         cap_l, cap_s = cap
@@ -903,6 +981,7 @@ class ShardedDistributedEmbedding(base.Layer):
         self._note_stats(gi, stats, key)
         saved = dict(batch=batch, seg_grow=r["seg_grow"], send_segs=None, recv_segs=None,
                      rows=rows, off=off, w=w, pdt=pdt, out_meta=(slab.dtype, slab.device))
+        self._plan_ahead(gi, g, rows, off, saved)
         return slab, saved
 
     def _forward_impl(self, gi, ids, batch, hots, offsets, weights, lead):
@@ -951,6 +1030,7 @@ class ShardedDistributedEmbedding(base.Layer):
                 slab = slab.to(self.compute_dtype)
         saved = dict(batch=batch, seg_grow=r["seg_grow"][:n_seg], send_segs=send_segs, recv_segs=recv_segs,
                      rows=rows, off=off, w=w, pdt=pdt, out_meta=(slab.dtype, slab.device))
+        self._plan_ahead(gi, g, rows, off, saved)
         return slab, saved
 
     def _backward_impl(self, gi, grad, s, slab_grad=None, lead_slots=0):
@@ -980,6 +1060,20 @@ class ShardedDistributedEmbedding(base.Layer):
             dseg = self._a2a(dpart, s["send_segs"], s["recv_segs"])               # to the owners
         lr = g.fused.lr_at(g.step)
         g.step += 1
+        plan = s.get("plan")
+        ws = None
+        if plan is not None:
+            ws, ev, owns = plan
+            cur = torch.cuda.current_stream(s["rows"].device)
+            cur.wait_event(ev)                      # the plan ran ahead on the plan stream: join it here
+            if ws is not None:
+                ws.record_stream(cur)
         with probe.span("k2"):
-            k.apply_segments(getattr(self, g.pname).data, self._slot(g), s["rows"], s["off"], s["w"], dseg, lr,
-                             g.fused.kind, g.fused.hyper(g.step), 1.0 / self.world if self.grad_average else 1.0)
+            if ws is not None:
+                k.apply_segments(getattr(self, g.pname).data, self._slot(g), s["rows"], s["off"], s["w"], dseg, lr,
+                                 g.fused.kind, g.fused.hyper(g.step), 1.0 / self.world if self.grad_average else 1.0, ws=ws)
+            else:     # (kernels without plan_segments -- the oracle-backed test kernels -- plan inside the call)
+                k.apply_segments(getattr(self, g.pname).data, self._slot(g), s["rows"], s["off"], s["w"], dseg, lr,
+                                 g.fused.kind, g.fused.hyper(g.step), 1.0 / self.world if self.grad_average else 1.0)
+        if plan is not None:
+            self._release_plan(gi, plan[2])       # (the next forward's plan is ordered behind this apply: it may take the buffer)

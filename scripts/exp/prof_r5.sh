@@ -1,0 +1,31 @@
+# Round-5 evidence runs (one gpurun call each).  Files land in gpurun_out/$TAG/ and are copied to profiles/ afterwards.
+#   prof_r5.sh TAG suite      GPU test suite + default bench line
+#   prof_r5.sh TAG sharded    the per-rank step of an 8-way job on one GPU (B_local = 8192): line + kernel trace
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r5a}
+WHAT=${2:-suite}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+if [[ $WHAT == *suite* ]]; then
+  timeout 900 python -m pytest tests -m gpu -x -q > $O/tests_gpu.log 2>&1; tail -3 $O/tests_gpu.log
+fi
+if [[ $WHAT == *bench* ]]; then
+  timeout 600 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err; tail -c 600 $O/bench_c3.err
+fi
+if [[ $WHAT == *sharded* ]]; then
+  timeout 300 python bench.py --force-sharded --batch 8192 --no-cpu-baseline > $O/sharded_b8192_static.json 2> $O/sharded_b8192_static.err
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/prof; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python $R/bench.py --force-sharded --batch 8192 --steps 8 --warmup 2 --no-cpu-baseline > $O/sharded_b8192_profiled.json 2>/dev/null
+  KRS_STATS_FULL_NAMES=1 python $R/scripts/rocpd_stats.py $(ls /tmp/prof/*/*.db /tmp/prof/*.db 2>/dev/null | head -1) 70 > $O/sharded_b8192_kernel_stats.md
+  cd $R
+fi
+python - <<PY
+import json, glob
+for f in sorted(glob.glob("$O/*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("/")[-1], round(d["ms_per_step"], 3), d["step_stats"]["median_ms"], d.get("roofline", {}).get("frac"), d.get("host_enqueue_ms_per_step"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY

@@ -21,7 +21,7 @@ def test_two_rank_bench_run_over_gloo():
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000"]
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000", "--sustained-steps", "4"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -31,6 +31,26 @@ def test_two_rank_bench_run_over_gloo():
     assert d["unit"] == "lookups/s" and d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
     assert "row-sharded over 2 GPUs" in d["config"]["parallelism"] and d["config"]["global_batch"] == 4096
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
+    # the N > 1 line checks ITSELF (round-4 review, next #1a): one step against an unsharded recompute of a slice, rows read
+    # back from their owners over the job's own collectives -- two ranks, real kernels on both
+    par = d["parity"]
+    assert par["checked"] and par["ok"] and "invalid" not in d, par
+    assert par["fwd_max_ulp"] == 0.0 and par["update_max_ulp"] <= 1.0 and par["rows_moved"] and par["checked_rows"] > 1000
+    assert d["sustained"]["steps"] == 4 and d["sustained"]["median_ms"] > 0
+
+
+def test_the_self_check_of_the_sharded_line_has_teeth():
+    """One table row moved behind the layer's back (KRS_BENCH_PARITY_SABOTAGE) before the checked step: `parity.ok` is false
+    and the line is marked invalid."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["KRS_BENCH_PARITY_SABOTAGE"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--batch", "2048", "--vocab", "20000", "--sustained-steps", "0", "--probe-steps", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["parity"]["checked"] and not d["parity"]["ok"] and d["parity"]["fwd_max_ulp"] > 1.0
+    assert "self-check" in d["invalid"]
 
 
 def _json_line(stdout):
@@ -42,7 +62,7 @@ def test_bare_bench_command_launches_its_own_ranks():
     than GPUs and the default backend it falls back to gloo and says so in the line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000"]
+           "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000", "--sustained-steps", "0"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
@@ -75,9 +95,20 @@ def test_sharded_step_through_a_one_rank_rccl_communicator():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     for exchange in ("static", "exact"):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--rccl-self", "--exchange", exchange,
-               "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--batch", "8192", "--vocab", "100000"]
+               "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--batch", "8192", "--vocab", "100000",
+               "--sustained-steps", "0"]
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         d = _json_line(r.stdout)
         assert d["backend"] == "nccl (RCCL)" and d["exchange"]["mode"] == exchange and d["a2a_bytes_per_step"] > 0
         assert "one-rank RCCL communicator" in d["config"]["parallelism"]
+        # the self-check ran over the RCCL communicator too, and -- static exchange -- the step was captured into a HIP graph
+        # WITH its collectives and replayed behind the eager legs; the faster leg is `value`, both are in the line
+        assert d["parity"]["ok"] and d["parity"]["fwd_max_ulp"] == 0.0
+        if exchange == "static":
+            gl = d["graph_leg"]
+            assert gl["attempted"] and gl["ok"], gl
+            assert gl["ms_per_step"] > 0 and gl["host_enqueue_ms_per_step"] < gl["ms_per_step"]
+            assert ("eager_leg" in d) == bool(gl.get("promoted_to_value"))
+        else:
+            assert "graph_leg" not in d
