@@ -95,6 +95,9 @@ def parse():
     ap.add_argument("--no-c2", action="store_true",
                     help="skip the `also_c2` leg (BASELINE.json configs[1]: 8 tables x 100k x 64 fp32, 3 full-rank FeatureCross, "
                          "batch 8192, fp32)")
+    ap.add_argument("--c2-leg", action="store_true",
+                    help="(internal) run ONLY the C2 leg and print its object: the default run starts this in a process of its "
+                         "own, so that the leg's graph capture cannot take the headline line with it")
     ap.add_argument("--no-parity", action="store_true",
                     help="sharded runs: skip the self-check of one step against an unsharded recompute of a slice (`parity`)")
     ap.add_argument("--no-graph-leg", action="store_true",
@@ -646,7 +649,8 @@ def measure_c2(a, dev):
     model = Model(c, hots, 1, 0)
     model.embedding.build(None)
     steps, warm = 100, 10
-    r = measure(model, c, hots, 1, 0, dev, c.batch, steps, warm, [None], probe_steps=3, sustained_steps=0)
+    opt_box = [None]
+    r = measure(model, c, hots, 1, 0, dev, c.batch, steps, warm, opt_box, probe_steps=3, sustained_steps=0)
     ms = r["elapsed"] / steps * 1e3
     out = {"workload": "C2 (BASELINE.json configs[1]): 8 tables x 100000 rows x 64 fp32, batch 8192, hotness L = 1, uniform ids, "
                        "3 x full-rank FeatureCross(d=512) fp32, fused Adagrad on tables; no DotInteraction (the config has none)",
@@ -660,6 +664,18 @@ def measure_c2(a, dev):
     rs = roofline_step(c, hots, c.batch, r)
     if rs:
         out["roofline_step"] = rs
+    if getattr(a, "c2_leg", False):
+        # (own process, see main(): the first and only capture of this process) the same step replayed from a HIP graph --
+        # one hipGraphLaunch per step instead of ~40 Python / ctypes launches
+        c.graph, c._graph_used = True, False
+        rg = measure(model, c, hots, 1, 0, dev, c.batch, steps, warm, opt_box, probe_steps=0)
+        g_ms = rg["elapsed"] / steps * 1e3
+        out["graph_replay"] = {"ms_per_step": g_ms, "value": c.batch * sum(hots) / (rg["elapsed"] / steps),
+                               "step_stats": step_stats(rg["step_ms"]), "host_enqueue_ms_per_step": rg["enqueue_s"] / steps * 1e3,
+                               "launch": "every timed step is one replay of a HIP graph captured from the eager step"}
+        if g_ms < ms:
+            out["eager"] = {"ms_per_step": ms, "value": out["value"]}
+            out.update(ms_per_step=g_ms, value=out["graph_replay"]["value"], launch=out["graph_replay"]["launch"])
     del model
     torch.cuda.empty_cache()
     return out
@@ -725,9 +741,9 @@ def sharded_parity(model, a, hots, world, rank, dev, b_local, ids, pre, backend)
         acc = allreduce(slot[local] * own[:, None])
         return w, acc
 
-    if os.environ.get("KRS_BENCH_PARITY_SABOTAGE") and rank == 0:      # (tests: the check must notice a wrong row)
-        shard[int(local[own][0])] += 1.0
     w0, acc0 = read_rows()
+    if os.environ.get("KRS_BENCH_PARITY_SABOTAGE") and rank == 0:      # (tests: the check must notice a row that is not
+        shard[int(local[own][0])] += 1.0                               #  what its owner was asked for)
     lr = float(g.fused.lr_at(g.step))
     out = emb(pre)
     got = torch.stack([out[p][:s_n].detach().float() for p in g.paths], 1)          # [S, F, D]
@@ -790,7 +806,9 @@ def sharded_parity(model, a, hots, world, rank, dev, b_local, ids, pre, backend)
                "rows read back from their owners); updated rows vs acc += g^2, w -= lr g / sqrt(acc) with g = global lookup "
                "count x the step's constant output gradient; no oracle, no CPU path",
     }
-    res["ok"] = bool(res["fwd_max_ulp"] <= 1.0 and res["update_max_ulp"] <= 1.0 and res["accumulator_max_rel_err"] <= 1e-6
+    # (one bf16 ulp on the updated weights: the kernel's lr g / sqrt(acc) in fp32 against this check's float64; the ulp
+    #  distance itself is computed in fp32, hence the 1e-3 of slack)
+    res["ok"] = bool(res["fwd_max_ulp"] <= 1.001 and res["update_max_ulp"] <= 1.001 and res["accumulator_max_rel_err"] <= 1e-6
                      and moved)
     return res
 
@@ -1016,6 +1034,9 @@ def main():
     from keras_rs_amd import autograd as krs_autograd
 
     krs_autograd.set_wgrad_side_stream(bool(int(os.environ.get("KRS_WGRAD_SIDE", "0"))))
+    if a.c2_leg:
+        print(json.dumps(measure_c2(a, dev)))
+        return
     model = Model(a, primary, world, rank)
     model.embedding.build(None)
     opt_box = [None]
@@ -1036,7 +1057,15 @@ def main():
     elapsed, k1_s, elapsed2, k1_s2 = r1["elapsed"], r1["k1_s"], r2["elapsed"], r2["k1_s"]
     c2 = None
     if not a.no_c2 and world == 1 and not a.force_sharded and not a.criteo_vocab and not a.graph:
-        c2 = measure_c2(a, dev)
+        # in a process of its own (its graph capture is then the first of a process, and a failure costs this leg only)
+        import subprocess
+
+        try:
+            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c2-leg", "--no-cpu-baseline"], capture_output=True,
+                                text=True, timeout=420)
+            c2 = json.loads([ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        except Exception as e:   # noqa: BLE001
+            c2 = {"error": "the C2 leg's process failed: " + repr(e)[:300]}
     host = None
     if a.host_inputs > 0 and world == 1 and not a.force_sharded:
         # ids start in host memory: a small pool of batches cycles through the loader threads, which

@@ -29,3 +29,20 @@ for f in sorted(glob.glob("$O/*.json")):
     except Exception as e:
         print(f, "unreadable", e)
 PY
+if [[ $WHAT == *planab* ]]; then
+  # A/B of the owner-side backward plan running ahead on a side stream (KRS_SHARD_PLAN_AHEAD), eager and through the one-rank RCCL communicator + graph leg
+  for v in 1 0 1 0; do
+    KRS_SHARD_PLAN_AHEAD=$v timeout 300 python bench.py --force-sharded --batch 8192 --no-cpu-baseline --sustained-steps 0 --probe-steps 0 --no-parity > $O/planab_$v.json 2>/dev/null
+    python - <<PY
+import json
+d = json.loads(open("$O/planab_$v.json").read().strip().splitlines()[-1])
+print("plan_ahead=$v", round(d["ms_per_step"], 3), d["step_stats"]["median_ms"], "L=1", round(d["also"]["ms_per_step"], 3), "host", round(d["host_enqueue_ms_per_step"], 3))
+PY
+  done
+  timeout 400 python bench.py --force-sharded --rccl-self --batch 8192 --no-cpu-baseline > $O/sharded_b8192_rccl_one_rank.json 2> $O/sharded_b8192_rccl_one_rank.err
+  python - <<PY
+import json
+d = json.loads(open("$O/sharded_b8192_rccl_one_rank.json").read().strip().splitlines()[-1])
+print("rccl one rank: value leg", round(d["ms_per_step"], 3), "eager", (d.get("eager_leg") or {}).get("ms_per_step"), "graph", d.get("graph_leg"), "parity", d.get("parity"))
+PY
+fi

@@ -35,7 +35,7 @@ def test_two_rank_bench_run_over_gloo():
     # back from their owners over the job's own collectives -- two ranks, real kernels on both
     par = d["parity"]
     assert par["checked"] and par["ok"] and "invalid" not in d, par
-    assert par["fwd_max_ulp"] == 0.0 and par["update_max_ulp"] <= 1.0 and par["rows_moved"] and par["checked_rows"] > 1000
+    assert par["fwd_max_ulp"] == 0.0 and par["update_max_ulp"] <= 1.001 and par["rows_moved"] and par["checked_rows"] > 1000
     assert d["sustained"]["steps"] == 4 and d["sustained"]["median_ms"] > 0
 
 

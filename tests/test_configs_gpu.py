@@ -93,24 +93,40 @@ def test_c2_eight_tables_three_full_rank_cross_layers_fp32():
         us.append(u)
         rl = r0 * u + rl
     rl.backward(g.double().cpu())
-    # (weight gradients are fp32 sums of 8192 products of magnitude <= 1: 1e-4 of the column scale, ~ 1e-4 absolute)
-    for layer, (k, b) in zip(layers, W):
-        np.testing.assert_allclose(layer.weights[0].grad.cpu().numpy(), k.grad.numpy(), rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(layer.weights[1].grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-4)
-        # ... and the north star's 1e-5 as a bound on the gradient as a whole (largest error against largest entry)
-        for got, ref in ((layer.weights[0].grad, k.grad), (layer.weights[1].grad, b.grad)):
-            assert np.abs(got.cpu().numpy() - ref.numpy()).max() <= 1e-5 * np.abs(ref.numpy()).max()
-    # ELEMENT-wise 1e-5 (round-3 review): every entry of dK = x^T dz is a sum of 8192 products; its fp32 error is bounded
-    # relative to the sum of the products' MAGNITUDES (entries that cancel to ~0 have no meaningful relative error of
-    # their own).  |got - ref|_ij <= 1e-5 * (|x|^T |dz|)_ij for every entry, likewise the bias gradient against sum |dz|.
-    for layer, (k, b), x_l, u_l in zip(layers, W, xs, us):
+    # Weight gradients, element by element against the float64 composition (round-4 review, next #5a).  Every entry of
+    # dK = x^T dz is an fp32 sum of 8192 signed products; what fp32 can promise is an error relative to the sum of the
+    # products' MAGNITUDES, S_ij = (|x|^T |dz|)_ij -- an entry whose products cancel (|ref| << S) has no meaningful relative
+    # error of its own.  The test SELECTS the entries per element instead of loosening the tolerance globally:
+    #   (1) entries that do not cancel by more than 32x (|ref| >= S / 32): the stated tolerance, rtol = 1e-5;
+    #   (2) every entry: |got - ref| <= 1e-5 * S  (the magnitude-scaled 1e-5);
+    #   (3) the cancelling entries only: the old element-wise bound rtol = 1e-4, atol = 1e-4;
+    #   (4) the worst scaled error is no larger than 4x that of the SAME gradient evaluated in fp32 by torch on the CPU
+    #       (the reference's own arithmetic on its CPU path): the HIP path is as close to float64 as fp32 gets.
+    # The assertion messages carry the worst errors and the share of entries in each class.
+    def check_sum_gradient(name, got, ref, scale, fp32_twin):
+        got64 = got.astype(np.float64)
+        err = np.abs(got64 - ref)
+        well = np.abs(ref) * 32.0 >= scale
+        worst_rel = float((err[well] / np.abs(ref[well])).max()) if well.any() else 0.0
+        worst_scaled = float((err / (scale + 1e-300)).max())
+        twin_scaled = float((np.abs(fp32_twin.astype(np.float64) - ref) / (scale + 1e-300)).max())
+        msg = ("%s: %.1f %% of the entries do not cancel (|ref| >= S/32), their worst relative error is %.3g (bound 1e-5); worst "
+               "|err| / S over all entries %.3g (bound 1e-5; the fp32 CPU composition: %.3g)"
+               % (name, 100.0 * well.mean(), worst_rel, worst_scaled, twin_scaled))
+        print(msg)
+        assert well.mean() > 0.02, msg
+        assert worst_rel <= 1e-5, msg
+        assert (err <= 1e-5 * scale + 1e-30).all(), msg
+        np.testing.assert_allclose(got64[~well], ref[~well], rtol=1e-4, atol=1e-4, err_msg=msg)
+        assert worst_scaled <= 4.0 * twin_scaled + 1e-9, msg
+
+    for li, (layer, (k, b), x_l, u_l) in enumerate(zip(layers, W, xs, us)):
         dz = u_l.grad
-        scale_k = (x_l.abs().T @ dz.abs()).numpy()
-        err_k = np.abs(layer.weights[0].grad.cpu().numpy().astype(np.float64) - k.grad.numpy())
-        assert (err_k <= 1e-5 * scale_k + 1e-30).all(), float((err_k / (scale_k + 1e-30)).max())
-        scale_b = dz.abs().sum(0).numpy()
-        err_b = np.abs(layer.weights[1].grad.cpu().numpy().astype(np.float64) - b.grad.numpy())
-        assert (err_b <= 1e-5 * scale_b + 1e-30).all(), float((err_b / (scale_b + 1e-30)).max())
+        twin_k = (x_l.float().T @ dz.float()).numpy()                 # the same sums in fp32 on the CPU
+        twin_b = dz.float().sum(0).numpy()
+        check_sum_gradient(f"layer {li} dK", layer.weights[0].grad.cpu().numpy(), k.grad.numpy(),
+                           (x_l.abs().T @ dz.abs()).numpy(), twin_k)
+        check_sum_gradient(f"layer {li} dbias", layer.weights[1].grad.cpu().numpy(), b.grad.numpy(), dz.abs().sum(0).numpy(), twin_b)
     # embedding-table gradient = scatter-add of the x0 gradient slices (index work: exact rows, 1e-5 values)
     dx0 = r0.grad.numpy()
     for t in (0, 5):
@@ -118,4 +134,16 @@ def test_c2_eight_tables_three_full_rank_cross_layers_fp32():
         np.add.at(dense, ids[f"f{t}"], dx0[:, t * D:(t + 1) * D])
         got = emb.weights[t].grad.cpu().numpy()
         assert np.array_equal(np.nonzero(np.abs(got).sum(1))[0], np.nonzero(np.abs(dense).sum(1))[0])
-        np.testing.assert_allclose(got, dense, rtol=1e-4, atol=1e-5)
+        # values: a touched row is the sum of <= a few slices of dL/dx0, itself a 512-term fp32 sum per element (dz K^T) on top
+        # of the direct terms: rtol = 1e-5 against float64 wherever the element does not cancel against the slice's scale
+        # (|ref| >= 1e-2 x the largest entry of its row), the magnitude-scaled 1e-5 (of the row's largest entry) everywhere
+        err = np.abs(got.astype(np.float64) - dense)
+        row_max = np.abs(dense).max(1, keepdims=True)
+        well = np.abs(dense) >= 1e-2 * row_max
+        well &= row_max > 0
+        worst_rel = float((err[well] / np.abs(dense[well])).max())
+        worst_scaled = float((err / (row_max + 1e-300)).max())
+        msg = "table %d: worst relative error %.3g on %.1f %% of the elements, worst |err| / row max %.3g" % (
+            t, worst_rel, 100.0 * well.mean(), worst_scaled)
+        print(msg)
+        assert worst_rel <= 1e-5 and worst_scaled <= 1e-5, msg
