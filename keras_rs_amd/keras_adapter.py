@@ -195,28 +195,32 @@ def make_layers(keras) -> types.SimpleNamespace:
         # itself: every entry of the torch state_dict (tables or stacks, slot planes; bf16 as float32, which holds
         # it exactly) plus the per-group iteration counts.  Counterpart of the slot variables the reference adds to
         # the layer (jax/distributed_embedding.py:316-345) so that they are checkpointed with it.
+        # The store is used through the surface saving_lib's H5Entry / NpzIOStore entries offer and no further: item
+        # assignment, item access read with `[...]`, `keys()` -- no `in`, no nested keys (a "/" would ask the store for a
+        # group of its own): the step counts travel as "iterations__<group>".
         def save_own_variables(self, store):
             import numpy as np
 
             sd = self._impl.state_dict()
             extra = sd.pop("_extra_state", None)
             for k, v in sd.items():
-                store[k] = (v.float() if v.dtype == torch.bfloat16 else v).detach().cpu().numpy()
+                store[k.replace("/", "__")] = (v.float() if v.dtype == torch.bfloat16 else v).detach().cpu().numpy()
             its = (extra or {}).get("iterations", {})
             for k, n in its.items():
-                store["iterations/" + k] = np.asarray(int(n), np.int64)
+                store["iterations__" + str(k).replace("/", "__")] = np.asarray(int(n), np.int64)
 
         def load_own_variables(self, store):
             if not self.built:
                 self.build(None)
             sd = self._impl.state_dict()
             extra = sd.pop("_extra_state", None)
-            missing = [k for k in sd if k not in store]
+            have = set(store.keys())
+            missing = [k for k in sd if k.replace("/", "__") not in have]
             if missing:
                 raise ValueError(f"DistributedEmbedding.load_own_variables: the checkpoint lacks {missing}")
-            new = {k: torch.as_tensor(store[k][...]).to(v.dtype) for k, v in sd.items()}
-            its = {k: int(store["iterations/" + k][...]) for k in (extra or {}).get("iterations", {})
-                   if "iterations/" + k in store}
+            new = {k: torch.as_tensor(store[k.replace("/", "__")][...]).to(v.dtype) for k, v in sd.items()}
+            its = {k: int(store["iterations__" + str(k).replace("/", "__")][...]) for k in (extra or {}).get("iterations", {})
+                   if "iterations__" + str(k).replace("/", "__") in have}
             if extra is not None:     # (a module without extra state rejects the key under strict loading)
                 new["_extra_state"] = {"iterations": its}
             self._impl.load_state_dict(new)

@@ -46,3 +46,15 @@ d = json.loads(open("$O/sharded_b8192_rccl_one_rank.json").read().strip().splitl
 print("rccl one rank: value leg", round(d["ms_per_step"], 3), "eager", (d.get("eager_leg") or {}).get("ms_per_step"), "graph", d.get("graph_leg"), "parity", d.get("parity"))
 PY
 fi
+if [[ $WHAT == *newtests* ]]; then
+  timeout 1200 python -m pytest tests/test_configs_gpu.py tests/test_bench_multiproc_gpu.py tests/test_full_size_properties_gpu.py tests/test_dense_ops_gpu.py tests/test_embed_bag_bwd_gpu.py "tests/test_layers_gpu.py::test_a_forward_without_a_backward_leaves_no_stale_bookkeeping" tests/test_graph_step_gpu.py tests/test_sharded_gpu.py -q -s -m gpu > $O/newtests.log 2>&1
+  grep -E "passed|failed|do not cancel|table [0-9]+:|Error|error" $O/newtests.log | head -60
+fi
+if [[ $WHAT == *rccl1* ]]; then
+  timeout 400 python bench.py --force-sharded --rccl-self --batch 8192 --no-cpu-baseline > $O/sharded_b8192_rccl_one_rank.json 2> $O/sharded_b8192_rccl_one_rank.err
+  python - <<PY
+import json
+d = json.loads(open("$O/sharded_b8192_rccl_one_rank.json").read().strip().splitlines()[-1])
+print("rccl one rank: value leg", round(d["ms_per_step"], 3), "eager", (d.get("eager_leg") or {}).get("ms_per_step"), "graph", {k: v for k, v in (d.get("graph_leg") or {}).items() if k != "step_stats"}, "parity ok", d["parity"]["ok"], d["parity"]["update_max_ulp"])
+PY
+fi

@@ -97,7 +97,8 @@ def test_c2_eight_tables_three_full_rank_cross_layers_fp32():
     # dK = x^T dz is an fp32 sum of 8192 signed products; what fp32 can promise is an error relative to the sum of the
     # products' MAGNITUDES, S_ij = (|x|^T |dz|)_ij -- an entry whose products cancel (|ref| << S) has no meaningful relative
     # error of its own.  The test SELECTS the entries per element instead of loosening the tolerance globally:
-    #   (1) entries that do not cancel by more than 32x (|ref| >= S / 32): the stated tolerance, rtol = 1e-5;
+    #   (1) entries that do not cancel by more than 128x (|ref| >= S / 128; about 55 % of dK): the stated tolerance, rtol = 1e-5
+    #       (measured on MI355X: worst relative error 5e-6 there; worst |err| / S over ALL entries 4.1e-8, the fp32 CPU twin 2.7e-8);
     #   (2) every entry: |got - ref| <= 1e-5 * S  (the magnitude-scaled 1e-5);
     #   (3) the cancelling entries only: the old element-wise bound rtol = 1e-4, atol = 1e-4;
     #   (4) the worst scaled error is no larger than 4x that of the SAME gradient evaluated in fp32 by torch on the CPU
@@ -106,15 +107,15 @@ def test_c2_eight_tables_three_full_rank_cross_layers_fp32():
     def check_sum_gradient(name, got, ref, scale, fp32_twin):
         got64 = got.astype(np.float64)
         err = np.abs(got64 - ref)
-        well = np.abs(ref) * 32.0 >= scale
+        well = np.abs(ref) * 128.0 >= scale
         worst_rel = float((err[well] / np.abs(ref[well])).max()) if well.any() else 0.0
         worst_scaled = float((err / (scale + 1e-300)).max())
         twin_scaled = float((np.abs(fp32_twin.astype(np.float64) - ref) / (scale + 1e-300)).max())
-        msg = ("%s: %.1f %% of the entries do not cancel (|ref| >= S/32), their worst relative error is %.3g (bound 1e-5); worst "
+        msg = ("%s: %.1f %% of the entries do not cancel (|ref| >= S/128), their worst relative error is %.3g (bound 1e-5); worst "
                "|err| / S over all entries %.3g (bound 1e-5; the fp32 CPU composition: %.3g)"
                % (name, 100.0 * well.mean(), worst_rel, worst_scaled, twin_scaled))
         print(msg)
-        assert well.mean() > 0.02, msg
+        assert well.mean() > 0.2, msg
         assert worst_rel <= 1e-5, msg
         assert (err <= 1e-5 * scale + 1e-30).all(), msg
         np.testing.assert_allclose(got64[~well], ref[~well], rtol=1e-4, atol=1e-4, err_msg=msg)
@@ -136,10 +137,10 @@ def test_c2_eight_tables_three_full_rank_cross_layers_fp32():
         assert np.array_equal(np.nonzero(np.abs(got).sum(1))[0], np.nonzero(np.abs(dense).sum(1))[0])
         # values: a touched row is the sum of <= a few slices of dL/dx0, itself a 512-term fp32 sum per element (dz K^T) on top
         # of the direct terms: rtol = 1e-5 against float64 wherever the element does not cancel against the slice's scale
-        # (|ref| >= 1e-2 x the largest entry of its row), the magnitude-scaled 1e-5 (of the row's largest entry) everywhere
+        # (|ref| >= 3e-2 x the largest entry of its row), the magnitude-scaled 1e-5 (of the row's largest entry) everywhere
         err = np.abs(got.astype(np.float64) - dense)
         row_max = np.abs(dense).max(1, keepdims=True)
-        well = np.abs(dense) >= 1e-2 * row_max
+        well = np.abs(dense) >= 3e-2 * row_max
         well &= row_max > 0
         worst_rel = float((err[well] / np.abs(dense[well])).max())
         worst_scaled = float((err / (row_max + 1e-300)).max())
