@@ -675,7 +675,10 @@ def measure_c2(a, dev):
                                "launch": "every timed step is one replay of a HIP graph captured from the eager step"}
         if g_ms < ms:
             out["eager"] = {"ms_per_step": ms, "value": out["value"]}
-            out.update(ms_per_step=g_ms, value=out["graph_replay"]["value"], launch=out["graph_replay"]["launch"])
+            out.update(ms_per_step=g_ms, value=out["graph_replay"]["value"], launch=out["graph_replay"]["launch"],
+                       step_stats=out["graph_replay"]["step_stats"],
+                       host_enqueue_ms_per_step=out["graph_replay"]["host_enqueue_ms_per_step"])
+            out["eager"].update(host_enqueue_ms_per_step=r["enqueue_s"] / steps * 1e3, step_stats=step_stats(r["step_ms"]))
     del model
     torch.cuda.empty_cache()
     return out

@@ -58,3 +58,23 @@ d = json.loads(open("$O/sharded_b8192_rccl_one_rank.json").read().strip().splitl
 print("rccl one rank: value leg", round(d["ms_per_step"], 3), "eager", (d.get("eager_leg") or {}).get("ms_per_step"), "graph", {k: v for k, v in (d.get("graph_leg") or {}).items() if k != "step_stats"}, "parity ok", d["parity"]["ok"], d["parity"]["update_max_ulp"])
 PY
 fi
+if [[ $WHAT == *tests2* ]]; then
+  timeout 1200 python -m pytest tests/test_c5_full_gpu.py tests/test_keras_adapter.py tests/test_configs_gpu.py tests/test_bench_multiproc_gpu.py -q -s -m gpu --durations=8 > $O/tests2.log 2>&1
+  grep -E "passed|failed|do not cancel|table [0-9]+:|Error|error|^[0-9.]+s " $O/tests2.log | head -60
+fi
+if [[ $WHAT == *stacks* ]]; then
+  timeout 400 python scripts/prof_step_stacks.py > $O/aten_in_step_c3.md 2> $O/aten_in_step_c3.err; head -30 $O/aten_in_step_c3.md
+  timeout 400 python scripts/prof_step_stacks.py --force-sharded --batch 8192 > $O/aten_in_step_sharded_b8192.md 2> $O/aten_in_step_sharded.err; head -40 $O/aten_in_step_sharded_b8192.md
+fi
+if [[ $WHAT == *k2split* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  for sub in all hot100 hot1 mid; do
+    python $R/scripts/exp/k2_split.py --subset $sub >> $O/k2_split.txt 2>/dev/null
+    for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+      rm -rf /tmp/pmc; timeout 200 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc -o p -- python $R/scripts/exp/k2_split.py --subset $sub --iters 2 > /dev/null 2>&1
+      echo "subset=$sub counters=[$c]" >> $O/k2_split.txt
+      python $R/scripts/rocpd_pmc.py $(ls /tmp/pmc/*/*.db /tmp/pmc/*.db 2>/dev/null | head -1) | grep -E "bag_apply_fast_kernel" >> $O/k2_split.txt
+    done
+  done
+  cd $R; cat $O/k2_split.txt
+fi

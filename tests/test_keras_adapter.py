@@ -303,7 +303,7 @@ def test_dlrm_dcn_v2_shaped_model_on_the_adapter_in_the_order_of_the_reference_e
         loss.backward()
         with torch.no_grad():                                                    # plain SGD on the trainable Keras weights
             for v in model.trainable_weights:
-                v.value -= 0.1 * v.value.grad
+                v.value.sub_(0.1 * v.value.grad)
                 v.value.grad = None
         return float(loss)
 
