@@ -672,7 +672,9 @@ class EmbedBagFusedFn(torch.autograd.Function):
         if ctx.owns_plan_ws:
             # (the next forward's plan is ordered behind this apply: it may take the buffer)
             _release_plan_ws(weakref.ref(bags), ctx.owns_plan_ws)
-        return (None, None, None, None, None, None, None, None, torch.zeros((), device=g.device), None, None)
+        # (no gradient for the anchor -- it exists only to make autograd call this function; a zero tensor here cost a fill and an
+        #  accumulate launch per step)
+        return (None,) * 11
 
 
 class SlabFillFn(torch.autograd.Function):

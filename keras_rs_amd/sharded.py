@@ -332,7 +332,7 @@ class _ShardedLookupFn(torch.autograd.Function):
         else:
             grad = _sum_slab_and_feature_grads(g_slab, gs, lead, ctx.saved["batch"], n, g.dim, out_dtype, device)
             layer._backward_impl(ctx.gi, grad, ctx.saved)
-        return (None, None, None, None, None, None, None, None, torch.zeros((), device=device))
+        return (None,) * 9     # (the anchor gets no gradient: it only makes autograd call this function)
 
 
 class ShardedDistributedEmbedding(base.Layer):

@@ -78,3 +78,19 @@ if [[ $WHAT == *k2split* ]]; then
   done
   cd $R; cat $O/k2_split.txt
 fi
+if [[ $WHAT == *trace* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/prof; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-c2 --sustained-steps 0 > $O/bench_c3_profiled.json 2>/dev/null
+  KRS_STATS_FULL_NAMES=1 python $R/scripts/rocpd_stats.py $(ls /tmp/prof/*/*.db /tmp/prof/*.db 2>/dev/null | head -1) 60 > $O/bench_c3_kernel_stats.md
+  rm -rf /tmp/prof; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o k -- python $R/scripts/bench_k1.py --multihot --iters 20 > $O/k1_k2_multihot.txt 2>/dev/null
+  KRS_STATS_FULL_NAMES=1 python $R/scripts/rocpd_stats.py $(ls /tmp/prof/*/*.db /tmp/prof/*.db 2>/dev/null | head -1) 30 > $O/k1_k2_standalone_kernel_stats.md
+  rm -rf /tmp/prof; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o k -- python $R/scripts/bench_k1.py --iters 20 > $O/k1_k2_hot1.txt 2>/dev/null
+  KRS_STATS_FULL_NAMES=1 python $R/scripts/rocpd_stats.py $(ls /tmp/prof/*/*.db /tmp/prof/*.db 2>/dev/null | head -1) 30 >> $O/k1_k2_standalone_kernel_stats.md
+  cd $R
+  head -12 $O/bench_c3_kernel_stats.md | cut -c1-200
+fi
+if [[ $WHAT == *full* ]]; then
+  timeout 400 python bench.py --full-model --no-cpu-baseline --no-c2 --sustained-steps 0 > $O/bench_c3_full_model.json 2>/dev/null
+  timeout 600 python bench.py --criteo-vocab 40000000 --id-skew 4 --no-c2 --sustained-steps 0 > $O/bench_c5_powerlaw.json 2>/dev/null
+  python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+fi

@@ -43,19 +43,19 @@ for _ in range(4):
     step()
 torch.cuda.synchronize()
 N = 3
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     for _ in range(N):
         step()
     torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or ev.cpu_children:
+rows = []
+for ev in prof.key_averages(group_by_input_shape=True, group_by_stack_n=8):
+    if not ev.key.startswith("aten::") or ev.device_time_total <= 0:
         continue
-    frames = [f for f in (ev.stack or []) if ("keras_rs_amd" in f or "bench" in f or "prof_step" in f) and "torch/" not in f]
-    key = (ev.name, " <- ".join(f.split("/")[-1] for f in frames[:3]))
-    agg[key][0] += 1
-    agg[key][1] += ev.device_time_total
-print("| aten op | launches per step | device us per step | python frames (innermost first) |")
-print("|---|---|---|---|")
-for (name, where), (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"| {name} | {cnt / N:.1f} | {us / N:.1f} | {where} |")
+    frames = [f for f in (ev.stack or []) if ("keras_rs_amd" in f or "bench" in f or "prof_step" in f or "examples" in f)]
+    rows.append((ev.self_device_time_total / N, ev.count / N, ev.key, str(ev.input_shapes)[:90],
+                 " <- ".join(f.split("/")[-1].strip() for f in frames[:3])))
+print("| aten op | calls per step | self device us per step | input shapes | python frames (innermost first) |")
+print("|---|---|---|---|---|")
+for us, cnt, name, shapes, where in sorted(rows, reverse=True):
+    if us > 0:
+        print(f"| {name} | {cnt:.1f} | {us:.1f} | {shapes} | {where} |")
