@@ -961,12 +961,17 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     kbeg = (int64_t)split * p.k_per_split;
     nkb = (min(p.k, kbeg + p.k_per_split) - kbeg) / 32;
   } else {
-    // the N tiles of one M panel run back to back on one XCD (workgroup id % 8) and share A in its L2
-    const int64_t m_tile = (slot / nt) * 8 + xcd;
+    // the N tiles of one M panel run back to back on one XCD (workgroup id % 8) and share A in its L2.  With split-K
+    // (outputs too small to fill the chip with 256x256 tiles: the per-rank products of a strongly-scaled job) the
+    // splits of a tile are neighbours on that XCD too: slot = ((m group * nt) + n tile) * splits + split
+    const int64_t tslot = slot / p.splits;
+    split = (int)(slot - tslot * p.splits);
+    const int64_t m_tile = (tslot / nt) * 8 + xcd;
     if (m_tile * TM >= p.m) return;
     m0 = m_tile * TM;
-    n0 = (slot % nt) * TN_;
-    nkb = p.k / 32;
+    n0 = (tslot % nt) * TN_;
+    kbeg = (int64_t)split * p.k_per_split;
+    nkb = (min(p.k, kbeg + p.k_per_split) - kbeg) / 32;
   }
 
   // DMA sources of this thread's two instructions per piece; `astep` / `bstep` = bytes per K block
@@ -980,8 +985,8 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
     for (int i = 0; i < 2; ++i) {
       const int r = (wave * 2 + i) * 16 + (lane >> 2);
       const int c = (lane & 3) ^ ((r >> 2) & 3);
-      ap[i] = p.a + min(m0 + r, p.m - 1) * p.lda * 2 + c * 16;
-      bp[i] = p.b + min(n0 + r, p.n - 1) * p.ldb * 2 + c * 16;
+      ap[i] = p.a + (min(m0 + r, p.m - 1) * p.lda + kbeg) * 2 + c * 16;
+      bp[i] = p.b + (min(n0 + r, p.n - 1) * p.ldb + kbeg) * 2 + c * 16;
     }
     astep = bstep = 64;
   } else {
@@ -1363,6 +1368,24 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_vec4_kernel(const GemmPa
   *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.c) + i * p.ldc + j) = v;
 }
 
+// eight columns per thread + the vector epilogue (bf16 or fp32 output, bias / activation / cross / residual forms): the
+// reduce of the K-contiguous split products (round 5), same slab order
+__global__ __launch_bounds__(256) void gemm_slab_reduce_vec8_kernel(const GemmParams p) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;   // group of 8 consecutive columns
+  const int64_t nq = p.n / 8;
+  if (q >= p.m * nq) return;
+  const int64_t i = q / nq, j = (q - i * nq) * 8;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = 0.0f;
+  for (int s = 0; s < p.splits; ++s) {
+    const float* src = p.slabs + ((int64_t)s * p.m + i) * p.n + j;
+    const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 4);
+    v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+  }
+  epilogue_store_vec8(p, i, j, v);
+}
+
 // any shape / alignment: one thread per output element
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmParams p, int in_dtype) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1412,6 +1435,18 @@ int pick_splits(int64_t m, int64_t n, int64_t k, int a_is_km) {
       if (s == 1 || cost < best) { best = cost; best_s = s; }
     }
     return best_s;
+  }
+  // K-contiguous products whose output is too small for 256x256 tiles to fill the chip (M = 8192 against N = 512: 64 tiles)
+  // but whose K is long: the ring kernel with the K range dealt to s workgroups per tile -- half the operand bytes per flop
+  // of the 128x128 kernel that ran these shapes until round 5, at the price of s fp32 slabs (h = x U at M = 8192: 59 -> 4x us,
+  // DESIGN.md section 4).  s * tiles ~ 256 workgroups, >= 512 of K per split, whole 32-k blocks.
+  if (!a_is_km && m >= 256 && n >= 256 && k >= 2048 && k % 32 == 0) {
+    const int64_t t256 = ceil_div(m, 256) * ceil_div(n, 256);
+    if (t256 < 192) {
+      int64_t s = 256 / t256;
+      while (s > 1 && (k / s < 512 || k % (s * 32) != 0)) --s;
+      if (s > 1) return (int)s;
+    }
   }
   const int64_t tiles = ceil_div(m, BM) * ceil_div(n, BN);
   if (tiles >= 256 || k < 4096) return 1;
@@ -1468,6 +1503,10 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
   // (K = 512: eight tiles, then a heavy epilogue) run better on the register-staged kernel, whose
   // 36 KB of LDS lets three workgroups share a CU and hide each other's epilogues.
   const bool dma_ok = !p.a_km && p.b_nk && p.splits == 1 && p.k % (ROW_BYTES / ES) == 0;
+  // split-K on the ring kernel (round 5): K-contiguous bf16 operands, every split a whole number of 32-k blocks and at
+  // least a ring's depth of them (pick_splits' nt branch hands out exactly such splits)
+  const bool ring_split = ES == 2 && !p.a_km && p.b_nk && p.splits > 1 && p.k % 32 == 0 && p.k_per_split % 32 == 0 &&
+                          p.k - (int64_t)(p.splits - 1) * p.k_per_split >= 128 && gemm_pipe() != 0;
   // development switch: 128 x 128 tiles at two workgroups per CU for every LDS-DMA shape (y = cross(h V): 474 us against 429)
   static const bool force128 = getenv("KRS_GEMM_FORCE128") != nullptr;
   const bool use_glds = dma_ok && (p.k >= 1024 || force128);
@@ -1478,8 +1517,9 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     // the ring kernel (gemm_pp256_kernel); krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, 0) sends these shapes to the 128x128
     // two-stage kernels below instead (same fragment layout, same k order per accumulator: bit-identical results -- the
     // reference schedule of tests/test_dense_ops_gpu.py and scripts/exp/gemm_bench)
-    if (dma_ok && gemm_pipe() != 0 && p.k >= 256 && p.k % 32 == 0 && p.m >= 256 && p.n >= 256 && fills256 && !force128) {
-      const dim3 grid256((unsigned)(ceil_div(ceil_div(p.m, 256), 8) * 8 * ceil_div(p.n, 256)));
+    if (((dma_ok && fills256) || ring_split) && gemm_pipe() != 0 && p.k >= 256 && p.k % 32 == 0 && p.m >= 256 && p.n >= 256 &&
+        !force128) {
+      const dim3 grid256((unsigned)(ceil_div(ceil_div(p.m, 256), 8) * 8 * ceil_div(p.n, 256) * p.splits));
       const int nt_ = (int)ceil_div(p.n, 256);
       // (the residual-add form with a short K -- dx = dh U^T + g -- was 4 % faster on a two-stage loop until its R
       // operands were fetched under the ring's tail: 340 -> 301 us)
@@ -1632,6 +1672,8 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
                         (reinterpret_cast<uintptr_t>(c) & 15) == 0;
       if (vec4)
         hipLaunchKernelGGL(gemm_slab_reduce_vec4_kernel, dim3((unsigned)ceil_div(m * (n / 4), 256)), dim3(256), 0, st, p);
+      else if (p.ep_vec && n % 8 == 0)
+        hipLaunchKernelGGL(gemm_slab_reduce_vec8_kernel, dim3((unsigned)ceil_div(m * (n / 8), 256)), dim3(256), 0, st, p);
       else
         hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)ceil_div(m * n, 256)), dim3(256), 0, st, p);
       KRS_CHECK_LAUNCH("gemm_slab_reduce_kernel");

@@ -94,3 +94,7 @@ if [[ $WHAT == *full* ]]; then
   timeout 600 python bench.py --criteo-vocab 40000000 --id-skew 4 --no-c2 --sustained-steps 0 > $O/bench_c5_powerlaw.json 2>/dev/null
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 fi
+if [[ $WHAT == *splitk* ]]; then
+  timeout 600 python -m pytest tests/test_dense_ops_gpu.py -q -x -m gpu -k "split_k or ring_gemm or fused_cross" > $O/splitk_tests.log 2>&1; tail -3 $O/splitk_tests.log
+  timeout 900 python -m pytest tests/test_layers_gpu.py tests/test_sharded_gpu.py tests/test_mlperf_model_gpu.py tests/test_graph_step_gpu.py -q -x -m gpu > $O/splitk_tests2.log 2>&1; tail -3 $O/splitk_tests2.log
+fi

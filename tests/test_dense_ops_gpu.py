@@ -568,3 +568,41 @@ def test_ring_gemm_equals_the_two_stage_kernels_bit_for_bit():
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
         else:
             assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("m,n,k,ep", [(8192, 512, 3456, None), (8192, 1024, 3456, "bias_relu"), (4096 + 64, 512 + 40, 2048 + 96, None)])
+def test_split_k_on_the_ring_kernel_for_outputs_too_small_to_fill_the_chip(m, n, k, ep):
+    """Round 5: K-contiguous bf16 products whose 256 x 256 tiles would not fill the chip (the per-rank `h = x U` / `dh = dz K^T`
+    of a strongly-scaled job: M = 8192 against N = 512 is 64 tiles) run the ring kernel with the K range dealt to several
+    workgroups per tile (fp32 slabs, fixed-order reduce with the vector epilogue) instead of one round of 128 x 128 tiles.
+    Against float64: the bf16 output is the fp32 sum rounded once (<= 1 ulp of the exact value); partial tiles, a K whose last
+    split is shorter, and the bias + ReLU epilogue of a Dense layer at that batch.  Run-to-run identical (no atomics)."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd import dense_ops as D
+
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(31)
+    a = ((torch.rand(m, k, device=dev, generator=gen) - 0.5)).to(torch.bfloat16)
+    bt = ((torch.rand(n, k, device=dev, generator=gen) - 0.5) * 0.2).to(torch.bfloat16)
+    wsb = int(L.lib().krs_gemm_workspace_bytes(C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int(0)))
+    assert wsb >= 2 * m * n * 4, "the shape is expected to take split-K"
+    bias = (torch.rand(n, device=dev, generator=gen) - 0.5) if ep else None
+    got, _ = D.gemm(a, bt, b_is_nk=True, bias=bias, act=L.ACT_RELU if ep else L.ACT_NONE)
+    again, _ = D.gemm(a, bt, b_is_nk=True, bias=bias, act=L.ACT_RELU if ep else L.ACT_NONE)
+    assert torch.equal(got, again)
+    rows = torch.cat([torch.arange(0, 256, device=dev), torch.arange(m - 130, m, device=dev)])
+    ref = a[rows].double() @ bt.double().t()
+    if ep:
+        ref = torch.relu(ref + bias.double())
+    # one bf16 rounding of an fp32 sum of k products of magnitude <= 0.05: relative 2^-8, absolute a few fp32 ulps of the sum's scale
+    torch.testing.assert_close(got[rows].double(), ref, rtol=2.0 ** -8 * 1.01, atol=1e-4)
+    # the reference schedule (pipeline 0: no ring) on the same split: same slabs order, other tile kernels -> same value to fp32 noise
+    try:
+        L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(0)), "krs_gemm_set_option")
+        ref0, _ = D.gemm(a, bt, b_is_nk=True, bias=bias, act=L.ACT_RELU if ep else L.ACT_NONE)
+    finally:
+        L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(4))
+    assert (got == ref0).float().mean() > 0.99
+    torch.testing.assert_close(got.float(), ref0.float(), rtol=2.0 ** -7, atol=1e-4)
