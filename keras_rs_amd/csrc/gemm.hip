@@ -1443,8 +1443,14 @@ int pick_splits(int64_t m, int64_t n, int64_t k, int a_is_km) {
   if (!a_is_km && m >= 256 && n >= 256 && k >= 2048 && k % 32 == 0) {
     const int64_t t256 = ceil_div(m, 256) * ceil_div(n, 256);
     if (t256 < 192) {
+      // (krs_gemm rounds the K per split up to whole 64-k tiles: the last split takes what is left, and must still hold
+      //  a ring's depth of 32-k blocks)
       int64_t s = 256 / t256;
-      while (s > 1 && (k / s < 512 || k % (s * 32) != 0)) --s;
+      auto fits = [&](int64_t q) {
+        const int64_t kps = ceil_div(ceil_div(k, q), 64) * 64, last = k - (q - 1) * kps;
+        return k / q >= 512 && last >= 128 && last % 32 == 0;
+      };
+      while (s > 1 && !fits(s)) --s;
       if (s > 1) return (int)s;
     }
   }
