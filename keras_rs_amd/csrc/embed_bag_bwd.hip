@@ -400,10 +400,13 @@ __global__ __launch_bounds__(kHistThreads) void hist_seg_kernel(const SegPass p)
 #pragma unroll
     for (int it = 0; it < kHistItems; ++it)
       idv[it] = ld_index(p.gen.ids, p.gen.id64, min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1));
+    // (a tile lies inside ONE feature almost always -- tiles never straddle tables, and a table's features are few: the
+    //  per-key search over the feature bases is then one search per tile; round 5)
+    const int f_lo = gen_feature(g, p.gen.n_feats, (uint32_t)base), f_hi = gen_feature(g, p.gen.n_feats, (uint32_t)(end - 1));
 #pragma unroll
     for (int it = 0; it < kHistItems; ++it) {
       const int64_t q = min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1);
-      const int f = gen_feature(g, p.gen.n_feats, (uint32_t)q);
+      const int f = f_lo == f_hi ? f_lo : gen_feature(g, p.gen.n_feats, (uint32_t)q);
       const bool valid = idv[it] >= 0 && idv[it] < (int64_t)g.vocab[f];
       key[it] = valid ? (uint32_t)idv[it] : (1u << p.key_bits) - 1u;
       bad = bad || (!valid && base + it * kHistThreads + threadIdx.x < end);
@@ -456,10 +459,11 @@ __global__ __launch_bounds__(kThreads) void scatter_seg_kernel(const SegPass p) 
       const int64_t q = min<int64_t>(base + it * 64 + lane, tile_end - 1);
       idv[it] = ld_index(p.gen.ids, p.gen.id64, q);
     }
+    const int f_lo = gen_feature(g, p.gen.n_feats, (uint32_t)tile0), f_hi = gen_feature(g, p.gen.n_feats, (uint32_t)(tile_end - 1));
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
       const int64_t q = min<int64_t>(base + it * 64 + lane, tile_end - 1);
-      const int f = gen_feature(g, p.gen.n_feats, (uint32_t)q);
+      const int f = f_lo == f_hi ? f_lo : gen_feature(g, p.gen.n_feats, (uint32_t)q);   // (one search per tile, see hist_seg_kernel)
       const bool valid = idv[it] >= 0 && idv[it] < (int64_t)g.vocab[f];
       key[it] = valid ? (uint32_t)idv[it] : (1u << p.key_bits) - 1u;
       pos[it] = (uint32_t)q;
@@ -546,6 +550,13 @@ __global__ __launch_bounds__(kThreads) void scatter_seg_kernel(const SegPass p) 
   __syncthreads();
   const int n_here = (int)(tile_end - tile0);
   const uint32_t sentinel = (1u << p.key_bits) - 1u, rb = p.seg.row_base[pr];
+  // (last pass: a key's original position lies anywhere in its TABLE's run; a table looked up by one feature -- the usual
+  //  case -- needs one search per tile instead of one per key)
+  int pf_lo = 0, pf_hi = 1;
+  if constexpr (LAST) {
+    pf_lo = gen_feature(g, p.gen.n_feats, p.seg.lookup_start[pr]);
+    pf_hi = gen_feature(g, p.gen.n_feats, p.seg.lookup_start[pr + 1] - 1);
+  }
 #pragma unroll
   for (int it = 0; it < kItems; ++it) {
     const int i = it * kThreads + threadIdx.x;
@@ -554,7 +565,7 @@ __global__ __launch_bounds__(kThreads) void scatter_seg_kernel(const SegPass p) 
       const int d = (int)((k >> p.shift) & (bins - 1));
       const int o = gbase[d] + (i - (int)tile_excl[d]);
       if constexpr (LAST) {
-        const int f = gen_feature(g, p.gen.n_feats, q);
+        const int f = pf_lo == pf_hi ? pf_lo : gen_feature(g, p.gen.n_feats, q);
         const uint32_t bag = (uint32_t)f * (uint32_t)p.gen.batch + (q - g.base[f]) / g.hot[f];
         p.keys_out[o] = k == sentinel ? kInvalidKey : rb + k;
         p.vals_out[o] = ((uint64_t)bag << 32) | (uint64_t)q;

@@ -98,3 +98,7 @@ if [[ $WHAT == *splitk* ]]; then
   timeout 600 python -m pytest tests/test_dense_ops_gpu.py -q -x -m gpu -k "split_k or ring_gemm or fused_cross" > $O/splitk_tests.log 2>&1; tail -3 $O/splitk_tests.log
   timeout 900 python -m pytest tests/test_layers_gpu.py tests/test_sharded_gpu.py tests/test_mlperf_model_gpu.py tests/test_graph_step_gpu.py -q -x -m gpu > $O/splitk_tests2.log 2>&1; tail -3 $O/splitk_tests2.log
 fi
+if [[ $WHAT == *plan* ]]; then
+  timeout 900 python -m pytest tests/test_embed_bag_bwd_gpu.py tests/test_full_size_properties_gpu.py tests/test_layers_gpu.py -q -x -m gpu > $O/plan_tests.log 2>&1; tail -2 $O/plan_tests.log
+  timeout 300 python scripts/bench_k1.py --multihot --iters 10 2>/dev/null | grep -E "plan_variant|k2_plan_us" | cut -c1-200
+fi
