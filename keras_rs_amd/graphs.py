@@ -43,7 +43,12 @@ class GraphedStep:
                 step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph):
+        # capture_error_mode="thread_local": only THIS thread's calls are held to the capture rules.  With the default
+        # ("global") an event query from any other thread while the capture is open is an error that aborts the process --
+        # and ProcessGroupNCCL's watchdog thread polls the events of the eager warm-up steps' collectives for a few
+        # milliseconds more (seen once in ~8 runs of `bench.py --force-sharded --rccl-self`: the bench died inside
+        # WorkNCCL::finishedGPUExecutionInternal before it could print its line; round 5).
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             step()
 
     def __call__(self) -> None:

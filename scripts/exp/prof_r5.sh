@@ -102,3 +102,20 @@ if [[ $WHAT == *plan* ]]; then
   timeout 900 python -m pytest tests/test_embed_bag_bwd_gpu.py tests/test_full_size_properties_gpu.py tests/test_layers_gpu.py -q -x -m gpu > $O/plan_tests.log 2>&1; tail -2 $O/plan_tests.log
   timeout 300 python scripts/bench_k1.py --multihot --iters 10 2>/dev/null | grep -E "plan_variant|k2_plan_us" | cut -c1-200
 fi
+if [[ $WHAT == *graphstress* ]]; then
+  ok=0; bad=0
+  for i in 1 2 3 4 5 6 7 8; do
+    if timeout 300 python bench.py --force-sharded --rccl-self --steps 3 --warmup 2 --no-cpu-baseline --batch 8192 --vocab 100000 --sustained-steps 0 --probe-steps 0 > $O/stress_$i.json 2> $O/stress_$i.err; then
+      python - <<PY && ok=$((ok+1)) || bad=$((bad+1))
+import json, sys
+d = json.loads(open("$O/stress_$i.json").read().strip().splitlines()[-1])
+g = d.get("graph_leg") or {}
+print("run $i", round(d["ms_per_step"], 3), g.get("ok"), g.get("error"))
+sys.exit(0 if g.get("ok") else 1)
+PY
+    else
+      bad=$((bad+1)); echo "run $i rc!=0"; grep -m3 -iE "hip error|HIP error|capturing|what\(\)|Error" $O/stress_$i.err | cut -c1-300
+    fi
+  done
+  echo "graph stress: ok=$ok bad=$bad"
+fi
