@@ -43,6 +43,13 @@ class GraphedStep:
                 step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # let ProcessGroupNCCL's watchdog (a 100 ms polling loop) retire the warm-up steps' collectives before the
+            # capture opens: an event query of its that meets the capture invalidates it (hipErrorCapturedEvent, seen once
+            # in 8 runs; the caller then falls back to the eager step)
+            import time
+
+            time.sleep(0.5)
         # capture_error_mode="thread_local": only THIS thread's calls are held to the capture rules.  With the default
         # ("global") an event query from any other thread while the capture is open is an error that aborts the process --
         # and ProcessGroupNCCL's watchdog thread polls the events of the eager warm-up steps' collectives for a few

@@ -104,7 +104,7 @@ if [[ $WHAT == *plan* ]]; then
 fi
 if [[ $WHAT == *graphstress* ]]; then
   ok=0; bad=0
-  for i in 1 2 3 4 5 6 7 8; do
+  for i in ${STRESS_RUNS:-1 2 3 4 5 6 7 8}; do
     if timeout 300 python bench.py --force-sharded --rccl-self --steps 3 --warmup 2 --no-cpu-baseline --batch 8192 --vocab 100000 --sustained-steps 0 --probe-steps 0 > $O/stress_$i.json 2> $O/stress_$i.err; then
       python - <<PY && ok=$((ok+1)) || bad=$((bad+1))
 import json, sys
