@@ -368,3 +368,46 @@ def test_bench_phase_table_of_a_sharded_run():
     a = ph["a2a_partials"]
     assert a["min_ms"] == a["max_ms"] == pytest.approx(0.5) and a["bytes_off_rank_per_step"] == 7_000_000
     assert a["bytes_per_link_per_step"] == 7_000_000 and a["GB_per_s_per_rank"] == pytest.approx(7e6 / 0.5e-3 / 1e9)
+
+
+def test_bench_prices_every_product_family_against_its_own_bound():
+    """bench.py::gemm_family_rooflines (round-4 review, next #3): from probe spans named by operand layout / epilogue / dtype /
+    shape, one entry per family with flops AND algorithmic bytes, `bound` = the longer of flops / MFMA peak and bytes / 8 TB/s.
+    At the C3 shapes the long-K products are MFMA-bound and the K = 512 cross form is HBM-bound; fp32 products are priced
+    against the fp32 MFMA peak; the committed counter traffic is attached to the shapes it was measured on.  Also the bf16
+    ulp distance the N > 1 self-check uses."""
+    import importlib.util
+    import os
+    import types
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("krs_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    B, d, p_ = 65536, 3456, 512
+    pr = {f"gemm[nt bf16] {B}x{p_}x{d}": {"calls": 6, "ms_total": 6 * 0.25, "work_total": 6 * 2.0 * B * p_ * d},
+          f"gemm[nt:cross bf16] {B}x{d}x{p_}": {"calls": 3, "ms_total": 3 * 0.45, "work_total": 3 * 2.0 * B * p_ * d},
+          f"gemm[tn bf16] {p_}x{d}x{B}": {"calls": 3, "ms_total": 3 * 0.22, "work_total": 3 * 2.0 * B * p_ * d},
+          "gemm[nt:res f32] 8192x512x512": {"calls": 3, "ms_total": 3 * 0.05, "work_total": 3 * 2.0 * 8192 * 512 * 512},
+          "k2_apply": {"calls": 1, "ms_total": 2.4, "work_total": 0.0}}
+    out = bench.gemm_family_rooflines(types.SimpleNamespace(), pr, 1, B)
+    by = {e["kernel"].split(" x ")[0]: e for e in out}
+    h = by[f"krs_gemm nt bf16 {B}x{p_}x{d}"]
+    assert h["bound"] == "mfma" and h["unit"] == "TFLOP/s" and h["calls_per_step"] == 6
+    assert h["frac"] == pytest.approx((2.0 * B * p_ * d / 2.5e15) / 0.25e-3) and h["achieved"] == pytest.approx(2.0 * B * p_ * d / 0.25e-3 / 1e12)
+    assert h["algorithmic_bytes"] == (B * d + p_ * d + B * p_) * 2 and h["traffic"] == 577737932     # profiles/k1_pmc.json
+    y = by[f"krs_gemm nt:cross bf16 {B}x{d}x{p_}"]
+    assert y["bound"] == "hbm" and y["unit"] == "GB/s" and y["algorithmic_bytes"] == (B * p_ + d * p_ + B * d) * 2 + 3 * B * d * 2
+    assert y["frac"] == pytest.approx(y["algorithmic_bytes"] / 8e12 / 0.45e-3) and y["traffic"] > y["algorithmic_bytes"]
+    t = by[f"krs_gemm tn bf16 {p_}x{d}x{B}"]
+    assert t["bound"] == "mfma" and t["algorithmic_bytes"] == (B * p_ + B * d) * 2 + p_ * d * 4          # fp32 output
+    f = by["krs_gemm nt:res f32 8192x512x512"]
+    assert f["peak"] == pytest.approx(157.3) and f["traffic"] is None
+    agg = out[-1]
+    assert "aggregate" in agg["kernel"] and agg["flops_per_step"] == pytest.approx(sum(v["work_total"] for k, v in pr.items() if k.startswith("gemm[")))
+    # bf16 ulp distance: 1.0 and its bf16 neighbour are one ulp apart; equal values and zeros are 0
+    a = torch.tensor([1.0, 1.0, 0.0, -3.0])
+    b = torch.tensor([1.0 + 2.0 ** -7, 1.0, 0.0, -3.0 - 2.0 ** -6])
+    assert bench._bf16_ulps(a, b).tolist() == [1.0, 0.0, 0.0, 1.0]
