@@ -287,6 +287,11 @@ int krs_gemm(const void* a, int64_t lda, int a_is_km,
              int in_dtype, int out_dtype,
              const krs_gemm_epilogue* epilogue,
              void* workspace, size_t workspace_bytes, void* stream);
+/* Bytes of `workspace` a krs_gemm call of this shape needs (0 = none): split-K products keep one fp32 [M, N] slab per
+ * split and reduce them in a fixed order (deterministic, no atomics) -- the weight-gradient contractions over the batch
+ * (a_is_km), and since round 5 K-contiguous products whose output is too small for 256 x 256 tiles to fill the chip but
+ * whose K is long (M = 8192 against N = 512, K = 3456: the per-rank products of a strongly-scaled job).  A call with less
+ * workspace than this returns KRS_ERR_WORKSPACE. */
 size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
 
 /* Data-gradient product of a cross layer FUSED with the elementwise backward of the cross layer below it in a stack
