@@ -381,49 +381,82 @@ __device__ __forceinline__ uint32_t seg_local_key(const SegPass& p, const GenLds
   return (1u << p.key_bits) - 1u;
 }
 
+// Round 5: one workgroup counts kHistGroup CONSECUTIVE tiles of a problem (the workgroup of the group's first tile; the
+// others leave at once).  The count matrix is [digit][tile]: one tile per workgroup wrote its 1024 counters as 1024
+// scattered 4-byte stores -- 14 MB of counters cost 120 MB at the write counter (32-byte sectors), and that, not the
+// 56 MB of keys it reads, was the kernel's time.  A group writes kHistGroup neighbouring counters per digit (32
+// contiguous bytes), and keeps four tiles' keys in flight at a time.
+constexpr int kHistGroup = 8, kHistBatch = 4;
 template <bool FIRST>
 __global__ __launch_bounds__(kHistThreads) void hist_seg_kernel(const SegPass p) {
-  __shared__ int h[kMaxBins];
+  __shared__ int h[kHistGroup][kMaxBins];
   __shared__ GenLds g;
   const int bins = 1 << p.bits;
-  for (int i = threadIdx.x; i < bins; i += kHistThreads) h[i] = 0;
-  if constexpr (FIRST) load_gen_seg(p, g, kHistThreads);
-  __syncthreads();
   const int pr = seg_problem(p.seg, blockIdx.x);
   const uint32_t tl = blockIdx.x - p.seg.tile_start[pr], nt = p.seg.tile_start[pr + 1] - p.seg.tile_start[pr];
-  const int64_t base = (int64_t)p.seg.lookup_start[pr] + (int64_t)tl * kTile;
-  const int64_t end = min<int64_t>(base + kTile, p.seg.lookup_start[pr + 1]);
+  if (tl % kHistGroup != 0) return;
+  const int ntl = (int)min<uint32_t>(kHistGroup, nt - tl);
+  for (int i = threadIdx.x; i < ntl * kMaxBins; i += kHistThreads) (&h[0][0])[i] = 0;
+  if constexpr (FIRST) load_gen_seg(p, g, kHistThreads);
+  __syncthreads();
   bool bad = false;
-  uint32_t key[kHistItems];
-  if constexpr (FIRST) {
-    int64_t idv[kHistItems];
+  const int64_t pend = p.seg.lookup_start[pr + 1];
+  for (int j0 = 0; j0 < ntl; j0 += kHistBatch) {
+    uint32_t key[kHistBatch][kHistItems];
+    if constexpr (FIRST) {
+      int64_t idv[kHistBatch][kHistItems];
 #pragma unroll
-    for (int it = 0; it < kHistItems; ++it)
-      idv[it] = ld_index(p.gen.ids, p.gen.id64, min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1));
-    // (a tile lies inside ONE feature almost always -- tiles never straddle tables, and a table's features are few: the
-    //  per-key search over the feature bases is then one search per tile; round 5)
-    const int f_lo = gen_feature(g, p.gen.n_feats, (uint32_t)base), f_hi = gen_feature(g, p.gen.n_feats, (uint32_t)(end - 1));
+      for (int jj = 0; jj < kHistBatch; ++jj) {
+        const int64_t base = (int64_t)p.seg.lookup_start[pr] + (int64_t)(tl + min(j0 + jj, ntl - 1)) * kTile;
+        const int64_t end = min<int64_t>(base + kTile, pend);
 #pragma unroll
-    for (int it = 0; it < kHistItems; ++it) {
-      const int64_t q = min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1);
-      const int f = f_lo == f_hi ? f_lo : gen_feature(g, p.gen.n_feats, (uint32_t)q);
-      const bool valid = idv[it] >= 0 && idv[it] < (int64_t)g.vocab[f];
-      key[it] = valid ? (uint32_t)idv[it] : (1u << p.key_bits) - 1u;
-      bad = bad || (!valid && base + it * kHistThreads + threadIdx.x < end);
+        for (int it = 0; it < kHistItems; ++it)
+          idv[jj][it] = ld_index(p.gen.ids, p.gen.id64, min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1));
+      }
+#pragma unroll
+      for (int jj = 0; jj < kHistBatch; ++jj) {
+        const int64_t base = (int64_t)p.seg.lookup_start[pr] + (int64_t)(tl + min(j0 + jj, ntl - 1)) * kTile;
+        const int64_t end = min<int64_t>(base + kTile, pend);
+        // (a tile lies inside ONE feature almost always -- tiles never straddle tables, and a table's features are few:
+        //  the per-key search over the feature bases is then one search per tile)
+        const int f_lo = gen_feature(g, p.gen.n_feats, (uint32_t)base), f_hi = gen_feature(g, p.gen.n_feats, (uint32_t)(end - 1));
+#pragma unroll
+        for (int it = 0; it < kHistItems; ++it) {
+          const int64_t q = min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1);
+          const int f = f_lo == f_hi ? f_lo : gen_feature(g, p.gen.n_feats, (uint32_t)q);
+          const bool valid = idv[jj][it] >= 0 && idv[jj][it] < (int64_t)g.vocab[f];
+          key[jj][it] = valid ? (uint32_t)idv[jj][it] : (1u << p.key_bits) - 1u;
+          bad = bad || (!valid && j0 + jj < ntl && base + it * kHistThreads + threadIdx.x < end);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < kHistBatch; ++jj) {
+        const int64_t base = (int64_t)p.seg.lookup_start[pr] + (int64_t)(tl + min(j0 + jj, ntl - 1)) * kTile;
+        const int64_t end = min<int64_t>(base + kTile, pend);
+#pragma unroll
+        for (int it = 0; it < kHistItems; ++it)
+          key[jj][it] = p.keys_in[min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1)];
+      }
     }
-  } else {
 #pragma unroll
-    for (int it = 0; it < kHistItems; ++it)
-      key[it] = p.keys_in[min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1)];
+    for (int jj = 0; jj < kHistBatch; ++jj) {
+      if (j0 + jj >= ntl) break;
+      const int64_t base = (int64_t)p.seg.lookup_start[pr] + (int64_t)(tl + j0 + jj) * kTile;
+      const int64_t end = min<int64_t>(base + kTile, pend);
+#pragma unroll
+      for (int it = 0; it < kHistItems; ++it)
+        if (base + it * kHistThreads + threadIdx.x < end) atomicAdd(&h[j0 + jj][(key[jj][it] >> p.shift) & (bins - 1)], 1);
+    }
   }
-#pragma unroll
-  for (int it = 0; it < kHistItems; ++it)
-    if (base + it * kHistThreads + threadIdx.x < end) atomicAdd(&h[(key[it] >> p.shift) & (bins - 1)], 1);
   if constexpr (FIRST)
     if (bad && p.gen.err_flag) atomicOr(p.gen.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
   __syncthreads();
   int32_t* dst = p.counts + (int64_t)bins * p.seg.tile_start[pr];
-  for (int i = threadIdx.x; i < bins; i += kHistThreads) dst[(int64_t)i * nt + tl] = h[i];
+  for (int i = threadIdx.x; i < bins; i += kHistThreads) {
+    int32_t* row = dst + (int64_t)i * nt + tl;
+    for (int j = 0; j < ntl; ++j) row[j] = h[j][i];
+  }
 }
 
 template <bool FIRST, bool LAST>

@@ -119,3 +119,14 @@ PY
   done
   echo "graph stress: ok=$ok bad=$bad"
 fi
+if [[ $WHAT == *pmck1* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  for mode in "--multihot" ""; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rm -rf /tmp/pmc; timeout 200 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc -o p -- python $R/scripts/bench_k1.py $mode --iters 5 > /dev/null 2>&1
+      echo "mode=[$mode] counters=[$c]" >> $O/k1_k2_pmc.txt
+      python $R/scripts/rocpd_pmc.py $(ls /tmp/pmc/*/*.db /tmp/pmc/*.db 2>/dev/null | head -1) | grep -E "bag_apply_fast_kernel|embed_bag_fwd_vec|embed_gather_hot1|scatter_seg|hist_seg" >> $O/k1_k2_pmc.txt
+    done
+  done
+  cd $R; cat $O/k1_k2_pmc.txt
+fi
