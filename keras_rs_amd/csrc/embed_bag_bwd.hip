@@ -328,7 +328,6 @@ struct Seg {
   int n;                                  // problems
   uint32_t lookup_start[kMaxProb + 1];    // first lookup position of problem i; [n] = nnz
   uint32_t tile_start[kMaxProb + 1];      // first tile of problem i; [n] = tiles in all
-  uint32_t group_start[kMaxProb + 1];     // first histogram workgroup (kHistGroup consecutive tiles) of problem i
   uint32_t row_base[kMaxProb];            // global row of the table's row 0
 };
 struct SegPass {
@@ -382,84 +381,53 @@ __device__ __forceinline__ uint32_t seg_local_key(const SegPass& p, const GenLds
   return (1u << p.key_bits) - 1u;
 }
 
-// Round 5: one workgroup (1024 threads) counts kHistGroup CONSECUTIVE tiles of a problem.  The count matrix is [digit][tile]: one tile per workgroup wrote its 1024 counters as 1024
-// scattered 4-byte stores -- 14 MB of counters cost 120 MB at the write counter (32-byte sectors), and that, not the
-// 56 MB of keys it reads, was the kernel's time.  A group writes kHistGroup neighbouring counters per digit (32
-// contiguous bytes), and keeps four tiles' keys in flight at a time.
-constexpr int kHistGroup = 8, kHistBatch = 4, kHistSegThreads = 1024;
-constexpr int kHistSegItems = kHistBatch * kTile / kHistSegThreads;     // 16 keys per thread and batch of four tiles
-constexpr int kHistSegPerTile = kTile / kHistSegThreads;                // 4 of them in each tile
+// (Round 5 measured one workgroup per EIGHT consecutive tiles here, so that a digit's counters leave as 32 contiguous bytes:
+//  the write counter of this kernel fell from 121 MB to 14 MB per launch -- one tile's 1024 counters are 1024 scattered
+//  4-byte stores into the [digit][tile] matrix -- and the plan got SLOWER, 558 -> 582 us with 1024-thread groups (1815 us
+//  with 256-thread ones): the partial-sector writes are absorbed by L2, the kernel wants its 3400 independent workgroups.)
 template <bool FIRST>
-__global__ __launch_bounds__(kHistSegThreads) void hist_seg_kernel(const SegPass p) {
-  __shared__ int h[kHistGroup][kMaxBins];
+__global__ __launch_bounds__(kHistThreads) void hist_seg_kernel(const SegPass p) {
+  __shared__ int h[kMaxBins];
   __shared__ GenLds g;
   const int bins = 1 << p.bits;
-  int pr = 0;
-  {
-    int lo = 0, hi = p.seg.n;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (p.seg.group_start[mid] <= blockIdx.x) lo = mid; else hi = mid;
-    }
-    pr = lo;
-  }
-  const uint32_t tl = (blockIdx.x - p.seg.group_start[pr]) * kHistGroup, nt = p.seg.tile_start[pr + 1] - p.seg.tile_start[pr];
-  const int ntl = (int)min<uint32_t>(kHistGroup, nt - tl);
-  for (int i = threadIdx.x; i < ntl * kMaxBins; i += kHistSegThreads) (&h[0][0])[i] = 0;
-  if constexpr (FIRST) load_gen_seg(p, g, kHistSegThreads);
+  for (int i = threadIdx.x; i < bins; i += kHistThreads) h[i] = 0;
+  if constexpr (FIRST) load_gen_seg(p, g, kHistThreads);
   __syncthreads();
+  const int pr = seg_problem(p.seg, blockIdx.x);
+  const uint32_t tl = blockIdx.x - p.seg.tile_start[pr], nt = p.seg.tile_start[pr + 1] - p.seg.tile_start[pr];
+  const int64_t base = (int64_t)p.seg.lookup_start[pr] + (int64_t)tl * kTile;
+  const int64_t end = min<int64_t>(base + kTile, p.seg.lookup_start[pr + 1]);
   bool bad = false;
-  const int64_t p0 = p.seg.lookup_start[pr], pend = p.seg.lookup_start[pr + 1];
-  for (int j0 = 0; j0 < ntl; j0 += kHistBatch) {
-    // item `it` of this thread: key (it % 4) * 1024 + tid of tile j0 + it / 4 (clamped to the group's last tile; dead items
-    // are masked at the count)
-    uint32_t key[kHistSegItems];
-    if constexpr (FIRST) {
-      int64_t idv[kHistSegItems];
+  uint32_t key[kHistItems];
+  if constexpr (FIRST) {
+    int64_t idv[kHistItems];
 #pragma unroll
-      for (int it = 0; it < kHistSegItems; ++it) {
-        const int64_t base = p0 + (int64_t)(tl + min(j0 + it / kHistSegPerTile, ntl - 1)) * kTile;
-        const int64_t end = min<int64_t>(base + kTile, pend);
-        idv[it] = ld_index(p.gen.ids, p.gen.id64, min<int64_t>(base + (it % kHistSegPerTile) * kHistSegThreads + threadIdx.x, end - 1));
-      }
+    for (int it = 0; it < kHistItems; ++it)
+      idv[it] = ld_index(p.gen.ids, p.gen.id64, min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1));
+    // (a tile lies inside ONE feature almost always -- tiles never straddle tables, and a table's features are few: the
+    //  per-key search over the feature bases is then one search per tile; round 5)
+    const int f_lo = gen_feature(g, p.gen.n_feats, (uint32_t)base), f_hi = gen_feature(g, p.gen.n_feats, (uint32_t)(end - 1));
 #pragma unroll
-      for (int it = 0; it < kHistSegItems; ++it) {
-        const int64_t base = p0 + (int64_t)(tl + min(j0 + it / kHistSegPerTile, ntl - 1)) * kTile;
-        const int64_t end = min<int64_t>(base + kTile, pend);
-        const int64_t q = min<int64_t>(base + (it % kHistSegPerTile) * kHistSegThreads + threadIdx.x, end - 1);
-        // (a tile lies inside ONE feature almost always -- tiles never straddle tables, and a table's features are few:
-        //  the search over the feature bases runs on the tile's ends first)
-        const int f_lo = gen_feature(g, p.gen.n_feats, (uint32_t)base), f_hi = gen_feature(g, p.gen.n_feats, (uint32_t)(end - 1));
-        const int f = f_lo == f_hi ? f_lo : gen_feature(g, p.gen.n_feats, (uint32_t)q);
-        const bool valid = idv[it] >= 0 && idv[it] < (int64_t)g.vocab[f];
-        key[it] = valid ? (uint32_t)idv[it] : (1u << p.key_bits) - 1u;
-        bad = bad || (!valid && j0 + it / kHistSegPerTile < ntl && base + (it % kHistSegPerTile) * kHistSegThreads + threadIdx.x < end);
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < kHistSegItems; ++it) {
-        const int64_t base = p0 + (int64_t)(tl + min(j0 + it / kHistSegPerTile, ntl - 1)) * kTile;
-        const int64_t end = min<int64_t>(base + kTile, pend);
-        key[it] = p.keys_in[min<int64_t>(base + (it % kHistSegPerTile) * kHistSegThreads + threadIdx.x, end - 1)];
-      }
+    for (int it = 0; it < kHistItems; ++it) {
+      const int64_t q = min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1);
+      const int f = f_lo == f_hi ? f_lo : gen_feature(g, p.gen.n_feats, (uint32_t)q);
+      const bool valid = idv[it] >= 0 && idv[it] < (int64_t)g.vocab[f];
+      key[it] = valid ? (uint32_t)idv[it] : (1u << p.key_bits) - 1u;
+      bad = bad || (!valid && base + it * kHistThreads + threadIdx.x < end);
     }
+  } else {
 #pragma unroll
-    for (int it = 0; it < kHistSegItems; ++it) {
-      const int j = j0 + it / kHistSegPerTile;
-      const int64_t base = p0 + (int64_t)(tl + min(j, ntl - 1)) * kTile;
-      const int64_t end = min<int64_t>(base + kTile, pend);
-      if (j < ntl && base + (it % kHistSegPerTile) * kHistSegThreads + threadIdx.x < end)
-        atomicAdd(&h[j][(key[it] >> p.shift) & (bins - 1)], 1);
-    }
+    for (int it = 0; it < kHistItems; ++it)
+      key[it] = p.keys_in[min<int64_t>(base + it * kHistThreads + threadIdx.x, end - 1)];
   }
+#pragma unroll
+  for (int it = 0; it < kHistItems; ++it)
+    if (base + it * kHistThreads + threadIdx.x < end) atomicAdd(&h[(key[it] >> p.shift) & (bins - 1)], 1);
   if constexpr (FIRST)
     if (bad && p.gen.err_flag) atomicOr(p.gen.err_flag, KRS_FLAG_ID_OUT_OF_RANGE);
   __syncthreads();
   int32_t* dst = p.counts + (int64_t)bins * p.seg.tile_start[pr];
-  for (int i = threadIdx.x; i < bins; i += kHistSegThreads) {
-    int32_t* row = dst + (int64_t)i * nt + tl;
-    for (int j = 0; j < ntl; ++j) row[j] = h[j][i];
-  }
+  for (int i = threadIdx.x; i < bins; i += kHistThreads) dst[(int64_t)i * nt + tl] = h[i];
 }
 
 template <bool FIRST, bool LAST>
@@ -1656,16 +1624,12 @@ static bool plan_sort_by_table(const PlanLayout& l, const krs_table* tables, con
   }
   if (pos != nnz || sg.n == 0) return false;
   sg.lookup_start[sg.n] = (uint32_t)nnz;
-  uint32_t tiles = 0, groups = 0;
+  uint32_t tiles = 0;
   for (int i = 0; i < sg.n; ++i) {
     sg.tile_start[i] = tiles;
-    sg.group_start[i] = groups;
-    const uint32_t nt_i = (uint32_t)ceil_div((int64_t)sg.lookup_start[i + 1] - sg.lookup_start[i], rs::kTile);
-    tiles += nt_i;
-    groups += (nt_i + rs::kHistGroup - 1) / rs::kHistGroup;
+    tiles += (uint32_t)ceil_div((int64_t)sg.lookup_start[i + 1] - sg.lookup_start[i], rs::kTile);
   }
   sg.tile_start[sg.n] = tiles;
-  sg.group_start[sg.n] = groups;
   if (tiles == 0) return false;
   // key = id, plus one pattern (all ones) for an out-of-range id
   unsigned bits = 1;
@@ -1696,8 +1660,8 @@ static bool plan_sort_by_table(const PlanLayout& l, const krs_table* tables, con
     sp.keys_out = last ? l.keys_sorted : (out_is_i0 ? k0 : k1);
     sp.pos_out = last ? nullptr : (out_is_i0 ? q0 : q1);
     sp.vals_out = last ? l.vals_sorted : nullptr;
-    if (first) hipLaunchKernelGGL(rs::hist_seg_kernel<true>, dim3(groups), dim3(rs::kHistSegThreads), 0, st, sp);
-    else hipLaunchKernelGGL(rs::hist_seg_kernel<false>, dim3(groups), dim3(rs::kHistSegThreads), 0, st, sp);
+    if (first) hipLaunchKernelGGL(rs::hist_seg_kernel<true>, dim3(tiles), dim3(rs::kHistThreads), 0, st, sp);
+    else hipLaunchKernelGGL(rs::hist_seg_kernel<false>, dim3(tiles), dim3(rs::kHistThreads), 0, st, sp);
     scan::exclusive(counts, counts, (int64_t)(1 << sp.bits) * tiles, sums, nullptr, st);
     if (first && last) hipLaunchKernelGGL((rs::scatter_seg_kernel<true, true>), dim3(tiles), dim3(rs::kThreads), 0, st, sp);
     else if (first) hipLaunchKernelGGL((rs::scatter_seg_kernel<true, false>), dim3(tiles), dim3(rs::kThreads), 0, st, sp);
