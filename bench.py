@@ -1254,6 +1254,10 @@ def main():
 
     finish["fn"] = emit
     if want_graph:
+        if rank == 0:
+            # (the eager legs' line goes to STDERR first: should the capture take the process down -- which no handler can catch --
+            #  the measurement is at least in the log)
+            print("KRS_EAGER_LINE " + json.dumps(out), file=sys.stderr, flush=True)
         info = {"attempted": True, "ok": False}
         try:
             a.graph, a._graph_used = True, False
