@@ -98,6 +98,11 @@ def parse():
     ap.add_argument("--c2-leg", action="store_true",
                     help="(internal) run ONLY the C2 leg and print its object: the default run starts this in a process of its "
                          "own, so that the leg's graph capture cannot take the headline line with it")
+    ap.add_argument("--replicate-below", type=int, default=0, metavar="ROWS",
+                    help="sharded runs: tables with fewer rows are REPLICATED on every rank instead of sharded (dense gradients, "
+                         "joined to the dense all-reduce) -- what the reference's model does below its embedding_threshold "
+                         "(examples/ml_perf/main.py:135-141); the Criteo vocabularies hold tables of 3 ... 155 rows that would "
+                         "send all their lookups to a few owners")
     ap.add_argument("--no-parity", action="store_true",
                     help="sharded runs: skip the self-check of one step against an unsharded recompute of a slice (`parity`)")
     ap.add_argument("--no-graph-leg", action="store_true",
@@ -220,7 +225,8 @@ class Model(torch.nn.Module):
             # (capacity_settle_steps: the blocks of the static exchange shrink to the settled statistics after that many
             #  fitting steps -- a resize, i.e. fresh buffers, in the middle of a 20-step timed region; off unless asked for)
             self.embedding = ShardedDistributedEmbedding(feats, dtype=emb_policy, slab_lead_cols=self.lead,
-                                                         exchange=a.exchange, capacity_settle_steps=a.capacity_settle)
+                                                         exchange=a.exchange, capacity_settle_steps=a.capacity_settle,
+                                                         replicate_below=getattr(a, "replicate_below", 0))
             self.embedding._collectives_at_world1 = bool(a.rccl_self)
         else:
             # the dense feature's 128 columns are reserved in front of the 26 embeddings: the lookups land
@@ -710,9 +716,11 @@ def sharded_parity(model, a, hots, world, rank, dev, b_local, ids, pre, backend)
     import torch.distributed as dist
 
     emb = model.embedding
-    if len(emb._sgroups) != 1 or emb._replicated is not None or emb._sgroups[0].fused.kind != "adagrad":
+    if len(emb._sgroups) != 1 or emb._sgroups[0].fused.kind != "adagrad":
         return {"checked": False, "ok": True, "reason": "the self-check covers one sharded Adagrad group (the bench's model)"}
+    # (replicated tables -- --replicate-below -- are looked up locally by the unsharded layer: not part of this check)
     g, n, d = emb._sgroups[0], emb.world, emb._sgroups[0].dim
+    hots = [hots[emb._paths.index(p)] for p in g.paths]      # bag lengths of the SHARDED features, in the group's order
     multi = world > 1
     staged = multi and backend == "gloo"
 
