@@ -103,6 +103,11 @@ def parse():
                          "joined to the dense all-reduce) -- what the reference's model does below its embedding_threshold "
                          "(examples/ml_perf/main.py:135-141); the Criteo vocabularies hold tables of 3 ... 155 rows that would "
                          "send all their lookups to a few owners")
+    ap.add_argument("--virtual-world", type=int, default=0, metavar="N",
+                    help="with --force-sharded on ONE GPU: run rank 0's step of an N-way job with the shapes of N ranks (1/N shard, "
+                         "batch / N samples, ids routed to N owners, N blocks per exchange, N partials per bag) and device copies "
+                         "for the links -- the per-rank KERNEL time of an N-way job (ShardedDistributedEmbedding(virtual_world=N)); "
+                         "`value` is then a projection that leaves the link time out, and the line says so")
     ap.add_argument("--no-parity", action="store_true",
                     help="sharded runs: skip the self-check of one step against an unsharded recompute of a slice (`parity`)")
     ap.add_argument("--no-graph-leg", action="store_true",
@@ -226,7 +231,8 @@ class Model(torch.nn.Module):
             #  fitting steps -- a resize, i.e. fresh buffers, in the middle of a 20-step timed region; off unless asked for)
             self.embedding = ShardedDistributedEmbedding(feats, dtype=emb_policy, slab_lead_cols=self.lead,
                                                          exchange=a.exchange, capacity_settle_steps=a.capacity_settle,
-                                                         replicate_below=getattr(a, "replicate_below", 0))
+                                                         replicate_below=getattr(a, "replicate_below", 0),
+                                                         virtual_world=getattr(a, "virtual_world", 0))
             self.embedding._collectives_at_world1 = bool(a.rccl_self)
         else:
             # the dense feature's 128 columns are reserved in front of the 26 embeddings: the lookups land
@@ -1030,7 +1036,10 @@ def main():
     rank, world, local, backend = dist_setup(a.gpus, a.dist_backend, single_rank_group=a.force_sharded and a.rccl_self)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    b_local = a.batch // world
+    if a.virtual_world > 1 and (world > 1 or not a.force_sharded or a.rccl_self):
+        raise SystemExit("--virtual-world N goes with --force-sharded on one GPU (no process group)")
+    vworld = a.virtual_world if a.virtual_world > 1 else world      # the job size the SHAPES follow
+    b_local = a.batch // vworld
     hots_multi = (ML_PERF_HOTS * 8)[: a.tables]
     hots_one = [1] * a.tables
     primary = hots_one if a.hotness == "1" else hots_multi
@@ -1053,11 +1062,13 @@ def main():
     if a.c2_leg:
         print(json.dumps(measure_c2(a, dev)))
         return
-    model = Model(a, primary, world, rank)
+    model = Model(a, primary, vworld, rank)
     model.embedding.build(None)
     opt_box = [None]
     parity = None
-    if (world > 1 or a.force_sharded) and not a.no_parity:
+    if a.virtual_world > 1:
+        parity = {"checked": False, "ok": True, "reason": "virtual world: the other ranks' shards do not exist in this process"}
+    elif (world > 1 or a.force_sharded) and not a.no_parity:
         # one step of the layer the timed steps use, checked on a slice against an unsharded recompute (HIP path only)
         ids0, _ = make_inputs(a, primary, b_local, rank, dev)
         parity = sharded_parity(model, a, primary, world, rank, dev, b_local, ids0, model.embedding.preprocess(ids0), backend)
@@ -1192,6 +1203,9 @@ def main():
                                 else "Adagrad")),
                 "global_batch": a.batch,
                 "parallelism": ("single GPU" if world == 1 and not a.force_sharded else
+                                ("rank 0's step of a %d-way job on ONE GPU (virtual world: 1/%d shard, batch / %d samples, ids "
+                                 "routed to %d owners, device copies for the links; `value` = global batch / this step: a "
+                                 "projection WITHOUT link time)" % ((a.virtual_world,) * 4)) if a.virtual_world > 1 else
                                 "sharded code path on ONE GPU (dry run: %s)" % (
                                     "collectives through a one-rank RCCL communicator" if backend else
                                     "device copies stand in for the links") if world == 1
@@ -1204,6 +1218,8 @@ def main():
         }
         if r1.get("sustained"):
             out["sustained"] = r1["sustained"]
+        if a.virtual_world > 1:
+            out["virtual_world"] = a.virtual_world
         if a.graph:
             out["launch"] = "every timed step is one replay of a HIP graph captured from the eager step (keras_rs_amd.graphs)"
         if sharded and "exchange" in r1:
@@ -1230,9 +1246,9 @@ def main():
         if k1_s is not None:
             n1 = "embed_gather_hot1 (K1 owner-side row gather of the sharded path, rank 0)" if sharded else k1_name(primary)
             n2 = n1 if sharded else k1_name(secondary)
-            out["embed_fwd_lookups_per_s"] = world * b_local * sum(primary) / k1_s
+            out["embed_fwd_lookups_per_s"] = vworld * b_local * sum(primary) / k1_s
             out["roofline"] = k1_roofline(a, primary, b_local, k1_s, n1, sharded)
-            second["embed_fwd_lookups_per_s"] = world * b_local * sum(secondary) / k1_s2
+            second["embed_fwd_lookups_per_s"] = vworld * b_local * sum(secondary) / k1_s2
             second["roofline"] = k1_roofline(a, secondary, b_local, k1_s2, n2, sharded)
         for res, tgt, hots in ((r1, out, primary), (r2, second, secondary)):
             rs = roofline_step(a, hots, b_local, res)

@@ -348,7 +348,7 @@ class ShardedDistributedEmbedding(base.Layer):
     def __init__(self, feature_configs: dict[str, FeatureConfig], *, process_group=None, kernels=None,
                  slab_lead_cols: int = 0, replicate_below: int = 0, grad_average: bool = False,
                  partial_dtype=None, exchange: str = "exact", capacity="auto", capacity_headroom: float = 1.25,
-                 update_stats: bool = True, capacity_settle_steps: int = 0, **kwargs: Any):
+                 update_stats: bool = True, capacity_settle_steps: int = 0, virtual_world: int = 0, **kwargs: Any):
         super().__init__(**kwargs)
         # (base_distributed_embedding.py:461-464: whether the per-partition limits follow the running statistics; here
         #  the capacities of the static exchange.  False = they stay what they were sized to, overflows are only counted)
@@ -394,6 +394,14 @@ class ShardedDistributedEmbedding(base.Layer):
         self._pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # virtual_world = N (measurement only, no process group): ONE process holds rank 0's 1/N shard and runs the step with
+        # the shapes of an N-way job -- ids routed to N owners, N blocks per exchange, N partials per bag -- while every
+        # "all-to-all" is a device copy of its own send buffer (block k comes back as if rank k had sent what this rank sent it:
+        # the same load under MOD interleaving; a local row is valid in every shard, they have one shape).  The per-rank kernel
+        # times of an N-way job on one GPU (bench.py --virtual-world); table reads / writes across "ranks" mean nothing here.
+        self.virtual = int(virtual_world) > 1 and not dist.is_initialized()
+        if self.virtual:
+            self.world = int(virtual_world)
         self.kernels = kernels or HipShardKernels()
         self.replicate_below = int(replicate_below)
         self.grad_average = bool(grad_average)
@@ -513,6 +521,8 @@ class ShardedDistributedEmbedding(base.Layer):
             g.step = int(s)
 
     def _all_gather_rows(self, mine: torch.Tensor) -> list:
+        if self.virtual:
+            raise L.KrsError("ShardedDistributedEmbedding(virtual_world=N) holds one rank's shard only: tables cannot be assembled")
         if self.world == 1:
             return [mine]
         mine = mine.contiguous()
@@ -673,7 +683,7 @@ class ShardedDistributedEmbedding(base.Layer):
         """all-to-all of the leading dimension; without counts every pair exchanges send.shape[0] / world rows."""
         n_recv = send.shape[0] if recv_counts is None else sum(recv_counts)
         recv = torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        if self.world == 1 and not (dist.is_initialized() and self._collectives_at_world1):
+        if self.virtual or (self.world == 1 and not (dist.is_initialized() and self._collectives_at_world1)):
             recv.copy_(send)     # dry run on one GPU: a device copy stands in for the links
         elif send.is_cuda and dist.get_backend(self._pg) == "gloo":
             # gloo has no device all-to-all: stage through the host (debugging / single-GPU test rigs only;

@@ -130,3 +130,16 @@ if [[ $WHAT == *pmck1* ]]; then
   done
   cd $R; cat $O/k1_k2_pmc.txt
 fi
+if [[ $WHAT == *virtual8* ]]; then
+  timeout 300 python bench.py --force-sharded --virtual-world 8 --no-cpu-baseline > $O/sharded_virtual8.json 2> $O/sharded_virtual8.err
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/prof; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python $R/bench.py --force-sharded --virtual-world 8 --steps 8 --warmup 2 --no-cpu-baseline --sustained-steps 0 > $O/sharded_virtual8_profiled.json 2>/dev/null
+  KRS_STATS_FULL_NAMES=1 python $R/scripts/rocpd_stats.py $(ls /tmp/prof/*/*.db /tmp/prof/*.db 2>/dev/null | head -1) 60 > $O/sharded_virtual8_kernel_stats.md
+  cd $R
+  tail -c 300 $O/sharded_virtual8.err
+  python - <<PY
+import json
+d = json.loads(open("$O/sharded_virtual8.json").read().strip().splitlines()[-1])
+print("virtual 8:", round(d["ms_per_step"], 3), d["step_stats"]["median_ms"], "L=1", round(d["also"]["ms_per_step"], 3), "host", round(d["host_enqueue_ms_per_step"], 3), d["exchange"], {k: round(v["ms_per_step"], 3) for k, v in d["phases"].items()}, d.get("overflow_steps"), d.get("invalid"))
+PY
+fi
