@@ -112,3 +112,34 @@ def test_sharded_step_through_a_one_rank_rccl_communicator():
             assert ("eager_leg" in d) == bool(gl.get("promoted_to_value"))
         else:
             assert "graph_leg" not in d
+
+
+def test_virtual_world_runs_rank_zero_of_an_n_way_job_with_n_way_shapes():
+    """`--force-sharded --virtual-world N` (round 5): one process, rank 0's 1/N shard and batch / N samples, ids routed to N
+    owners, N blocks per exchange, loopback copies for the links -- the per-rank KERNEL time of an N-way job, a projection
+    that the line labels as such (no parity: the other ranks' shards do not exist)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--virtual-world", "4", "--steps", "3", "--warmup", "2",
+           "--no-cpu-baseline", "--batch", "8192", "--vocab", "100000", "--sustained-steps", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["virtual_world"] == 4 and "4-way job on ONE GPU" in d["config"]["parallelism"] and "projection" in d["config"]["parallelism"]
+    assert d["parity"] == {"checked": False, "ok": True, "reason": d["parity"]["reason"]} and "graph_leg" not in d
+    ex = d["exchange"]
+    # batch / 4 samples per rank, every bag split over up to 4 owners: more segments than bags, four blocks per exchange
+    bags = (8192 // 4) * 26
+    assert ex["mode"] == "static" and ex["received"][1] > bags and ex["need"][0] <= ex["capacity"][0]
+    assert d["overflow_steps"] == 0 and "invalid" not in d and d["phases"]["combine"]["ms_per_step"] > 0
+    import torch
+
+    from keras_rs_amd import _lib as L
+    import keras_rs_amd.layers as kl
+    from keras_rs_amd.sharded import ShardedDistributedEmbedding
+
+    tc = kl.TableConfig("t", 1000, 16, optimizer=kl.Adagrad(0.1, 0.1), combiner="sum", placement="sparsecore")
+    layer = ShardedDistributedEmbedding({"f": kl.FeatureConfig("f", tc, (64, 3), (64, 16))}, virtual_world=4, exchange="static")
+    out = layer({"f": torch.randint(0, 1000, (64, 3), device="cuda:0", dtype=torch.int32)})["f"]
+    assert out.shape == (64, 16) and layer.shard.shape[0] == 250 and layer.world == 4 and layer.virtual
+    with pytest.raises(L.KrsError):
+        layer.get_embedding_tables()
