@@ -832,6 +832,10 @@ __device__ __forceinline__ int find_table(const krs_table* tables, int n_tables,
 
 constexpr int kLongUnroll = 4;   // ... and per group in the hot-row kernel, whose chunks are long
 constexpr int kSegsPerGroup = 4;  // segments each group walks (amortises the descriptor prologue)
+// ... per mode: the slot-less modes (SGD, dense, compact) keep fewer rows in flight per lane and run better with TWO
+// (round 5, variant builds at the C3 shape: fused SGD 1297-1315 -> 1119 us multi-hot, 273 -> 260 us at L = 1; Adagrad is flat
+// over 1 / 2 / 3 / 4 -- 2266 / 2301 / 2314 / 2282 us -- and 22 % slower with 8)
+constexpr int segs_per_group(int mode) { return mode_slots(mode) == 0 && mode != kAdagradRow ? 2 : kSegsPerGroup; }
 constexpr int kMaxLdsDesc = 512;  // features / tables whose descriptors are cached in LDS
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -854,7 +858,7 @@ typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
 //     in unaligned-access mode, a `global_load_dwordx4` needs no 16-byte alignment), so there is one access form;
 //   * weights / bag scales / LDS descriptors are compile-time cases (the host picks the instance);
 //   * invalid or out-of-range work is CLAMPED to a valid address and masked at the store, never skipped;
-//   * the metadata of the group's kSegsPerGroup segments is fetched in two trips for all of them (bounds; key and
+//   * the metadata of the group's segs_per_group(MODE) segments is fetched in two trips for all of them (bounds; key and
 //     the first two values), and the segments are software-pipelined: the table row, accumulator row and the
 //     first two gradient rows of segment i+1 are requested before segment i is consumed.
 // Per group that is 2 + 1 trips for four segments instead of ~8 each.  Segments longer than two lookups finish
@@ -933,7 +937,7 @@ constexpr int kFastMore = 4;    // ... and per trip of the remainder loop
 template <typename GT, typename TT, int LPR, int MODE, bool HAS_W, bool HAS_SCALE>
 __global__ __launch_bounds__(256) void bag_apply_fast_kernel(const ApplyParams p) {
   constexpr int N = Piece<GT>::N;
-  constexpr int S = kSegsPerGroup;
+  constexpr int S = segs_per_group(MODE);
   constexpr int WT = N * (int)sizeof(TT) / 4;   // dwords of a lane's table piece
   constexpr int WS = N;                         // ... of its fp32 slot piece
   constexpr bool kFused = mode_is_fused(MODE);
@@ -1485,7 +1489,7 @@ template <typename GT, typename TT, int MODE>
 int launch_apply_lpr(const ApplyParams& p, int pieces, hipStream_t st) {
   const int lpr = pieces <= 8 ? 8 : (pieces <= 16 ? 16 : (pieces <= 32 ? 32 : 64));
   const int64_t groups = p.nnz;  // upper bound of the segment count (device-side n_seg trims it)
-  const int64_t blocks = ceil_div(groups, (256 / lpr) * kSegsPerGroup);
+  const int64_t blocks = ceil_div(groups, (256 / lpr) * segs_per_group(MODE));
   if (blocks > 0x7fffffffLL) return fail(KRS_ERR_UNSUPPORTED, "embed_bag_bwd: grid too large");
 #define KRS_LAUNCH_FAST(L, W, SC) \
   hipLaunchKernelGGL((bag_apply_fast_kernel<GT, TT, L, MODE, W, SC>), dim3((unsigned)blocks), dim3(256), 0, st, p)
