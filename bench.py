@@ -43,6 +43,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_START = time.perf_counter()
 
 ML_PERF_HOTS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
 # Criteo-1TB vocabulary sizes of the 26 categorical features (data of examples/ml_perf/configs/v6e_8.py:15-172)
@@ -132,6 +133,14 @@ def parse():
                     help="also time the step with ids that start in HOST memory, fed through "
                          "keras_rs_amd.data.ThreadedDataLoader with this many loader threads (PCIe-inclusive rate, "
                          "reported under `host_inputs`; never `value`)")
+    ap.add_argument("--detail", default="bench_detail.json", metavar="PATH",
+                    help="side file with everything the run measured (roofline_step, also, also_c2, phases, graph_leg, per-step "
+                         "times); the last stdout line is a summary below %d bytes that names it" % 4096)
+    ap.add_argument("--print-detail", action="store_true",
+                    help="also print the side file's content as an earlier stdout line (KRS_BENCH_DETAIL ...)")
+    ap.add_argument("--cpu-pools", default="16", metavar="LIST",
+                    help="intra-op pool sizes of the torch-CPU leg of cpu_baseline, comma separated, each capped at the host's "
+                         "thread count (BASELINE.md section 4 records the 256- and 64-thread pools as 130x / 2.4x SLOWER than 16)")
     a = ap.parse_args()
     if a.criteo_vocab:
         if a.tables != len(CRITEO_VOCABS):
@@ -398,7 +407,8 @@ def cpu_baseline(a, hots):
     # "all threads": torch's intra-op pool at every hardware thread is far from its best on a many-core host (a
     # 256-thread box measured 75x SLOWER per lookup than one thread: synchronisation, not work), so the pool size is
     # swept and the fastest is the one reported as the all-threads leg; every size tried is listed
-    tried = [torch_leg(t, b, 2, 10) for t in sorted({n_thr, min(n_thr, 64), min(n_thr, 16)}, reverse=True)]
+    pools = sorted({max(1, min(n_thr, int(v))) for v in str(getattr(a, "cpu_pools", "16")).split(",") if v.strip()}, reverse=True)
+    tried = [torch_leg(t, b, 2, 10) for t in pools]
     torch_all = max(tried, key=lambda r: r["value"])
     torch_one = torch_leg(1, max(b // 4, 64), 1, 3)
     torch.set_num_threads(n_thr)
@@ -987,11 +997,18 @@ def gemm_family_rooflines(a, pr, n, b_local):
         out.append({"kernel": "krs_gemm x %d per step, all families above in aggregate (against the MFMA peak; the per-family "
                               "entries say which of them are HBM-bound)" % agg_calls, "bound": "mfma",
                     "achieved": agg_fl / sec / 1e12, "peak": agg_peak / 1e12, "unit": "TFLOP/s", "frac": agg_fl / sec / agg_peak,
-                    "ms_per_step": agg_ms, "flops_per_step": agg_fl, "traffic": None})
+                    "ms_per_step": agg_ms, "flops_per_step": agg_fl, "traffic": None, "aggregate": True})
     return out
 
 
-def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False):
+def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False, in_step_s=None):
+    """`roofline` of K1.  `k1_s` = one launch on an otherwise idle stream (blocker-backed event pairs behind the timed
+    steps); `in_step_s` = the same launch INSIDE real steps (probe span: beside the K2 plan's kernels on the side stream, as
+    the timed steps run it).  When both exist the in-step duration is the one `achieved` / `frac` are computed from and the
+    isolated one is kept beside it as `isolated_us` (round-5 review: the line must price what the step runs)."""
+    iso_s = k1_s
+    if in_step_s:
+        k1_s = in_step_s
     nnz = b_local * sum(hots)
     # gather form (sharded owner side): one output vector per lookup, i.e. `bags` = nnz
     alg = k1_bytes(nnz, nnz if gather_form else b_local * a.tables, a.dim, 4 if getattr(a, "fp32", False) else 2)
@@ -1003,6 +1020,9 @@ def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False):
             "traffic_source": None if traffic is None else "profiles/k1_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                               "passes of this kernel at this shape (counters cannot be read inside this run)",
             "launch_us": k1_s * 1e6,
+            "launch_us_source": ("HIP events around the call inside the probe steps (in-step)" if in_step_s else
+                                 "HIP events around one launch behind the timed steps (isolated)"),
+            "isolated_us": iso_s * 1e6, "isolated_frac": alg / iso_s / HBM_PEAK,
             "algorithmic_bytes": alg}
 
 
@@ -1027,6 +1047,125 @@ def pmc_traffic(kernel):
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+LINE_LIMIT = 4096     # bytes of the LAST stdout line (the driver keeps a ~8 KB tail of stdout + stderr: round-5's 21 KB line was cut)
+
+
+def _sig(v, digits=6):
+    """Floats to `digits` significant figures (the line is a summary: the side file keeps every bit)."""
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v)) if math.isfinite(v) else None
+    return v
+
+
+def _pick(obj, keys):
+    return {k: _sig(obj[k]) for k in keys if isinstance(obj, dict) and k in obj}
+
+
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_us", "launch_us_source", "isolated_us",
+                 "isolated_frac",
+                 "algorithmic_bytes", "ms_per_step", "calls_per_step")
+
+
+def dominant_roofline(entries, single=False):
+    """The `roofline_step` entry that costs the step the most time and has a roofline of its own (a `frac`): per-step time =
+    `ms_per_step`, or launch_us x calls_per_step.  `single` leaves the aggregate-over-families entry out: the answer is then
+    one kernel (one product family), not a sum."""
+    best, best_ms = None, -1.0
+    for e in entries or []:
+        if "frac" not in e or (single and e.get("aggregate")):
+            continue
+        ms = e["ms_per_step"] if "ms_per_step" in e else e.get("launch_us", 0.0) * e.get("calls_per_step", 1) * 1e-3
+        if ms > best_ms:
+            best, best_ms = dict(e, ms_per_step=ms), ms
+    return best
+
+
+def compact_line(full, detail_path):
+    """The ONE line the driver parses: the contract's keys, `roofline` (K1, the north-star kernel, at its in-step duration),
+    `roofline_dominant` (the kernel family that costs the step the most time, with its own fraction), `cpu_baseline`, the
+    sustained / secondary legs as one number each, the N > 1 self-check, and the path of the side file that holds everything
+    else (`roofline_step`, `also`, `also_c2`, `phases`, `graph_leg`, per-step times ...).  Always below LINE_LIMIT bytes:
+    optional members are dropped, last first, until it fits (tests/test_layers_host.py)."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data"))
+    cfg = full.get("config", {})
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:330], "global_batch": cfg.get("global_batch"),
+                      "parallelism": str(cfg.get("parallelism", ""))[:170]}
+    if "roofline" in full:
+        line["roofline"] = dict(_pick(full["roofline"], ROOFLINE_KEYS), kernel=str(full["roofline"].get("kernel", ""))[:80])
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = dict(_pick(cb, ("value", "unit", "cores", "kind")), sample=str(cb.get("sample", ""))[:260],
+                                    implementation=str(cb.get("implementation", ""))[:150])
+    optional = []           # (key, value) in order of importance: dropped from the END when the line is too long
+    if full.get("invalid"):
+        optional.append(("invalid", str(full["invalid"])[:200]))
+    if "overflow_steps" in full:
+        optional.append(("overflow_steps", full["overflow_steps"]))
+    if isinstance(full.get("parity"), dict):
+        optional.append(("parity", _pick(full["parity"], ("checked", "ok", "fwd_max_ulp", "update_max_ulp", "checked_rows"))))
+    for key, single in (("roofline_dominant", False), ("roofline_dominant_kernel", True)):
+        dom = dominant_roofline(full.get("roofline_step"), single)
+        if dom and not (single and dom.get("kernel") == (dominant_roofline(full.get("roofline_step")) or {}).get("kernel")):
+            optional.append((key, dict(_pick(dom, ROOFLINE_KEYS), kernel=str(dom.get("kernel", ""))[:80])))
+    if isinstance(full.get("sustained"), dict):
+        optional.append(("sustained", _pick(full["sustained"], ("steps", "ms_per_step", "median_ms", "vs_timed_region"))))
+    if isinstance(full.get("step_stats"), dict):
+        optional.append(("step_stats", _pick(full["step_stats"], ("median_ms", "min_ms", "max_ms", "steps_over_1.5x_median"))))
+    if "host_enqueue_ms_per_step" in full:
+        optional.append(("host_enqueue_ms_per_step", _sig(full["host_enqueue_ms_per_step"])))
+    if isinstance(full.get("also"), dict):
+        al = _pick(full["also"], ("value", "unit", "ms_per_step"))
+        al["workload"] = str(full["also"].get("workload", ""))[:60]
+        if isinstance(full["also"].get("roofline"), dict):
+            al["roofline"] = _pick(full["also"]["roofline"], ("kernel", "frac", "launch_us", "algorithmic_bytes", "traffic"))
+            al["roofline"]["kernel"] = str(al["roofline"].get("kernel", ""))[:60]
+        optional.append(("also", al))
+    for key, keys in (("graph_leg", ("attempted", "ok", "ms_per_step", "value", "promoted_to_value", "error")),
+                      ("eager_leg", ("ms_per_step", "value")), ("full_model", ("ms_per_step", "value")),
+                      ("host_inputs", ("ms_per_step", "value", "loader_threads"))):
+        if isinstance(full.get(key), dict):
+            sub = _pick(full[key], keys)
+            if "error" in sub:
+                sub["error"] = str(sub["error"])[:160]
+            optional.append((key, sub))
+    if isinstance(full.get("exchange"), dict):
+        optional.append(("exchange", _pick(full["exchange"], ("mode", "bytes_at_capacity", "bytes_at_need", "capacity", "need"))))
+    for key in ("ranks", "backend", "virtual_world", "a2a_bytes_per_step", "embed_fwd_lookups_per_s", "launch"):
+        if full.get(key) is not None:
+            optional.append((key, _sig(full[key]) if not isinstance(full[key], str) else full[key][:120]))
+    if isinstance(full.get("also_c2"), dict):
+        optional.append(("also_c2", _pick(full["also_c2"], ("value", "unit", "ms_per_step", "dtype", "error"))))
+    if isinstance(full.get("phases"), dict):
+        optional.append(("phases_ms", {k: _sig(v.get("ms_per_step"), 4) for k, v in full["phases"].items() if isinstance(v, dict)}))
+    line["detail"] = detail_path
+    for key, val in optional:
+        line[key] = val
+    while len(json.dumps(line)) >= LINE_LIMIT and optional:
+        key, _ = optional.pop()
+        line.pop(key, None)
+    assert len(json.dumps(line)) < LINE_LIMIT, "the headline members alone exceed the line limit"
+    return line
+
+
+def write_detail(full, path):
+    """Everything the run measured, as one JSON file: `path` (default ./bench_detail.json) and, when the run is inside a
+    gpurun snapshot, gpurun_out/bench_detail.json as well (the directory that travels back)."""
+    paths = [path]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) or os.environ.get("GRAFT_REPO_ROOT"):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = []
+    for p in paths:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(p)), exist_ok=True)
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1)
+            written.append(p)
+        except OSError:
+            pass
+    return written
 
 
 def main():
@@ -1073,26 +1212,22 @@ def main():
         ids0, _ = make_inputs(a, primary, b_local, rank, dev)
         parity = sharded_parity(model, a, primary, world, rank, dev, b_local, ids0, model.embedding.preprocess(ids0), backend)
         del ids0
+    wall = {"setup_build_model": time.perf_counter() - T_START}
+    t_mark = time.perf_counter()
     r1 = measure(model, a, primary, world, rank, dev, b_local, a.steps, a.warmup, opt_box, probe_steps=a.probe_steps,
                  sustained_steps=a.sustained_steps)
+    wall["primary_leg"] = time.perf_counter() - t_mark
+    t_mark = time.perf_counter()
     # the other C3 bag-length list (SURVEY.md section 8d lists both), same tables and model, shorter run.  The
     # shapes change (ids, plan workspace), so the leg gets its own warm-up of at least 5 steps: the caching
     # allocator re-carves its blocks during the first steps after a shape change
     sec_steps = max(3, a.steps // 2)
     r2 = measure(model, a, secondary, world, rank, dev, b_local, sec_steps, max(5, a.warmup), opt_box,
                  probe_steps=a.probe_steps)
+    wall["secondary_leg"] = time.perf_counter() - t_mark
     elapsed, k1_s, elapsed2, k1_s2 = r1["elapsed"], r1["k1_s"], r2["elapsed"], r2["k1_s"]
     c2 = None
-    if not a.no_c2 and world == 1 and not a.force_sharded and not a.criteo_vocab and not a.graph:
-        # in a process of its own (its graph capture is then the first of a process, and a failure costs this leg only)
-        import subprocess
-
-        try:
-            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c2-leg", "--no-cpu-baseline"], capture_output=True,
-                                text=True, timeout=420)
-            c2 = json.loads([ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")][-1])
-        except Exception as e:   # noqa: BLE001
-            c2 = {"error": "the C2 leg's process failed: " + repr(e)[:300]}
+    want_c2 = not a.no_c2 and world == 1 and not a.force_sharded and not a.criteo_vocab and not a.graph
     host = None
     if a.host_inputs > 0 and world == 1 and not a.force_sharded:
         # ids start in host memory: a small pool of batches cycles through the loader threads, which
@@ -1116,7 +1251,7 @@ def main():
                 "note": "ids generated on the host, ThreadedDataLoader -> preprocess -> pinned upload; PCIe-inclusive"}
     full = None
     if a.full_model and world == 1 and not a.force_sharded:
-        del model  # frees the first model's tables before the second set is built
+        model = None  # frees the first model's tables before the second set is built
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "examples"))
         import dlrm_dcn_v2 as ex
@@ -1212,6 +1347,7 @@ def main():
                                 else f"tables MOD row-sharded over {world} GPUs, dense part DP"),
             },
             "step_stats": step_stats(r1["step_ms"]),
+            "wall_seconds": wall,      # where the run's own wall clock went (host seconds per leg)
             # host time to ENQUEUE one step (the loop returns before the device has finished): below ms_per_step = the host
             # runs ahead of the GPU and the step is GPU-bound; equal to it = the host is the limit (e.g. a wait inside the step)
             "host_enqueue_ms_per_step": r1["enqueue_s"] / a.steps * 1e3,
@@ -1226,6 +1362,20 @@ def main():
             ex = r1["exchange"]
             out["a2a_bytes_per_step"] = ex.get("bytes_per_step")
             out["exchange"] = {k: v for k, v in ex.items() if k in ("mode", "bytes", "capacity", "need", "received")}
+            if ex.get("mode") == "static" and ex.get("capacity") and ex.get("need"):
+                # link bytes of the blocks as sized (capacity) against what this batch's data needed (the largest block
+                # need over all ranks, every block sized to it): the cost of the headroom in bytes, side by side
+                from keras_rs_amd import _lib as _L
+                import ctypes as _C
+
+                def block_bytes(cl, cs):
+                    w = int(_L.lib().krs_shard_static_block_words(_C.c_int64(int(cl)), _C.c_int64(int(cs)), _C.c_int(0)))
+                    es_p = ex["bytes"]["partials_fwd"] // max(1, vworld * ex["capacity"][1] * a.dim)
+                    off = (vworld - 1) / vworld if vworld > 1 else 1.0
+                    return int(off * (4 * vworld * w + 2 * vworld * int(cs) * a.dim * es_p))
+
+                out["exchange"]["bytes_at_capacity"] = block_bytes(*ex["capacity"])
+                out["exchange"]["bytes_at_need"] = block_bytes(*ex["need"])
             # static exchange: lookups beyond a block's capacity are DROPPED (the reference's id dropping) -- `value` would
             # then count dropped lookups as work, so the line says so at the top level
             if "phases" in r1:
@@ -1247,16 +1397,22 @@ def main():
             n1 = "embed_gather_hot1 (K1 owner-side row gather of the sharded path, rank 0)" if sharded else k1_name(primary)
             n2 = n1 if sharded else k1_name(secondary)
             out["embed_fwd_lookups_per_s"] = vworld * b_local * sum(primary) / k1_s
-            out["roofline"] = k1_roofline(a, primary, b_local, k1_s, n1, sharded)
+            def in_step(res):       # K1's span inside the probe steps (the unsharded layer: one krs_embed_bag_fwd per step)
+                e = (res.get("probe") or {}).get("k1")
+                return None if sharded or not e or not e["calls"] else e["ms_total"] / e["calls"] * 1e-3
+
+            out["roofline"] = k1_roofline(a, primary, b_local, k1_s, n1, sharded, in_step(r1))
             second["embed_fwd_lookups_per_s"] = vworld * b_local * sum(secondary) / k1_s2
-            second["roofline"] = k1_roofline(a, secondary, b_local, k1_s2, n2, sharded)
+            second["roofline"] = k1_roofline(a, secondary, b_local, k1_s2, n2, sharded, in_step(r2))
         for res, tgt, hots in ((r1, out, primary), (r2, second, secondary)):
             rs = roofline_step(a, hots, b_local, res)
             if rs:
                 tgt["roofline_step"] = rs
+        for key, single in (("roofline_dominant", False), ("roofline_dominant_kernel", True)):
+            dom = dominant_roofline(out.get("roofline_step"), single)
+            if dom:
+                out[key] = dom
         out["also"] = second
-        if c2 is not None:
-            out["also_c2"] = c2
         if host is not None:
             out["host_inputs"] = host
         if full is not None:
@@ -1268,9 +1424,11 @@ def main():
                                   "update_max_ulp %s)" % (parity.get("fwd_max_ulp"), parity.get("update_max_ulp")))
 
     def emit(graph_info=None):
-        line = dict(out)
+        full = dict(out)
         if graph_info is not None:
-            line["graph_leg"] = graph_info
+            full["graph_leg"] = graph_info
+        written = write_detail(full, a.detail)
+        line = compact_line(full, written[0] if written else None)
         # (RCCL writes its version banner through C stdio: push it out now, so that the JSON line is the LAST line)
         import ctypes
 
@@ -1278,6 +1436,8 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
+        if a.print_detail:
+            print("KRS_BENCH_DETAIL " + json.dumps(full))     # an EARLIER stdout line: the last one stays the compact one
         print(json.dumps(line))
         sys.stdout.flush()
 
@@ -1286,7 +1446,9 @@ def main():
         if rank == 0:
             # (the eager legs' line goes to STDERR first: should the capture take the process down -- which no handler can catch --
             #  the measurement is at least in the log)
-            print("KRS_EAGER_LINE " + json.dumps(out), file=sys.stderr, flush=True)
+            write_detail(dict(out, graph_leg={"attempted": True, "ok": None, "note": "written before the capture"}), a.detail)
+            print("KRS_EAGER_LINE " + json.dumps(_pick(out, ("value", "ms_per_step", "n_gpus", "overflow_steps"))),
+                  file=sys.stderr, flush=True)
         info = {"attempted": True, "ok": False}
         try:
             a.graph, a._graph_used = True, False
@@ -1319,8 +1481,28 @@ def main():
         torch.distributed.destroy_process_group()
     if rank != 0:
         return
+    t_mark = time.perf_counter()
+    if want_c2:
+        # the C2 leg (BASELINE.json configs[1]) in a process of its own: its graph capture is then the first of a process, and a
+        # failure costs this leg only.  It runs once this process is done with the GPU (tables freed) and BEFORE the host-CPU
+        # leg: side by side they share the host's cores, and a launch-bound step of ~40 launches measured 1.89 ms instead
+        # of 0.65 (and the CPU leg 2.9 M lookups/s instead of 3.5 M) -- gpurun_out of round 6, first call
+        import subprocess
+
+        model = r1 = r2 = None     # (tables and probe events freed before the leg's process asks for the GPU)
+        torch.cuda.empty_cache()
+        try:
+            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--c2-leg", "--no-cpu-baseline"], capture_output=True,
+                                text=True, timeout=420)
+            out["also_c2"] = json.loads([ln for ln in pr.stdout.strip().splitlines() if ln.startswith("{")][-1])
+        except Exception as e:   # noqa: BLE001
+            out["also_c2"] = {"error": "the C2 leg's process failed: " + repr(e)[:300]}
+        out["wall_seconds"]["c2_leg_process"] = time.perf_counter() - t_mark
+        t_mark = time.perf_counter()
     if not a.no_cpu_baseline and world == 1 and not a.criteo_vocab:   # the host-CPU leg is timed on rank 0 of the single-GPU run only
         out["cpu_baseline"] = cpu_baseline(a, primary)
+        out["wall_seconds"]["cpu_baseline"] = time.perf_counter() - t_mark
+    out["wall_seconds"]["total_since_import"] = time.perf_counter() - T_START
     emit()
 
 

@@ -1418,7 +1418,9 @@ int gemm_pipe() {
 // factor that minimises  rounds over the 256 CUs x (K per split + per-workgroup overhead) + slab traffic
 // -- 2 x 14 tiles of the C3 weight gradients: 9 splits = 252 workgroups in ONE round (16 splits were 448
 // workgroups = 1.75 rounds, and 113 MB of slabs instead of 64).
-int pick_splits(int64_t m, int64_t n, int64_t k, int a_is_km) {
+// `ring_ok`: the product can take the ring kernel's split-K form (bf16, B as [N, K]) -- the third branch hands
+// out splits for that kernel only; the workspace query leaves it true (an upper bound for every dtype / layout).
+int pick_splits(int64_t m, int64_t n, int64_t k, int a_is_km, bool ring_ok = true) {
   if (a_is_km && k >= 1024 && std::min(m, n) <= 16) {   // gemm_thin_kernel: >= 512 rows of K per split, <= 128 splits
     const int64_t s = k / 512;                            // (256 splits made the slab reduction the longer kernel,
     return (int)(s > 128 ? 128 : s);                      //  64 left half of the CUs without a workgroup)
@@ -1440,7 +1442,7 @@ int pick_splits(int64_t m, int64_t n, int64_t k, int a_is_km) {
   // but whose K is long: the ring kernel with the K range dealt to s workgroups per tile -- half the operand bytes per flop
   // of the 128x128 kernel that ran these shapes until round 5, at the price of s fp32 slabs (h = x U at M = 8192: 59 -> 4x us,
   // DESIGN.md section 4).  s * tiles ~ 256 workgroups, >= 512 of K per split, whole 32-k blocks.
-  if (!a_is_km && m >= 256 && n >= 256 && k >= 2048 && k % 32 == 0) {
+  if (ring_ok && !a_is_km && m >= 256 && n >= 256 && k >= 2048 && k % 32 == 0) {
     const int64_t t256 = ceil_div(m, 256) * ceil_div(n, 256);
     if (t256 < 192) {
       // (krs_gemm rounds the K per split up to whole 64-k tiles: the last split takes what is left, and must still hold
@@ -1630,10 +1632,14 @@ extern "C" size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int 
   return s > 1 ? (size_t)s * (size_t)m * (size_t)n * sizeof(float) : 0;
 }
 
-extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, int64_t ldb, int b_is_nk,
-                        void* c, int64_t ldc, int64_t m, int64_t n, int64_t k, int in_dtype, int out_dtype,
-                        const krs_gemm_epilogue* epilogue, void* workspace, size_t workspace_bytes,
-                        void* stream) {
+namespace krs {
+namespace {
+// krs_gemm's body.  `allow_split` false = one pass over K whatever pick_splits would choose (the two-call form of
+// krs_gemm_cross_bwd, whose workspace is sized for the column sums only).
+int gemm_run(const void* a, int64_t lda, int a_is_km, const void* b, int64_t ldb, int b_is_nk,
+             void* c, int64_t ldc, int64_t m, int64_t n, int64_t k, int in_dtype, int out_dtype,
+             const krs_gemm_epilogue* epilogue, void* workspace, size_t workspace_bytes,
+             void* stream, bool allow_split) {
   KRS_REQUIRE(a && b && c, "krs_gemm: null operand");
   KRS_REQUIRE(m >= 0 && n >= 0 && k >= 0, "krs_gemm: negative size");
   KRS_REQUIRE((in_dtype == KRS_F32 || in_dtype == KRS_BF16) && (out_dtype == KRS_F32 || out_dtype == KRS_BF16),
@@ -1661,7 +1667,7 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
   }
   const int es = in_dtype == KRS_BF16 ? 2 : 4;
   if (k > 0 && mfma_eligible(p, es) && !(p.a_km && p.b_nk)) {
-    const int s = pick_splits(m, n, k, a_is_km);
+    const int s = allow_split ? pick_splits(m, n, k, a_is_km, es == 2 && b_is_nk) : 1;
     if (s > 1) {
       const size_t need = (size_t)s * m * n * sizeof(float);
       if (!workspace || workspace_bytes < need)
@@ -1734,6 +1740,16 @@ extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, 
   KRS_CHECK_LAUNCH("gemm_generic_kernel");
   return KRS_OK;
 }
+}  // namespace
+}  // namespace krs
+
+extern "C" int krs_gemm(const void* a, int64_t lda, int a_is_km, const void* b, int64_t ldb, int b_is_nk,
+                        void* c, int64_t ldc, int64_t m, int64_t n, int64_t k, int in_dtype, int out_dtype,
+                        const krs_gemm_epilogue* epilogue, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  return gemm_run(a, lda, a_is_km, b, ldb, b_is_nk, c, ldc, m, n, k, in_dtype, out_dtype, epilogue, workspace,
+                  workspace_bytes, stream, true);
+}
 
 // ---- krs_gemm_cross_bwd: data-gradient product + the elementwise backward of the layer below, one launch ---------------
 extern "C" size_t krs_gemm_cross_bwd_workspace_bytes(int64_t m, int64_t n) {
@@ -1768,7 +1784,9 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
     krs_gemm_epilogue ep;
     memset(&ep, 0, sizeof(ep));
     ep.r = r; ep.ldr = ldr; ep.beta = beta;
-    if (int rc = krs_gemm(a, lda, 0, bt, ldb, 1, g_out, ldg, m, n, k, dtype, dtype, r ? &ep : nullptr, nullptr, 0, stream))
+    // (one pass over K: this entry's workspace holds the column sums, not split-K slabs)
+    if (int rc = gemm_run(a, lda, 0, bt, ldb, 1, g_out, ldg, m, n, k, dtype, dtype, r ? &ep : nullptr, nullptr, 0, stream,
+                          false))
       return rc;
     KRS_REQUIRE(ldg == ld, "krs_gemm_cross_bwd: the two-call form needs one row stride for G, x0, u, dz and dx0");
     if (u_upper) {   // the upper layer's term first: dx0 = R * u_upper (its own rounding here), then accumulate

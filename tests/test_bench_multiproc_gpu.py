@@ -15,18 +15,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _detail_path():
+    import tempfile
+
+    return os.path.join(tempfile.mkdtemp(prefix="krs_bench_"), "bench_detail.json")
+
+
 def test_two_rank_bench_run_over_gloo():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000", "--sustained-steps", "4"]
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000", "--sustained-steps", "4", "--detail", _detail_path()]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["unit"] == "lookups/s" and d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
     assert "row-sharded over 2 GPUs" in d["config"]["parallelism"] and d["config"]["global_batch"] == 4096
@@ -45,7 +50,7 @@ def test_the_self_check_of_the_sharded_line_has_teeth():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["KRS_BENCH_PARITY_SABOTAGE"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--batch", "2048", "--vocab", "20000", "--sustained-steps", "0", "--probe-steps", "0"]
+           "--no-cpu-baseline", "--batch", "2048", "--vocab", "20000", "--sustained-steps", "0", "--probe-steps", "0", "--detail", _detail_path()]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
@@ -54,7 +59,23 @@ def test_the_self_check_of_the_sharded_line_has_teeth():
 
 
 def _json_line(stdout):
-    return json.loads([ln for ln in stdout.strip().splitlines() if ln.startswith("{")][-1])
+    """The LAST stdout line (the driver's: below 4 KB, contract keys present) merged over the side file it names, which holds
+    the deep members (`phases`, `graph_leg`, `exchange`, per-step times)."""
+    last = stdout.strip().splitlines()[-1]
+    assert last.startswith("{") and len(last) < 4096, len(last)
+    line = json.loads(last)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "detail"):
+        assert key in line, key
+    with open(line["detail"]) as f:
+        full = json.load(f)
+    for key in ("value", "ms_per_step", "n_gpus"):
+        assert abs(full[key] - line[key]) <= 1e-5 * abs(full[key]), key
+    if "parity" in full:
+        assert line["parity"]["ok"] == full["parity"]["ok"]
+    if "invalid" in full:
+        assert "invalid" in line
+    return dict(line, **full)
 
 
 def test_bare_bench_command_launches_its_own_ranks():
@@ -62,7 +83,7 @@ def test_bare_bench_command_launches_its_own_ranks():
     than GPUs and the default backend it falls back to gloo and says so in the line."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000", "--sustained-steps", "0"]
+           "--no-cpu-baseline", "--batch", "4096", "--vocab", "50000", "--sustained-steps", "0", "--detail", _detail_path()]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
@@ -96,7 +117,7 @@ def test_sharded_step_through_a_one_rank_rccl_communicator():
     for exchange in ("static", "exact"):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--rccl-self", "--exchange", exchange,
                "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--batch", "8192", "--vocab", "100000",
-               "--sustained-steps", "0"]
+               "--sustained-steps", "0", "--detail", _detail_path()]
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         d = _json_line(r.stdout)
@@ -120,7 +141,7 @@ def test_virtual_world_runs_rank_zero_of_an_n_way_job_with_n_way_shapes():
     that the line labels as such (no parity: the other ranks' shards do not exist)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--virtual-world", "4", "--steps", "3", "--warmup", "2",
-           "--no-cpu-baseline", "--batch", "8192", "--vocab", "100000", "--sustained-steps", "0"]
+           "--no-cpu-baseline", "--batch", "8192", "--vocab", "100000", "--sustained-steps", "0", "--detail", _detail_path()]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)

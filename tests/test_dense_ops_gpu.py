@@ -606,3 +606,38 @@ def test_split_k_on_the_ring_kernel_for_outputs_too_small_to_fill_the_chip(m, n,
         L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(4))
     assert (got == ref0).float().mean() > 0.99
     torch.testing.assert_close(got.float(), ref0.float(), rtol=2.0 ** -7, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_cross_backward_with_a_long_k_on_a_small_batch_needs_no_split_k_workspace(dt):
+    """krs_gemm_cross_bwd's two-call form (fewer than 192 tiles of 256 x 256: a per-rank batch) with
+    K >= 2048 -- a Dense layer of >= 2048 units on a cross output, or projection_dim >= 2048 -- used to hand krs_gemm a NULL
+    workspace for a shape pick_splits deals over several workgroups per tile (KRS_ERR_WORKSPACE).  The inner product now runs in
+    one pass over K; G against float64, dz / dx0 from G as stored.  fp32 / row-major products of that shape no longer take the
+    ring's split either: krs_gemm with a NULL workspace succeeds for them."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd import dense_ops as D
+
+    dev = "cuda:0"
+    m, n, k = 2048, 3456, 2048
+    assert int(L.lib().krs_gemm_workspace_bytes(C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int(0))) > 0   # (a split shape)
+    gen = torch.Generator(device=dev).manual_seed(37)
+    rnd = lambda *sh: ((torch.rand(*sh, device=dev, generator=gen) - 0.5)).to(dt)  # noqa: E731
+    A, Bt, R, x0, u = rnd(m, k), rnd(n, k) * 0.1, rnd(m, n), rnd(m, n), rnd(m, n)
+    G, dz, dx0, db = D.gemm_cross_bwd(A, Bt, R, x0, u, act=L.ACT_NONE)
+    ref = A.double() @ Bt.double().t() + R.double()
+    tol = 2.0 ** -8 * 1.01 if dt == torch.bfloat16 else 1e-5
+    torch.testing.assert_close(G.double(), ref, rtol=tol, atol=1e-4)
+    torch.testing.assert_close(dz.double(), (G.double() * x0.double()), rtol=tol, atol=1e-6)
+    torch.testing.assert_close(dx0.double(), (G.double() * u.double()), rtol=tol, atol=1e-6)
+    torch.testing.assert_close(db.double(), dz.double().sum(0), rtol=1e-4, atol=1e-3)
+    if dt == torch.float32:
+        # krs_gemm itself, fp32 operands, NULL workspace: one pass (the ring's split is for bf16 [N, K] operands only)
+        out = torch.empty(m, n, device=dev, dtype=dt)
+        rc = L.lib().krs_gemm(C.c_void_p(A.data_ptr()), C.c_int64(k), C.c_int(0), C.c_void_p(Bt.data_ptr()), C.c_int64(k), C.c_int(1),
+                              C.c_void_p(out.data_ptr()), C.c_int64(n), C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int(L.F32),
+                              C.c_int(L.F32), None, None, C.c_size_t(0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        L.check(rc, "krs_gemm")
+        torch.testing.assert_close(out.double(), A.double() @ Bt.double().t(), rtol=1e-5, atol=1e-4)

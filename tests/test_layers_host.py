@@ -1,6 +1,8 @@
 """Host-side logic of the drop-in layers (no GPU): constructor/config/error behaviour of the
 reference API surface, nested-structure plumbing, loud failure on CPU."""
 
+import json
+import os
 import numpy as np
 import pytest
 import torch
@@ -411,3 +413,77 @@ def test_bench_prices_every_product_family_against_its_own_bound():
     a = torch.tensor([1.0, 1.0, 0.0, -3.0])
     b = torch.tensor([1.0 + 2.0 ** -7, 1.0, 0.0, -3.0 - 2.0 ** -6])
     assert bench._bf16_ulps(a, b).tolist() == [1.0, 0.0, 0.0, 1.0]
+
+
+def _load_bench():
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("krs_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench, root
+
+
+def test_bench_last_line_stays_below_the_drivers_tail():
+    """bench.py::compact_line (round-5 review, next #1): the LAST stdout line is a summary below 4 KB whatever the run measured
+    -- the full records of a default N = 1 run, a --force-sharded --rccl-self run (phases + graph leg), a --virtual-world 8 run
+    and a --full-model run (tests/golden/bench_lines/: round-5 outputs, 12-21 KB each) all shrink to it, the contract's keys and
+    the roofline / cpu_baseline / self-check members survive, and so does a record with every optional member blown up."""
+    import glob
+
+    bench, root = _load_bench()
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "detail")
+    files = sorted(glob.glob(os.path.join(root, "tests", "golden", "bench_lines", "*.json")))
+    assert len(files) >= 4
+    for path in files:
+        with open(path) as f:
+            full = json.load(f)
+        assert len(json.dumps(full)) > 8192          # (the record that overflowed the driver's tail)
+        line = bench.compact_line(full, "bench_detail.json")
+        text = json.dumps(line)
+        assert len(text) < bench.LINE_LIMIT <= 4096, (path, len(text))
+        for key in contract:
+            assert key in line, (path, key)
+        assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+        rf = line["roofline"]
+        assert rf["bound"] == "hbm" and rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-4)
+        assert rf["achieved"] == pytest.approx(rf["algorithmic_bytes"] / rf["launch_us"] / 1e3, rel=1e-3)
+        assert set(line["config"]) == {"workload", "global_batch", "parallelism"}
+        dom = line["roofline_dominant"]
+        assert dom["frac"] > 0 and dom["ms_per_step"] == pytest.approx(max(
+            e.get("ms_per_step", e.get("launch_us", 0) * e.get("calls_per_step", 1) * 1e-3) for e in full["roofline_step"] if "frac" in e), rel=1e-5)
+        if "cpu_baseline" in full:
+            assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+        if "parity" in full:
+            assert line["parity"]["ok"] == full["parity"]["ok"] and line["overflow_steps"] == full["overflow_steps"]
+        if "graph_leg" in full:
+            assert line["graph_leg"]["ok"] == full["graph_leg"]["ok"]
+    # worst case: every optional member present and every string long -- the tail members are dropped, the contract stays
+    with open(files[1]) as f:
+        full = json.load(f)
+    full["invalid"] = "x" * 5000
+    full["graph_leg"] = {"attempted": True, "ok": False, "error": "e" * 5000}
+    full["config"]["workload"] = "w" * 5000
+    full["config"]["parallelism"] = "p" * 5000
+    full["cpu_baseline"] = {"value": 1.0, "unit": "lookups/s", "cores": 16, "kind": "port", "sample": "s" * 5000, "implementation": "i" * 5000}
+    full["phases"] = {"phase_%d" % i: {"ms_per_step": 0.123456789 * i} for i in range(200)}
+    full["also_c2"] = {"value": 1.0, "unit": "lookups/s", "ms_per_step": 0.65, "dtype": "f32", "error": "c" * 5000}
+    line = bench.compact_line(full, "/a/long/path/" + "d" * 200 + "/bench_detail.json")
+    assert len(json.dumps(line)) < 4096
+    for key in contract + ("cpu_baseline", "invalid", "parity", "overflow_steps"):
+        assert key in line, key
+    assert "phases_ms" not in line
+
+
+def test_bench_dominant_entry_is_priced_per_step():
+    """bench.py::dominant_roofline: the entry with the largest per-step time among those with a roofline of their own; with
+    `single` the aggregate over the GEMM families is left out (K2 apply at C3)."""
+    bench, _ = _load_bench()
+    entries = [{"kernel": "k2", "frac": 0.55, "launch_us": 2400.0}, {"kernel": "nt", "frac": 0.34, "launch_us": 270.0, "calls_per_step": 6},
+               {"kernel": "all", "frac": 0.32, "ms_per_step": 4.7, "aggregate": True}, {"kernel": "K1 in step", "ms_per_step": 99.0}]
+    assert bench.dominant_roofline(entries)["kernel"] == "all"
+    one = bench.dominant_roofline(entries, single=True)
+    assert one["kernel"] == "k2" and one["ms_per_step"] == pytest.approx(2.4)
+    assert bench.dominant_roofline([]) is None
