@@ -231,6 +231,27 @@ int krs_embed_bag_bwd_fused_ftrl(const krs_table* tables, int n_tables,
                                  float learning_rate_power, float l1, float l2, float beta,
                                  const void* workspace, void* stream);
 
+/* krs_embed_bag_bwd_fused_adam with the bias-correction factor read from DEVICE memory when the kernel runs
+ * (*bias_correction_dev, one float): the form a step replayed from a HIP graph needs -- a by-value argument is frozen
+ * into the captured launch, the device float is rewritten before every replay (krs_store_f32).  The layers use this
+ * entry for eager steps as well, so both kinds of step run one code path. */
+int krs_embed_bag_bwd_fused_adam_dyn(const krs_table* tables, int n_tables,
+                                     const krs_feature* feats, int n_feats,
+                                     const float* weights, const float* bag_scale,
+                                     const void* grad, int grad_dtype, int64_t grad_ld,
+                                     int batch, int dim, int table_dtype, int64_t nnz,
+                                     float beta_1, float beta_2, float epsilon, const float* bias_correction_dev,
+                                     const void* workspace, void* stream);
+
+/* Step-dependent optimizer constants (scheduled learning rates, Adam's bias correction) -> device memory without a copy
+ * from the host: values_host[0..count) are read NOW (on the calling thread) and travel as kernel arguments; the kernel
+ * stores value i at (char*)dst + i * stride_bytes.  stride_bytes = sizeof(krs_table) with dst = &tables[0].lr rewrites the
+ * learning rates of a descriptor array in place; stride 4 fills a float array.  No page-locked buffer the host could
+ * overwrite too early, no wait: ordered on `stream` like any launch, so an eager call placed before a graph replay on the
+ * same stream is seen by that replay and not by the one before it.  The reference evaluates schedules on the host every
+ * step too (jax/config_conversion.py:136-176: callable learning rates). */
+int krs_store_f32(void* dst, int64_t stride_bytes, const float* values_host, int count, void* stream);
+
 /* Sparse form: unique global rows and their summed gradients.
  *   unique_rows [nnz] int64 (first *n_unique valid), row_grads [nnz, dim] fp32,
  *   n_unique device int64.

@@ -67,6 +67,8 @@ SYMBOLS = [
     "krs_embed_bag_bwd_fused_adagrad",
     "krs_embed_bag_bwd_fused_adagrad_rowwise",
     "krs_embed_bag_bwd_fused_adam",
+    "krs_embed_bag_bwd_fused_adam_dyn",
+    "krs_store_f32",
     "krs_embed_bag_bwd_fused_ftrl",
     "krs_embed_bag_bwd_sparse",
     "krs_gemm",

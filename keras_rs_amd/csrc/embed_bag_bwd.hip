@@ -737,7 +737,19 @@ struct ApplyParams {
   int64_t* unique_rows;        // sparse
   float* row_grads;            // sparse
   Hyper hyper;                 // Adam / FTRL
+  const float* hyper_d_dev;    // Adam: bias-correction factor read from device memory at run time (NULL: hyper.d)
 };
+
+// The constants a launch runs with: Adam's bias-correction factor comes from device memory when the caller keeps it there
+// (krs_embed_bag_bwd_fused_adam_dyn: a step replayed from a HIP graph reads the value of THIS replay, not the capture's).
+template <int MODE>
+__device__ __forceinline__ Hyper live_hyper(const ApplyParams& p) {
+  Hyper h = p.hyper;
+  if constexpr (MODE == kAdam) {
+    if (p.hyper_d_dev) h.d = *p.hyper_d_dev;
+  }
+  return h;
+}
 
 template <typename T>
 struct Piece;  // 16 bytes of gradient elements
@@ -947,6 +959,7 @@ __global__ __launch_bounds__(256) void bag_apply_fast_kernel(const ApplyParams p
   __shared__ krs_table s_tab[kMaxLdsDesc];
   constexpr int GPB = 256 / LPR;
   const uint32_t n_seg = *p.n_seg;
+  const Hyper hy = live_hyper<MODE>(p);
   const int64_t u_base = (int64_t)blockIdx.x * (GPB * S);
   if (u_base >= n_seg) return;
   for (int f = threadIdx.x; f < p.n_feats; f += 256) {
@@ -1113,7 +1126,7 @@ __global__ __launch_bounds__(256) void bag_apply_fast_kernel(const ApplyParams p
       if constexpr (kSlots >= 1) raw_to_f32<float, N>(x.a, av);
       if constexpr (kSlots == 2) raw_to_f32<float, N>(x.b, bv);
 #pragma unroll
-      for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], acc[k], x.tb.lr, p.hyper);
+      for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], acc[k], x.tb.lr, hy);
       if constexpr (kSlots >= 1) raw_store_nt<WS>(x.tb.slot + x.off, f32_to_raw<float, N>(av));
       if constexpr (kSlots == 2) raw_store_nt<WS>(x.tb.slot + (int64_t)x.tb.vocab * p.dim + x.off, f32_to_raw<float, N>(bv));
       raw_store_nt<WT>(reinterpret_cast<TT*>(x.tb.weights) + x.off, f32_to_raw<TT, N>(wv));
@@ -1180,8 +1193,9 @@ __device__ __forceinline__ void finish_row(const ApplyParams& p, uint32_t u, uin
       load_elems<TT, N>(reinterpret_cast<const TT*>(tb.weights) + off, wv, t_al);
       if constexpr (mode_slots(MODE) >= 1) load_elems<float, N>(tb.slot + off, av, t_al);
       if constexpr (mode_slots(MODE) == 2) load_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
+      const Hyper hy = live_hyper<MODE>(p);
 #pragma unroll
-      for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], tot[k], tb.lr, p.hyper);
+      for (int k = 0; k < N; ++k) row_update<MODE>(wv[k], av[k], bv[k], tot[k], tb.lr, hy);
       if constexpr (mode_slots(MODE) >= 1) store_elems<float, N>(tb.slot + off, av, t_al);
       if constexpr (mode_slots(MODE) == 2) store_elems<float, N>(tb.slot + plane + off, bv, t_al && plane % 4 == 0);
       store_elems<TT, N>(reinterpret_cast<TT*>(tb.weights) + off, wv, t_al);
@@ -1380,7 +1394,7 @@ __global__ __launch_bounds__(256) void bag_apply_generic(const ApplyParams p, in
         const int64_t plane = tb.vocab * p.dim;
         float s0 = mode_slots(MODE) >= 1 ? tb.slot[off] : 0.0f;
         float s1 = mode_slots(MODE) == 2 ? tb.slot[plane + off] : 0.0f;
-        row_update<MODE>(w, s0, s1, acc, tb.lr, p.hyper);
+        row_update<MODE>(w, s0, s1, acc, tb.lr, live_hyper<MODE>(p));
         if (mode_slots(MODE) >= 1) tb.slot[off] = s0;
         if (mode_slots(MODE) == 2) tb.slot[plane + off] = s1;
         st_elem(tb.weights, table_dtype, off, w);
@@ -1579,6 +1593,7 @@ ApplyParams make_apply(const krs_table* tables, int n_tables, const krs_feature*
   p.n_long = l.n_long; p.long_list = l.long_list; p.multi_list = l.multi_list; p.partials = l.partials;
   p.unique_rows = nullptr; p.row_grads = nullptr;
   p.hyper = Hyper{0.0f, 0.0f, 0.0f, 0.0f};
+  p.hyper_d_dev = nullptr;
   return p;
 }
 
@@ -1844,6 +1859,22 @@ extern "C" int krs_embed_bag_bwd_fused_adam(const krs_table* tables, int n_table
   if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
   ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
   p.hyper = Hyper{beta_1, beta_2, epsilon, bias_correction};
+  return run_apply<kAdam>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
+}
+#endif
+
+#if KRS_BWD_HAS(2)
+extern "C" int krs_embed_bag_bwd_fused_adam_dyn(const krs_table* tables, int n_tables, const krs_feature* feats,
+                                                int n_feats, const float* weights, const float* bag_scale,
+                                                const void* grad, int grad_dtype, int64_t grad_ld, int batch,
+                                                int dim, int table_dtype, int64_t nnz, float beta_1, float beta_2,
+                                                float epsilon, const float* bias_correction_dev, const void* workspace,
+                                                void* stream) {
+  if (int rc = check_apply_args(tables, 1, feats, grad, grad_dtype, batch, dim, nnz, workspace)) return rc;
+  KRS_REQUIRE(bias_correction_dev, "krs_embed_bag_bwd_fused_adam_dyn: null bias_correction_dev");
+  ApplyParams p = make_apply(tables, n_tables, feats, n_feats, weights, bag_scale, grad, grad_ld, batch, dim, nnz, workspace);
+  p.hyper = Hyper{beta_1, beta_2, epsilon, 1.0f};
+  p.hyper_d_dev = bias_correction_dev;
   return run_apply<kAdam>(p, grad_dtype, table_dtype, reinterpret_cast<hipStream_t>(stream));
 }
 #endif

@@ -14,6 +14,7 @@ keras_rs/src/layers/embedding/base_distributed_embedding.py:910-928.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Sequence
 
 import numpy as np
@@ -74,6 +75,28 @@ class FusedBags:
             self._tab_key, self._tab_dev, self._tab_host = key, dev, arr
         return dev
 
+    def store_lrs(self, lrs: Sequence[float]) -> None:
+        """New learning rates for the tables (a schedule's value for the coming update).  Once the descriptor array is on the
+        device they are written INTO it by a kernel whose arguments carry the values (krs_store_f32: no upload, no wait, ordered
+        on the current stream) -- the form that also works between the replays of a captured step; before that they only
+        replace `self.lrs` and ride along with the first upload."""
+        lrs = [float(v) for v in lrs]
+        if len(lrs) != len(self.tables):
+            raise L.KrsError("store_lrs: one learning rate per table")
+        if lrs == self.lrs:
+            return
+        self.lrs = lrs
+        if self._tab_dev is None or self._tab_key is None:
+            return
+        n = len(self.tables)
+        vals = (C.c_float * n)(*lrs)
+        rc = L.lib().krs_store_f32(C.c_void_p(self._tab_dev.data_ptr() + L.TABLE_DT.fields["lr"][1]), C.c_int64(L.TABLE_DT.itemsize),
+                                   vals, C.c_int(n), L.stream_ptr())
+        L.check(rc, "krs_store_f32")
+        self._tab_key = self._tab_key[:2 * n] + tuple(lrs) + self._tab_key[3 * n:]
+        if self._tab_host is not None:
+            self._tab_host["lr"] = lrs
+
     def feature_desc(self, batch: int, hots: Sequence[int] | None, device) -> torch.Tensor:
         # CSR form (hots is None): the descriptors carry no batch-dependent field
         key = (batch if hots is not None else None, None if hots is None else tuple(hots), str(device))
@@ -132,7 +155,7 @@ class FusedBags:
         global_order (default): the global sort -- out-of-range ids form ONE trailing run, every apply form accepts
         the plan.  global_order=False: dense bags take the faster table-segmented sort, which leaves them at the end
         of their table's run; backward_dense / backward_fused skip them wherever they are (the autograd functions
-        ask for this form), backward_sparse refuses such a plan (KRS_ERR_UNSUPPORTED)."""
+        ask for this form); for such a plan krs_embed_bag_bwd_sparse reports n_unique = -1 and backward_sparse raises KrsError."""
         L.require_device(ids, "ids")
         nnz = ids.numel()
         nbytes = L.lib().krs_embed_bag_bwd_workspace_bytes(C.c_int64(nnz))
@@ -203,6 +226,14 @@ class FusedBags:
         elif kind in ("adam", "ftrl"):
             if hyper is None or len(hyper) != 4:
                 raise L.KrsError(f"fused {kind} needs its four hyper-parameters")
+            if kind == "adam" and isinstance(hyper[3], torch.Tensor):
+                # bias correction kept in device memory (StepConstants): the launch reads it when it RUNS
+                L.require_device(hyper[3], "Adam bias correction")
+                with probe.span("k2_apply"):
+                    rc = L.lib().krs_embed_bag_bwd_fused_adam_dyn(*head, *(C.c_float(float(h)) for h in hyper[:3]),
+                                                                  L.ptr(hyper[3]), *tail)
+                L.check(rc, "krs_embed_bag_bwd_fused_adam_dyn")
+                return
             fn = {"adam": L.lib().krs_embed_bag_bwd_fused_adam, "ftrl": L.lib().krs_embed_bag_bwd_fused_ftrl}[kind]
             with probe.span("k2_apply"):
                 rc = fn(*head, *(C.c_float(float(h)) for h in hyper), *tail)
@@ -227,3 +258,47 @@ class FusedBags:
             raise L.KrsError("krs_embed_bag_bwd_sparse: the workspace holds a table-segmented plan; "
                              "plan_backward(global_order=True) is what the compact form needs")
         return rows[:u], vals[:u]
+
+
+class StepConstants:
+    """The optimizer constants of a fused group that change from step to step -- scheduled learning rates and Adam's
+    bias-correction factor sqrt(1 - beta_2^t) / (1 - beta_1^t) -- evaluated on the HOST once per update (the reference does
+    the same: callable learning rates, jax/config_conversion.py:136-176) and kept in DEVICE memory, where the fused update
+    reads them when it runs: the learning rates inside the krs_table descriptors, the Adam factor in a float of its own.
+    `advance()` is that once-per-update host work.  An eager step calls it from its backward pass; a step captured into a HIP
+    graph does not (the capture would freeze one step's values into the graph) -- keras_rs_amd.graphs.GraphedStep calls it
+    before every replay instead, on the replay's stream, so replay k runs with the constants of update k."""
+
+    def __init__(self, owner, bags_of, lrs_at, adam_betas=None):
+        self.owner = owner            # object with the `step` count (fused updates applied so far; checkpointed by the layers)
+        self.bags_of = bags_of        # () -> FusedBags whose descriptors hold the learning rates
+        self.lrs_at = lrs_at          # None (constant rates) or step -> [lr per table]
+        self.adam_betas = adam_betas  # None or (beta_1, beta_2)
+        self.bias_correction = None   # device float32[1]
+
+    def advance(self) -> None:
+        o = self.owner
+        if self.lrs_at is not None:
+            self.bags_of().store_lrs(self.lrs_at(o.step))
+        o.step += 1
+        if self.adam_betas is not None:
+            if self.bias_correction is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise L.KrsError("fused Adam: run one eager step before capturing (the bias-correction float is "
+                                     "allocated on first use)")
+                self.bias_correction = torch.ones(1, dtype=torch.float32, device=self.bags_of().tables[0].device)
+            b1, b2 = self.adam_betas
+            bc = math.sqrt(1.0 - b2 ** o.step) / (1.0 - b1 ** o.step)
+            rc = L.lib().krs_store_f32(L.ptr(self.bias_correction), C.c_int64(4), (C.c_float * 1)(bc), C.c_int(1), L.stream_ptr())
+            L.check(rc, "krs_store_f32")
+
+    def on_backward(self) -> None:
+        """Called where a step's backward pass reaches the fused update."""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            from keras_rs_amd import graphs
+
+            if self.adam_betas is not None and self.bias_correction is None:
+                raise L.KrsError("fused Adam: run one eager step before capturing")
+            graphs.before_each_replay(self.advance)      # raises outside GraphedStep's capture
+        else:
+            self.advance()

@@ -215,12 +215,30 @@ def make_layers(keras) -> types.SimpleNamespace:
             sd = self._impl.state_dict()
             extra = sd.pop("_extra_state", None)
             have = set(store.keys())
-            missing = [k for k in sd if k.replace("/", "__") not in have]
+
+            def stored(key, legacy):
+                """The store's name for `key`: the "__" spelling, or the one an earlier revision wrote ("/" kept, step counts
+                as "iterations/<group>") -- checkpoints of both revisions load."""
+                name = key.replace("/", "__")
+                return name if name in have else (legacy if legacy in have else None)
+
+            names = {k: stored(k, k) for k in sd}
+            missing = [k for k, n in names.items() if n is None]
             if missing:
                 raise ValueError(f"DistributedEmbedding.load_own_variables: the checkpoint lacks {missing}")
-            new = {k: torch.as_tensor(store[k.replace("/", "__")][...]).to(v.dtype) for k, v in sd.items()}
-            its = {k: int(store["iterations__" + str(k).replace("/", "__")][...]) for k in (extra or {}).get("iterations", {})
-                   if "iterations__" + str(k).replace("/", "__") in have}
+            new = {k: torch.as_tensor(store[names[k]][...]).to(v.dtype) for k, v in sd.items()}
+            its, absent = {}, []
+            for k in (extra or {}).get("iterations", {}):
+                n = stored("iterations__" + str(k), "iterations/" + str(k))
+                if n is None:
+                    absent.append(k)
+                else:
+                    its[k] = int(store[n][...])
+            if absent:
+                # the update counts drive Adam's bias correction and every learning-rate schedule: restoring the slot planes
+                # with a count of 0 would apply step-1 constants to trained moments
+                raise ValueError(f"DistributedEmbedding.load_own_variables: the checkpoint lacks the optimizer iteration "
+                                 f"count(s) of {absent}")
             if extra is not None:     # (a module without extra state rejects the key under strict loading)
                 new["_extra_state"] = {"iterations": its}
             self._impl.load_state_dict(new)

@@ -238,12 +238,30 @@ class _Group:
     def fused_kind(self) -> str | None:
         return None if self.fused is None else self.fused.kind
 
+    _constants: Any = None                # embedding_ops.StepConstants when a constant of the update depends on `step`
+
     def next_hyper(self):
-        """Called once per fused update: advances the step count, refreshes scheduled learning rates in
-        the kernel descriptors, returns the Adam / FTRL constants (None for SGD / Adagrad)."""
-        if self.table_opts and any(callable(o.lr) for o in self.table_opts):
-            self.bags.lrs = [o.lr_at(self.step) for o in self.table_opts]   # table_desc() re-uploads on change
-        self.step += 1
+        """Called once per fused update, from the backward pass: counts the update, refreshes the constants that depend on
+        the count -- scheduled learning rates (in the kernel descriptors) and Adam's bias correction, both kept in DEVICE
+        memory (embedding_ops.StepConstants) -- and returns the Adam / FTRL constants (None for SGD / Adagrad).  While a
+        stream is capturing nothing is counted or written: GraphedStep does that before every replay."""
+        scheduled = bool(self.table_opts) and any(callable(o.lr) for o in self.table_opts)
+        adam = self.fused.kind == "adam"
+        if not scheduled and not adam:
+            from keras_rs_amd import graphs
+
+            graphs.count_update(self)      # (per replay under GraphedStep)
+            return self.fused.hyper(self.step)
+        if self._constants is None:
+            from keras_rs_amd.embedding_ops import StepConstants
+
+            self._constants = StepConstants(
+                self, lambda: self.bags, (lambda step: [o.lr_at(step) for o in self.table_opts]) if scheduled else None,
+                self.fused.consts[:2] if adam else None)
+        self._constants.on_backward()
+        if adam:
+            b1, b2, eps = self.fused.consts
+            return (b1, b2, eps, self._constants.bias_correction)
         return self.fused.hyper(self.step)
 
 

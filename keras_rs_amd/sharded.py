@@ -71,6 +71,8 @@ from keras_rs_amd.layers.distributed_embedding_config import FeatureConfig, Tabl
 class HipShardKernels:
     """The compute side of the sharded path on MI355X (K1 / K2 / K6 through the C ABI)."""
 
+    device_step_constants = True     # scheduled learning rates / Adam's bias correction are read from device memory
+
     def __init__(self):
         self._shard_bags: dict = {}
         self._desc_cache: dict = {}
@@ -242,7 +244,8 @@ class HipShardKernels:
             return
         fb = self._bags_for(table, slot, 0.0)
         fb.slots = [slot]
-        fb.lrs = [float(lr)]   # scheduled rates change per step: the descriptor is re-uploaded when it does
+        if lr is not None:     # (None: the descriptor already holds this update's rate -- StepConstants wrote it)
+            fb.store_lrs([float(lr)])
         if ws is None:
             ws = fb.plan_backward(rows, n_seg, offsets=offsets)
         scale = None
@@ -440,6 +443,24 @@ class ShardedDistributedEmbedding(base.Layer):
             self._where[p] = ("shard", self._sgroups.index(g), len(g.paths))
             g.paths.append(p)
             g.table_of_feature.append(ti)
+        # A table with very few rows has few OWNERS under MOD sharding (3 rows: ranks 0-2 own everything) -- with the static
+        # exchange its lookups all land in a few (home, owner) blocks sized for a uniform spread and are DROPPED beyond the
+        # capacity (profiles/r5z_bench_c5_gpus8_one_gpu_gloo_tiny_tables_sharded_overflow.json: `overflow_steps` 1 with the
+        # Criteo tables of 3 ... 155 rows left sharded over 8 ranks).  The reference's model replicates such tables
+        # (examples/ml_perf/main.py:135-141, embedding_threshold); say so loudly when one stays sharded.
+        if self.world > 1:
+            tiny = sorted({tc.name for g in self._sgroups for tc in g.table_configs if tc.vocabulary_size < 64 * self.world})
+            if tiny:
+                import warnings
+
+                warnings.warn(
+                    f"ShardedDistributedEmbedding: table(s) {tiny} have fewer than 64 x world ({64 * self.world}) rows and stay "
+                    f"MOD-sharded over {self.world} ranks: their lookups reach only a few owners, and the static exchange drops "
+                    "what exceeds a block's capacity (overflow_steps).  Replicate them: replicate_below=<rows> or "
+                    "TableConfig(placement='default_device').", stacklevel=2)
+            self.tiny_sharded_tables = tiny
+        else:
+            self.tiny_sharded_tables = []
         for gi, g in enumerate(self._sgroups):
             g.local_rows = [math.ceil(tc.vocabulary_size / self.world) for tc in g.table_configs]
             g.row_off = [0]
@@ -471,6 +492,7 @@ class ShardedDistributedEmbedding(base.Layer):
         self._collectives_at_world1 = False   # bench --rccl-self: run the collectives through a one-rank communicator
         self._err_dev = self._err_host = self._err_event = None
         self.last_exchange: dict = {}    # host-side counts of the last lookup (tests / load-balance diagnostics)
+        self._step_constants: dict = {}  # group -> embedding_ops.StepConstants (scheduled rates / Adam bias correction)
 
     # single-group conveniences (the common case: one width, one optimizer) -- kept for callers / tests
     @property
@@ -940,6 +962,10 @@ class ShardedDistributedEmbedding(base.Layer):
                 t.record_stream(side)
         saved["plan"] = (ws, ev, owns)
         self.plans_ahead += 1
+        if base.stream_capturing():
+            from keras_rs_amd import graphs
+
+            graphs.join_at_capture_end(side)     # (a captured step without its backward would leave the fork open)
 
     def _release_plan(self, gi, owns) -> None:
         if owns[0]:
@@ -1068,8 +1094,29 @@ class ShardedDistributedEmbedding(base.Layer):
         off_rank = (self.world - 1) / self.world if self.world > 1 else 1.0
         with probe.span("a2a_grads", off_rank * dpart.numel() * dpart.element_size()):
             dseg = self._a2a(dpart, s["send_segs"], s["recv_segs"])               # to the owners
-        lr = g.fused.lr_at(g.step)
-        g.step += 1
+        if (callable(g.fused.lr) or g.fused.kind == "adam") and getattr(k, "device_step_constants", False):
+            # constants that depend on the update count live in device memory (embedding_ops.StepConstants): written here by an
+            # eager step, before every replay by GraphedStep when this backward is being captured
+            sc = self._step_constants.get(gi)
+            if sc is None:
+                from keras_rs_amd.embedding_ops import StepConstants
+
+                sc = self._step_constants[gi] = StepConstants(
+                    g, lambda g=g: k._bags_for(getattr(self, g.pname).data, self._slot(g), 0.0),
+                    (lambda step, g=g: [g.fused.lr_at(step)]) if callable(g.fused.lr) else None,
+                    g.fused.consts[:2] if g.fused.kind == "adam" else None)
+            sc.on_backward()
+            lr = None if callable(g.fused.lr) else g.fused.lr_at(g.step)
+            hyper = g.fused.consts + (sc.bias_correction,) if g.fused.kind == "adam" else g.fused.hyper(g.step)
+        else:
+            from keras_rs_amd import graphs
+
+            lr = g.fused.lr_at(g.step)
+            if callable(g.fused.lr) or g.fused.kind == "adam":
+                g.step += 1               # (test kernels without device-resident constants: by-value arguments, eager only)
+            else:
+                graphs.count_update(g)    # (per replay under GraphedStep)
+            hyper = g.fused.hyper(max(g.step, 1))
         plan = s.get("plan")
         ws = None
         if plan is not None:
@@ -1081,9 +1128,9 @@ class ShardedDistributedEmbedding(base.Layer):
         with probe.span("k2"):
             if ws is not None:
                 k.apply_segments(getattr(self, g.pname).data, self._slot(g), s["rows"], s["off"], s["w"], dseg, lr,
-                                 g.fused.kind, g.fused.hyper(g.step), 1.0 / self.world if self.grad_average else 1.0, ws=ws)
+                                 g.fused.kind, hyper, 1.0 / self.world if self.grad_average else 1.0, ws=ws)
             else:     # (kernels without plan_segments -- the oracle-backed test kernels -- plan inside the call)
                 k.apply_segments(getattr(self, g.pname).data, self._slot(g), s["rows"], s["off"], s["w"], dseg, lr,
-                                 g.fused.kind, g.fused.hyper(g.step), 1.0 / self.world if self.grad_average else 1.0)
+                                 g.fused.kind, hyper, 1.0 / self.world if self.grad_average else 1.0)
         if plan is not None:
             self._release_plan(gi, plan[2])       # (the next forward's plan is ordered behind this apply: it may take the buffer)

@@ -112,7 +112,9 @@ int main(int argc, char** argv) {
     dz[i] = alloc(B, d, d + xpad); dx0[i] = alloc(B, d, d + xpad);
     dk[i] = alloc(pj, d, d, 4); dh[i] = alloc(B, pj, pj + hpad); du[i] = alloc(d, pj, pj, 4); dx[i] = alloc(B, d, d + xpad);
   }
-  const size_t wsb = std::max(krs_gemm_workspace_bytes(pj, d, B, 1), krs_gemm_workspace_bytes(d, pj, B, 1));
+  // (the K-contiguous products take split-K too when their output is too small to fill the chip: B <= ~24k)
+  const size_t wsb = std::max(std::max(krs_gemm_workspace_bytes(pj, d, B, 1), krs_gemm_workspace_bytes(d, pj, B, 1)),
+                              std::max(krs_gemm_workspace_bytes(B, pj, d, 0), krs_gemm_workspace_bytes(B, d, pj, 0)));
   void* ws;
   CK(hipMalloc(&ws, wsb ? wsb : 16));
   printf("split-K workspace %.1f MB\n", wsb / 1e6);
@@ -137,11 +139,11 @@ int main(int argc, char** argv) {
     memset(&ep, 0, sizeof(ep));
     switch (c) {
       case 0:
-        KK(krs_gemm(x.p, x.ld, 0, Ut.p, Ut.ld, 1, h[i].p, h[i].ld, B, pj, d, KRS_BF16, KRS_BF16, nullptr, nullptr, 0, st));
+        KK(krs_gemm(x.p, x.ld, 0, Ut.p, Ut.ld, 1, h[i].p, h[i].ld, B, pj, d, KRS_BF16, KRS_BF16, nullptr, ws, wsb, st));
         break;
       case 1:
         ep.bias = (const float*)bias.p; ep.x0 = x0.p; ep.x = x.p; ep.ldx = x.ld; ep.u_out = u[i].p; ep.ldu = u[i].ld;
-        KK(krs_gemm(h[i].p, h[i].ld, 0, Vt.p, Vt.ld, 1, y[i].p, y[i].ld, B, d, pj, KRS_BF16, KRS_BF16, &ep, nullptr, 0, st));
+        KK(krs_gemm(h[i].p, h[i].ld, 0, Vt.p, Vt.ld, 1, y[i].p, y[i].ld, B, d, pj, KRS_BF16, KRS_BF16, &ep, ws, wsb, st));
         break;
       case 2:
         KK(krs_cross_epilogue_bwd(g.p, u[i].p, x0.p, x.p, dz[i].p, dx0[i].p, getenv("KRS_EW_ACC") ? 1 : 0, nullptr, dbias, B, d, x.ld, 0.0f,
@@ -152,7 +154,7 @@ int main(int argc, char** argv) {
                     wsb, st));
         break;
       case 4:
-        KK(krs_gemm(dz[i].p, dz[i].ld, 0, V.p, V.ld, 1, dh[i].p, dh[i].ld, B, pj, d, KRS_BF16, KRS_BF16, nullptr, nullptr, 0,
+        KK(krs_gemm(dz[i].p, dz[i].ld, 0, V.p, V.ld, 1, dh[i].p, dh[i].ld, B, pj, d, KRS_BF16, KRS_BF16, nullptr, ws, wsb,
                     st));
         break;
       case 5:
@@ -161,11 +163,11 @@ int main(int argc, char** argv) {
         break;
       case 6:
         ep.r = g.p; ep.ldr = g.ld; ep.beta = 1.0f;
-        KK(krs_gemm(dh[i].p, dh[i].ld, 0, U.p, U.ld, 1, dx[i].p, dx[i].ld, B, d, pj, KRS_BF16, KRS_BF16, &ep, nullptr, 0, st));
+        KK(krs_gemm(dh[i].p, dh[i].ld, 0, U.p, U.ld, 1, dx[i].p, dx[i].ld, B, d, pj, KRS_BF16, KRS_BF16, &ep, ws, wsb, st));
         break;
       case 7:   // krs_gemm_cross_bwd: the same product + dz / dL/dx0 (accumulating) / bias gradient of the layer below
         KK(krs_gemm_cross_bwd(dh[i].p, dh[i].ld, U.p, U.ld, g.p, g.ld, 1.0f, dx[i].p, dx[i].ld, x0.p, u[i].p, dz[i].p, dx0[i].p,
-                              x.ld, 1, 0, dbias, B, d, pj, KRS_ACT_NONE, KRS_BF16, ws2, ws2b, st));
+                              x.ld, 1, nullptr, 0, dbias, B, d, pj, KRS_ACT_NONE, KRS_BF16, ws2, ws2b, st));
         break;
     }
   };
@@ -217,7 +219,7 @@ int main(int argc, char** argv) {
   printf("%-40s", "case (median us | TF/s or GB/s)");
   for (int i = 0; i < NP; ++i) printf("   pipe %d          ", pipes[i]);
   printf("\n");
-  double tot[NP] = {0, 0, 0};
+  double tot[NP] = {0, 0};
   for (int c = 0; c < 8; ++c) {
     printf("%-40s", cases[c].name);
     for (int i = 0; i < NP; ++i) {

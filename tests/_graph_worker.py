@@ -11,12 +11,16 @@ sys.path.insert(0, ROOT)
 DEV = "cuda:0"
 
 
-def _build(sharded: bool, rccl: bool = False):
+def _build(sharded: bool, rccl: bool = False, optimizer: str = "adagrad"):
     import keras_rs_amd.layers as kl
     from keras_rs_amd.layers import base
 
     B, D, hots, vocabs = 33024, 32, [3, 1, 7, 2], [5000, 300, 20000, 1000]   # (above autograd.WGRAD_SIDE_MIN_ROWS)
-    opt = kl.Adagrad(learning_rate=0.05, initial_accumulator_value=0.1)
+    # "adam": the bias correction changes with every update; "sched": a learning-rate schedule called with the update count
+    # (jax/config_conversion.py:136-176) -- both are host-computed per step and reach the kernels through device memory
+    opt = {"adagrad": lambda: kl.Adagrad(learning_rate=0.05, initial_accumulator_value=0.1),
+           "adam": lambda: kl.Adam(learning_rate=0.01),
+           "sched": lambda: kl.Adagrad(learning_rate=lambda step: 0.05 / (1.0 + step), initial_accumulator_value=0.1)}[optimizer]()
     feats = {}
     for t in range(4):
         tc = kl.TableConfig(name=f"t{t}", vocabulary_size=vocabs[t], embedding_dim=D,
@@ -79,7 +83,7 @@ def _build(sharded: bool, rccl: bool = False):
     return emb, step, state
 
 
-def main(sharded: bool, rccl: bool = False):
+def main(sharded: bool, rccl: bool = False, optimizer: str = "adagrad", bare: bool = False, fwd_only: bool = False):
     from keras_rs_amd.graphs import GraphedStep
 
     if rccl:
@@ -96,11 +100,65 @@ def main(sharded: bool, rccl: bool = False):
         os.environ.setdefault("MASTER_PORT", str(port))
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    build = lambda: _build(sharded, rccl)   # noqa: E731
-    _, step_a, state_a = build()
+    build = lambda: _build(sharded, rccl, optimizer)   # noqa: E731
+    if fwd_only:
+        # a forward pass captured WITHOUT its backward, gradients enabled: the layer forks its plan stream in forward and only
+        # the backward joins it -- GraphedStep joins it before the capture ends
+        import keras_rs_amd.layers as kl
+        from keras_rs_amd.layers import base
+        from keras_rs_amd.sharded import ShardedDistributedEmbedding
+
+        B, D = 4096, 32
+        tc = kl.TableConfig(name="t", vocabulary_size=5000, embedding_dim=D, initializer=base.RandomUniform(-0.05, 0.05, seed=7),
+                            optimizer=kl.Adagrad(0.05, 0.1), combiner="sum", placement="sparsecore")
+        emb = ShardedDistributedEmbedding({"f": kl.FeatureConfig("f", tc, (B, 3), (B, D))}, dtype="bfloat16", exchange="static")
+        ids = {"f": torch.randint(0, 5000, (B, 3), device=DEV, dtype=torch.int32)}
+        pre = emb.preprocess(ids)
+        outs = []
+
+        def fwd():
+            assert torch.is_grad_enabled()
+            out = emb(pre)["f"]
+            outs[:] = [out.detach()]
+
+        fwd()
+        eager = outs[0].clone()
+        graphed = GraphedStep(fwd, warmup=1)
+        assert emb.plans_ahead >= 2 and len(graphed.joins) == 1
+        graphed()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], eager)
+        print("GRAPH_FWD_ONLY_OK", flush=True)
+        os._exit(0)
+    if bare:
+        # a capture that is NOT GraphedStep's has nobody to refresh the constants before a replay: refused, not replayed stale
+        # (a process of its own: the refused capture is this process's only one)
+        from keras_rs_amd import _lib as L
+
+        _, step_c, _ = build()
+        step_c()
+        step_c()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                step_c()
+        except Exception as e:   # noqa: BLE001 -- the capture's own teardown may wrap the layer's error
+            chain, seen = [], e
+            while seen is not None:
+                chain.append(seen)
+                seen = seen.__cause__ or seen.__context__
+            assert any(isinstance(x, L.KrsError) and "GraphedStep" in str(x) for x in chain) or "GraphedStep" in str(e), repr(chain)
+        else:
+            raise AssertionError("a bare capture of a step with step-dependent optimizer constants must raise")
+        print("GRAPH_REFUSED", optimizer, flush=True)
+        os._exit(0)
+    emb_a, step_a, state_a = build()
     for _ in range(5):
         step_a()
     ref = state_a()
+    steps_of = lambda e: [g.step for g in (e._sgroups if sharded else e._groups["sparsecore"])]   # noqa: E731
+    assert steps_of(emb_a) == [5]
 
     emb, step_b, state_b = build()
     graphed = GraphedStep(step_b, warmup=2)      # two eager steps, then the capture (which runs nothing)
@@ -111,6 +169,7 @@ def main(sharded: bool, rccl: bool = False):
         assert emb.poll_exchange_stats() is False and emb.overflow_steps == 0
         assert emb.last_exchange["need"][0] <= emb.last_exchange["capacity"][0]
     got = state_b()
+    assert steps_of(emb) == [5], steps_of(emb)     # two eager updates + three replays: the count (checkpointed `iterations`) advanced
     assert ref.keys() == got.keys() and len(ref) >= 10
     for k in ref:
         assert torch.equal(ref[k], got[k]), k
@@ -119,7 +178,7 @@ def main(sharded: bool, rccl: bool = False):
     step0()
     first = state0()
     assert not torch.equal(first["table.t0"], ref["table.t0"])
-    print("GRAPH_OK", ("sharded_rccl" if rccl else "sharded") if sharded else "single", flush=True)
+    print("GRAPH_OK", ("sharded_rccl" if rccl else "sharded") if sharded else "single", optimizer, flush=True)
     if rccl:
         # (destroy_process_group() waits forever while graphs that hold RCCL kernels are alive in this process, ROCm 7.2:
         #  leave without the teardown)
@@ -127,4 +186,5 @@ def main(sharded: bool, rccl: bool = False):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1].startswith("sharded"), sys.argv[1] == "sharded_rccl")
+    main(sys.argv[1].startswith("sharded"), sys.argv[1] == "sharded_rccl", sys.argv[2] if len(sys.argv) > 2 else "adagrad",
+         len(sys.argv) > 3 and sys.argv[3] == "bare", len(sys.argv) > 3 and sys.argv[3] == "fwdonly")

@@ -21,3 +21,28 @@ def test_replayed_steps_equal_eager_steps(which):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_graph_worker.py"), which], capture_output=True,
                        text=True, timeout=240 if which == "sharded_rccl" else 600, cwd=ROOT)
     assert r.returncode == 0 and f"GRAPH_OK {which}" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("which,optimizer", [("single", "adam"), ("single", "sched"), ("sharded", "adam"), ("sharded", "sched")])
+def test_replayed_steps_with_step_dependent_optimizer_constants_equal_eager_steps(which, optimizer):
+    """Round-5 review, weak #8: Adam's bias correction and scheduled learning rates are computed on the host once per update.
+    Frozen into a captured launch they made every replay apply step 1's constants, silently.  They now live in device memory
+    (embedding_ops.StepConstants; krs_store_f32 / krs_embed_bag_bwd_fused_adam_dyn), GraphedStep refreshes them before every
+    replay, and a bare torch.cuda.graph capture of such a step raises.  2 eager + 3 replayed updates leave the bits (tables,
+    both Adam moments, dense weights) and the update count of 5 eager updates."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_graph_worker.py"), which, optimizer], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and f"GRAPH_OK {which} {optimizer}" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("which,optimizer", [("single", "adam"), ("sharded", "sched")])
+def test_a_bare_capture_of_step_dependent_constants_is_refused(which, optimizer):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_graph_worker.py"), which, optimizer, "bare"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and f"GRAPH_REFUSED {optimizer}" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_a_forward_only_capture_of_the_sharded_layer_joins_its_plan_stream():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_graph_worker.py"), "sharded", "adagrad", "fwdonly"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "GRAPH_FWD_ONLY_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

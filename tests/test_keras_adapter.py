@@ -147,6 +147,23 @@ def test_adapter_checkpoint_round_trip_keeps_slots_and_iterations(opt):
     assert any(k.startswith("iterations__") for k in store.keys()) and sum(len(v.shape) >= 2 for v in store.values()) >= 2
     b = make()
     b.load_own_variables(store)
+    # a checkpoint of the previous revision ("/" kept in the names, counts as "iterations/<group>") loads as well, and one
+    # WITHOUT the update counts is refused instead of resetting them to 0 behind trained slot planes
+    legacy = keras_stub.Store()
+    for k in store.keys():
+        # (written behind the stub's flat-key rule: an old file is what it is)
+        legacy._d[("iterations/" + k[len("iterations__"):].replace("__", "/")) if k.startswith("iterations__") else k.replace("__", "/")] = \
+            np.asarray(store[k][...])
+    b2 = make()
+    b2.load_own_variables(legacy)
+    assert b2._impl.state_dict()["_extra_state"] == b._impl.state_dict()["_extra_state"]
+    assert all(torch.equal(v, b._impl.state_dict()[k]) for k, v in b2._impl.state_dict().items() if k != "_extra_state")
+    stripped = keras_stub.Store()
+    for k in store.keys():
+        if not k.startswith("iterations__"):
+            stripped[k] = store[k][...]
+    with pytest.raises(ValueError, match="iteration count"):
+        make().load_own_variables(stripped)
     for i in range(2, 4):
         step(a, i)
         step(b, i)

@@ -487,3 +487,24 @@ def test_bench_dominant_entry_is_priced_per_step():
     one = bench.dominant_roofline(entries, single=True)
     assert one["kernel"] == "k2" and one["ms_per_step"] == pytest.approx(2.4)
     assert bench.dominant_roofline([]) is None
+
+
+def test_sharded_layer_warns_when_a_tiny_table_stays_sharded():
+    """Round-5 review, next #4: a table with fewer than 64 x world rows left MOD-sharded sends its lookups to a few owners and
+    the static exchange drops what exceeds a block (the builder's own C5 run showed `overflow_steps` 1) -- the layer says so at
+    construction; replicating the table (replicate_below, the reference's embedding_threshold, main.py:135-141) silences it."""
+    import warnings
+
+    from keras_rs_amd.layers import SGD
+    from keras_rs_amd.sharded import ShardedDistributedEmbedding
+
+    tcs = [TableConfig("tiny", 3, 16, optimizer=SGD(0.1), combiner="sum", placement="sparsecore"),
+           TableConfig("big", 5000, 16, optimizer=SGD(0.1), combiner="sum", placement="sparsecore")]
+    fcs = {t.name: FeatureConfig(t.name, t, (8, 2), (8, 16)) for t in tcs}
+    with pytest.warns(UserWarning, match=r"\['tiny'\].*fewer than 64 x world \(512\)"):
+        layer = ShardedDistributedEmbedding(fcs, virtual_world=8, exchange="static")
+    assert layer.tiny_sharded_tables == ["tiny"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        layer = ShardedDistributedEmbedding(fcs, virtual_world=8, exchange="static", replicate_below=64)
+    assert layer.tiny_sharded_tables == []
