@@ -347,7 +347,9 @@ int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, int64_t ldb,
  *   KRS_GEMM_OPT_PIPELINE: 4 = the big bf16 shapes run the four-stage ping-pong ring on 256x256 tiles (default, or
  *   the environment variable KRS_GEMM_PIPE at first use); 0 = every shape runs the two-stage 128x128 kernels and
  *   krs_gemm_cross_bwd its two-call form -- the reference schedule of the bit-for-bit tests and A/B harnesses.
- *   (Rounds 2-4 also had 5 / 6 / 7: a five-stage ring, a prefetch schedule, a deep ring on 128x128 tiles; measured no
+ *   5 = the 32-k ring (gemm_pp256_kernel) also for the K-contiguous products that take the 64-k ring (gemm_pp64_kernel) by
+ *   default: the A/B switch of round 6.
+ *   (Rounds 2-4 used 5 / 6 / 7 for a five-stage ring, a prefetch schedule and a deep ring on 128x128 tiles; measured no
  *   faster and deleted in round 5.) */
 enum { KRS_GEMM_OPT_PIPELINE = 0 };
 int krs_gemm_set_option(int key, int value);

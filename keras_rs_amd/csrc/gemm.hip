@@ -10,7 +10,12 @@
 // the layer needs (forward, data gradient, weight gradient).  MFMA throughout:
 // v_mfma_f32_32x32x16_bf16 (bf16) / v_mfma_f32_32x32x2_f32 (fp32, exact fmaf chain), fp32
 // accumulators in registers, a lane's operand = 16 bytes of LDS.  Kernels, by shape:
-//   * gemm_pp256_kernel     what the big bf16 shapes dispatch to (both operand layouts): the 256x256 tile (8 waves as
+//   * gemm_pp64_kernel      (round 6) the big K-contiguous bf16 products -- h = x U, dh = dz K^T, the cross / residual /
+//                           fused-backward forms -- whenever K is whole 64-k blocks: gemm_pp256_kernel's tile and ping-pong
+//                           on 64-k pieces whose rows are whole 128-byte lines, five 32 KB slots, the LDS-DMA instructions
+//                           issued among the MFMAs (h 204 -> 189 us, dh 214 -> 193, cross product 455 -> 430; bit-identical);
+//   * gemm_pp256_kernel     the weight gradients (K-strided operands) and the K-contiguous shapes gemm_pp64_kernel does not
+//                           take: the 256x256 tile (8 waves as
 //                           2(M) x 4(N), 128x64 per wave) on a four-stage LDS-DMA ring (global_load_lds, XOR swizzle on
 //                           the source side), ping-pong wave groups, counted vmcnt, epilogue operands fetched under the
 //                           tail of the main loop; bit-identical to the 128x128 two-stage kernels below, which every
@@ -933,6 +938,9 @@ __device__ __forceinline__ void pp_vmcnt() {
 //  shapes of a strongly-scaled job; it measured equal or slower than gemm_glds_kernel (47.2 against 44.9 us at M = 8192,
 //  profiles/r4_gemm_ring128_b8192.txt: one 128x128 tile per CU already draws the ~40 GB/s per CU of the L2 -> LDS path) and
 //  was deleted in round 5.)
+// The steady state's LDS-DMA instructions are issued INSIDE the compute segment, behind its 2nd and 5th MFMA, not in the load
+// segment (round 6: the load segment -- six fragment reads + two DMA instructions at 60-185 cycles each -- was the longer
+// of the two and set the phase length; weight gradients 215 -> 212 us, profiles/r6_gemm_k64_dma_in_compute_ab.txt)
 template <bool TN, int NSTG, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int mt, int nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1019,6 +1027,15 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
       bp[i] += bstep;
     }
   };
+  auto issue_one = [&](bool is_a, int stage, int i) {
+    if (is_a) {
+      __builtin_amdgcn_global_load_lds((gptr)ap[i], (lptr)(smem + stage * pp::STAGE + dma_off + i * 1024), 16, 0, 0);
+      ap[i] += astep;
+    } else {
+      __builtin_amdgcn_global_load_lds((gptr)bp[i], (lptr)(smem + stage * pp::STAGE + pp::PIECE + dma_off + i * 1024), 16, 0, 0);
+      bp[i] += bstep;
+    }
+  };
 
   // fragment addresses inside a stage (phase hk = 1: ^ 32 for the K-contiguous image, + 4096 for the other)
   int a_lane, b_lane;
@@ -1086,6 +1103,20 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
       }
     __builtin_amdgcn_s_setprio(0);
   };
+  auto mfma8_dma = [&](const u32x4(&fa)[4], const u32x4(&fb)[2], bool is_a, int stage) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16& d = acc[i >> 1][i & 1][j];
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), d, 0,
+                                                   0, 0);
+        if (i * 2 + j == 1) { __builtin_amdgcn_sched_barrier(0); issue_one(is_a, stage, 0); __builtin_amdgcn_sched_barrier(0); }
+        if (i * 2 + j == 4) { __builtin_amdgcn_sched_barrier(0); issue_one(is_a, stage, 1); __builtin_amdgcn_sched_barrier(0); }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
 
   {
     // prologue (the host guarantees nkb >= NSTG): A(0), B(0), ..., A(NSTG-3), B(NSTG-3), A(NSTG-2)
@@ -1112,19 +1143,16 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
       u32x4 fa[4], fb[2];
       // ---- phase 2kb ----
       load_frags(rd, 0, fa, fb);
-      issue_b(wb);   // (the piece in FRONT of the fragment reads: 227 / 241 us against 204 / 210, K-contiguous / K-strided;
-                     //  its second instruction moved behind the second MFMA of the compute segment: equal)
       pp_barrier();
       if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
-      mfma8(fa, fb);
+      mfma8_dma(fa, fb, false, wb);
       pp_barrier();
       // ---- phase 2kb+1 ----
       load_frags(rd, 1, fa, fb);
-      issue_a(wa);
-      pp_vmcnt<STEADY>();
+      pp_vmcnt<STEADY - 2>();    // (this phase's piece is issued behind the wait, among the MFMAs)
       pp_barrier();
       if constexpr (TN) pp_lgkm_wait<0>(fa, fb);
-      mfma8(fa, fb);
+      mfma8_dma(fa, fb, true, wa);
       pp_barrier();
       advance();
     }
@@ -1165,6 +1193,201 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   if constexpr (EPI >= 3) {   // 3: + R, 4: + R, dx0 accumulates, 5: no R, 6: no R, dx0 accumulates, 7: + R, dx0 = R u_upper + ...,
                               // 8: no R, no dx0
+    gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : (EPI == 8 ? 3 : 0)), EPI == 3 || EPI == 4 || EPI == 7>(
+        p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
+    return;
+  }
+  if constexpr (NPFC > 0)
+    gemm_epilogue_wave128_pre<EPI, NPFC>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split, opf);
+  else
+    gemm_epilogue_wave128<EPI>(p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, split);
+}
+
+// ---- gemm_pp64_kernel: the ring on 64-k blocks with WHOLE 128-byte lines per LDS-DMA row (round 6) --------------------------
+// Same tile (256 x 256, eight waves as 2 x 4, 128 x 64 per wave, v_mfma_f32_32x32x16_bf16), same ping-pong of the two wave
+// groups, same k order per accumulator (bit-identical to gemm_pp256_kernel) -- what changes is the operand stream: a piece is
+// 256 rows x 64 k = 32 KB and every row of it is one whole 128-byte line (gemm_pp256_kernel's 32-k pieces fetch each line of
+// A / B in two 64-byte halves, one K block apart: twice the requests on the per-CU L2 -> LDS path, which is what bounds the long-K
+// products -- 1920 cycles per 32-k block against 1024 of MFMA; scripts/exp/gemm_probe3 measured the stream alone at 137 us with
+// whole lines against 174).
+//   LDS: FIVE 32 KB slots (160 KB, the whole CU), piece i (A of block kb = 2 kb, B = 2 kb + 1) in slot i % 5: while block kb
+//   is read from two slots, pieces 2kb+2 .. 2kb+4 are landed / in flight in the other three.  Block kb issues piece 2kb+3 in its
+//   phases 0, 1 and piece 2kb+4 in its phases 2, 3 (two instructions per wave per phase, as the 32-k ring); the slot of 2kb+3 held
+//   A(kb-1), read last in phase 3 of block kb-1 -- that phase waits for its fragment reads before its first barrier, so the
+//   restage is ordered behind them by a barrier whichever wave group issues it.  One counted wait per block (phase 3: vmcnt(4) =
+//   piece 2kb+4 may stay in flight), the reads of block kb+1 come a phase later.
+//   Row image: 128-byte pitch, 16-byte chunk c of row r at physical chunk c ^ ((r >> 1) & 7): the four 16-lane groups of a
+//   ds_read_b128 (rows {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, +32) then cover the sixteen slots of the 256-byte bank row once.
+//   The DMA writes lanes linearly (8 lanes = one row), so the swizzle is applied to the SOURCE chunk: the eight lanes of a row
+//   still fetch one whole line.
+namespace pp64 {
+constexpr int SLOT = 32768;
+constexpr int NSLOT = 5;
+}  // namespace pp64
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp64_kernel(const GemmParams p, int nt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = 256, TN_ = 256;
+  typedef const __attribute__((address_space(1))) void* gptr;
+  typedef __attribute__((address_space(3))) void* lptr;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2;
+  const int wm = grp, wn = wave & 3;
+  const int64_t xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  // (work-item order of gemm_pp256_kernel's K-contiguous form: the N tiles of an M panel, and the K splits of a tile, are
+  //  neighbours on one XCD)
+  const int64_t tslot = slot_id / p.splits;
+  const int split = (int)(slot_id - tslot * p.splits);
+  const int64_t m_tile = (tslot / nt) * 8 + xcd;
+  if (m_tile * TM >= p.m) return;
+  const int64_t m0 = m_tile * TM, n0 = (tslot % nt) * TN_;
+  const int64_t kbeg = (int64_t)split * p.k_per_split;
+  const int64_t nb = (min(p.k, kbeg + p.k_per_split) - kbeg) / 64;     // 64-k blocks (the host guarantees >= 3, whole)
+
+  // DMA sources: instruction q = wave*4 + i fills rows q*8 .. q*8+7 of a piece, lane = row*8 + physical chunk
+  const char* ap[4];
+  const char* bp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    ap[i] = p.a + (min(m0 + r, p.m - 1) * p.lda + kbeg) * 2 + c * 16;
+    bp[i] = p.b + (min(n0 + r, p.n - 1) * p.ldb + kbeg) * 2 + c * 16;
+  }
+  const int dma_off = wave * 4096;      // + i*1024
+  auto issue_one = [&](const char* (&src)[4], int slot, int i) {
+    __builtin_amdgcn_global_load_lds((gptr)src[i], (lptr)(smem + slot * pp64::SLOT + dma_off + i * 1024), 16, 0, 0);
+    src[i] += 128;
+  };
+  auto issue_half = [&](const char* (&src)[4], int slot, int half) {
+    issue_one(src, slot, half * 2);
+    issue_one(src, slot, half * 2 + 1);
+  };
+  // fragment addresses inside a slot (sub-phase hk: ^ hk*32)
+  const int frow = lane & 31, fhalf = lane >> 5, key = (frow >> 1) & 7;
+  const int a_lane = (wm * 128 + frow) * 128 + ((fhalf ^ key) << 4);
+  const int b_lane = (wn * 64 + frow) * 128 + ((fhalf ^ key) << 4);
+  auto load_frags = [&](int sa, int sb, int hk, u32x4(&fa)[4], u32x4(&fb)[2]) {
+    const char* pa = smem + sa * pp64::SLOT;
+    const char* pb = smem + sb * pp64::SLOT;
+    const int x = hk * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const u32x4*>(pb + (b_lane ^ x) + j * 4096);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(pa + (a_lane ^ x) + i * 4096);
+  };
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
+  constexpr int NPFC = EPI == 2 ? 4 : EPI == 1 ? 2 : 0;
+  constexpr int NPF = NPFC * (EPI == 1 ? 8 : 4);
+  EpiOperands opf[4];
+  auto mfma8 = [&](const u32x4(&fa)[4], const u32x4(&fb)[2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16& d = acc[i >> 1][i & 1][j];
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), d, 0,
+                                                   0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // the compute segment with the two LDS-DMA instructions of this phase's half piece (`src` / `slot`) behind its 2nd and 5th
+  // MFMA: in the load segment they (60-185 cycles each) made it the longer of the two segments -- h = x U 195 -> 189 us, the
+  // cross product 440 -> 430; where among the MFMAs they sit does not matter (profiles/r6_gemm_k64_dma_in_compute_ab.txt)
+  auto mfma8_dma = [&](const u32x4(&fa)[4], const u32x4(&fb)[2], const char* (&src)[4], int slot, int half) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16& d = acc[i >> 1][i & 1][j];
+        d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), d, 0,
+                                                   0, 0);
+        if (i * 2 + j == 1) { __builtin_amdgcn_sched_barrier(0); issue_one(src, slot, half * 2); __builtin_amdgcn_sched_barrier(0); }
+        if (i * 2 + j == 4) { __builtin_amdgcn_sched_barrier(0); issue_one(src, slot, half * 2 + 1); __builtin_amdgcn_sched_barrier(0); }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // one phase of a block that issues half a piece
+  auto phase = [&](int sa, int sb, int hk, const char* (&src)[4], int slot, int half, bool last_of_block) {
+    u32x4 fa[4], fb[2];
+    load_frags(sa, sb, hk, fa, fb);
+    if (last_of_block) {
+      // pieces 2kb+2, 2kb+3 have landed (read from the next phase on); the first half of piece 2kb+4 may stay in flight (its
+      // second half is issued behind this wait)
+      pp_vmcnt<2>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this block's last reads are done before the barrier: its A slot is restaged next
+    }
+    pp_barrier();
+    mfma8_dma(fa, fb, src, slot, half);
+    pp_barrier();
+  };
+  auto step5 = [](int v, int by) { v += by; return v >= pp64::NSLOT ? v - pp64::NSLOT : v; };
+
+  {
+    // prologue: pieces 0 (A0), 1 (B0), 2 (A1) whole; blocks 0's operands must have landed, piece 2 may fly on
+    issue_half(ap, 0, 0); issue_half(ap, 0, 1);
+    issue_half(bp, 1, 0); issue_half(bp, 1, 1);
+    issue_half(ap, 2, 0); issue_half(ap, 2, 1);
+    pp_vmcnt<4>();
+    pp_barrier();
+    if (grp == 1) pp_barrier();  // rows 128..255 run one segment behind rows 0..127
+    int sa = 0, sb = 1, s3 = 3, s4 = 4;   // slots of pieces 2kb, 2kb+1, 2kb+3, 2kb+4
+    int64_t kb = 0;
+    for (; kb + 2 < nb; ++kb) {   // steady state: pieces 2kb+3 (B of kb+1) and 2kb+4 (A of kb+2) are issued
+      phase(sa, sb, 0, bp, s3, 0, false);
+      phase(sa, sb, 1, bp, s3, 1, false);
+      phase(sa, sb, 2, ap, s4, 0, false);
+      phase(sa, sb, 3, ap, s4, 1, true);
+      sa = step5(sa, 2); sb = step5(sb, 2); s3 = step5(s3, 2); s4 = step5(s4, 2);
+    }
+    // block nb-2: only B(nb-1) = piece 2kb+3 is left to issue; the epilogue's operands are requested behind it
+    {
+      phase(sa, sb, 0, bp, s3, 0, false);
+      phase(sa, sb, 1, bp, s3, 1, false);
+      u32x4 fa[4], fb[2];
+      load_frags(sa, sb, 2, fa, fb);
+      if constexpr (NPFC > 0) {
+#pragma unroll
+        for (int c = 0; c < NPFC; ++c) epi_prefetch<EPI>(p, opf[c], m0 + wm * 128 + c * 32, n0 + wn * 64);
+      }
+      pp_barrier();
+      mfma8(fa, fb);
+      pp_barrier();
+      load_frags(sa, sb, 3, fa, fb);
+      pp_vmcnt<NPF>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pp_barrier();
+      mfma8(fa, fb);
+      pp_barrier();
+      sa = step5(sa, 2); sb = step5(sb, 2);
+    }
+    // block nb-1: nothing in flight but the epilogue's operands
+#pragma unroll
+    for (int hk = 0; hk < 4; ++hk) {
+      u32x4 fa[4], fb[2];
+      load_frags(sa, sb, hk, fa, fb);
+      pp_barrier();
+      mfma8(fa, fb);
+      pp_barrier();
+    }
+    if (grp == 0) pp_barrier();
+  }
+  lds_dma_retired<NPF>();
+  float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  if constexpr (EPI >= 3) {
     gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : (EPI == 8 ? 3 : 0)), EPI == 3 || EPI == 4 || EPI == 7>(
         p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
     return;
@@ -1400,7 +1623,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmParams p, i
   epilogue_store(p, i, j, acc);
 }
 
-// Main loop of the big bf16 shapes: 4 = the four-stage ping-pong ring on 256x256 tiles (gemm_pp256_kernel, default);
+// Main loop of the big bf16 shapes: 4 = the ping-pong rings on 256x256 tiles (default: gemm_pp64_kernel where K is whole 64-k
+// blocks, gemm_pp256_kernel otherwise and for the weight gradients); 5 = gemm_pp256_kernel for all of them (A/B of the two);
 // 0 = the two-stage 128x128 kernels for every shape (gemm_glds_kernel / gemm_tn_glds_kernel / gemm_mfma_kernel) and the
 // two-call form of krs_gemm_cross_bwd -- the reference schedule for A/B and bit-for-bit tests.
 // krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, v) / environment KRS_GEMM_PIPE (read once).
@@ -1409,7 +1633,7 @@ int gemm_pipe() {
   if (g_pipe < 0) {
     const char* e = getenv("KRS_GEMM_PIPE");
     g_pipe = e ? atoi(e) : 4;
-    if (g_pipe != 0) g_pipe = 4;
+    if (g_pipe != 0 && g_pipe != 5) g_pipe = 4;
   }
   return g_pipe;
 }
@@ -1542,6 +1766,28 @@ int launch_mfma(const GemmParams& p, hipStream_t st) {
     }                                                                                                \
     hipLaunchKernelGGL(kern, grid256, dim3(512), 4 * pp::STAGE, st, p, 0, nt_);                      \
   }
+      // whole 64-k blocks of both operands and of every split, at least three of them -> the 64-k ring (pipeline 5: never)
+      const bool k64 = gemm_pipe() == 4 && p.k % 64 == 0 && p.k_per_split % 64 == 0 &&
+                       p.k - (int64_t)(p.splits - 1) * p.k_per_split >= 192;
+#define KRS_PP64_LAUNCH(EP)                                                                          \
+  {                                                                                                  \
+    auto kern = gemm_pp64_kernel<EP>;                                                                \
+    static bool attr_set = false;                                                                    \
+    if (!attr_set) {                                                                                 \
+      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, pp64::NSLOT * pp64::SLOT)); \
+      attr_set = true;                                                                               \
+    }                                                                                                \
+    hipLaunchKernelGGL(kern, grid256, dim3(512), pp64::NSLOT * pp64::SLOT, st, p, nt_);              \
+  }
+      if (k64) {
+        if (epi == 1) KRS_PP64_LAUNCH(1)
+        else if (epi == 2) KRS_PP64_LAUNCH(2)
+        else KRS_PP64_LAUNCH(0)
+        KRS_CHECK_LAUNCH("gemm_pp64_kernel");
+        return KRS_OK;
+      }
+#undef KRS_PP64_LAUNCH
       if (epi == 1) KRS_PP_LAUNCH(1)
       else if (epi == 2) KRS_PP_LAUNCH(2)
       else KRS_PP_LAUNCH(0)
@@ -1619,7 +1865,7 @@ using namespace krs;
 
 extern "C" int krs_gemm_set_option(int key, int value) {
   if (key == KRS_GEMM_OPT_PIPELINE) {
-    KRS_REQUIRE(value == 0 || value == 4, "krs_gemm_set_option: pipeline must be 0 or 4");
+    KRS_REQUIRE(value == 0 || value == 4 || value == 5, "krs_gemm_set_option: pipeline must be 0, 4 or 5");
     g_pipe = value;
     return KRS_OK;
   }
@@ -1820,6 +2066,33 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
       attr_set = true;                                                                                 \
     }                                                                                                  \
     hipLaunchKernelGGL(kern, grid256, dim3(512), 4 * pp::STAGE, st, p, 0, nt_);                        \
+  }
+  if (gemm_pipe() == 4 && k % 64 == 0 && k >= 192) {   // the 64-k ring, as krs_gemm's K-contiguous products (level with the 32-k
+                                                        // ring on this epilogue-bound form: 640-650 us either way)
+#define KRS_CB64_LAUNCH(EP)                                                                            \
+  {                                                                                                    \
+    auto kern = gemm_pp64_kernel<EP>;                                                                  \
+    static bool attr_set = false;                                                                      \
+    if (!attr_set) {                                                                                   \
+      KRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, pp64::NSLOT * pp64::SLOT)); \
+      attr_set = true;                                                                                 \
+    }                                                                                                  \
+    hipLaunchKernelGGL(kern, grid256, dim3(512), pp64::NSLOT * pp64::SLOT, st, p, nt_);                \
+  }
+    if (u_upper) KRS_CB64_LAUNCH(7)
+    else if (r) {
+      if (dx0_accumulate) KRS_CB64_LAUNCH(4)
+      else KRS_CB64_LAUNCH(3)
+    } else {
+      if (!dx0) KRS_CB64_LAUNCH(8)
+      else if (dx0_accumulate) KRS_CB64_LAUNCH(6)
+      else KRS_CB64_LAUNCH(5)
+    }
+#undef KRS_CB64_LAUNCH
+    KRS_CHECK_LAUNCH("gemm_pp64_kernel (fused cross backward)");
+    if (dbias) return finish_colsum(p.f_partial, 2 * ceil_div(m, 256), n, dbias, st);
+    return KRS_OK;
   }
   if (u_upper) KRS_CB_LAUNCH(7)
   else if (r) {

@@ -101,8 +101,8 @@ int main(int argc, char** argv) {
   const float zs = getenv("KRS_ZERO") ? 0.0f : 1.0f;
   fill(x0, 1, 1.0f * zs); fill(x, 2, 1.0f * zs); fill(g, 3, 1.0f * zs);
   fill(Ut, 4, 0.05f * zs); fill(Vt, 5, 0.05f * zs); fill(U, 6, 0.05f * zs); fill(V, 7, 0.05f * zs);
-  const int pipes[] = {0, 4};   // 0 = the 128x128 two-stage kernels (reference schedule), 4 = the ring on 256x256 tiles
-  constexpr int NP = 2;
+  const int pipes[] = {0, 5, 4};   // 0 = the 128x128 two-stage kernels (reference schedule), 5 = the 32-k ring on 256x256 tiles for every product, 4 = default (64-k ring where K allows)
+  constexpr int NP = 3;
   // outputs per pipeline
   Buf h[NP], y[NP], u[NP], dz[NP], dx0[NP], dk[NP], dh[NP], du[NP], dx[NP];
   float* dbias;
@@ -219,7 +219,7 @@ int main(int argc, char** argv) {
   printf("%-40s", "case (median us | TF/s or GB/s)");
   for (int i = 0; i < NP; ++i) printf("   pipe %d          ", pipes[i]);
   printf("\n");
-  double tot[NP] = {0, 0};
+  double tot[NP] = {0, 0, 0};
   for (int c = 0; c < 8; ++c) {
     printf("%-40s", cases[c].name);
     for (int i = 0; i < NP; ++i) {

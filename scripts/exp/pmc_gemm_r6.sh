@@ -11,7 +11,7 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES
   rm -rf /tmp/pmc; rocprofv3 --pmc $c -d /tmp/pmc -o p -- /tmp/gemm_bench 1 > /tmp/pmc.log 2>&1
   echo "counters=[$c]" >> $O/gemm_pmc.txt
   db=$(ls /tmp/pmc/*/*.db /tmp/pmc/*.db 2>/dev/null | head -1)
-  if [ -z "$db" ]; then tail -5 /tmp/pmc.log >> $O/gemm_pmc.txt; else python $R/scripts/rocpd_pmc.py $db | grep -E "gemm_pp256|cross_bwd|slab_reduce" >> $O/gemm_pmc.txt; fi
+  if [ -z "$db" ]; then tail -5 /tmp/pmc.log >> $O/gemm_pmc.txt; else python $R/scripts/rocpd_pmc.py $db | grep -E "gemm_pp256|gemm_pp64|cross_bwd|slab_reduce" >> $O/gemm_pmc.txt; fi
 done
 rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats -d /tmp/kt -o k -- /tmp/gemm_bench 1 > /dev/null 2>&1
 python $R/scripts/rocpd_stats.py $(ls /tmp/kt/*/*.db /tmp/kt/*.db 2>/dev/null | head -1) > $O/gemm_kernel_stats.md 2>&1

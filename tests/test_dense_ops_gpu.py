@@ -483,7 +483,8 @@ def test_fused_data_gradient_and_cross_backward_equals_the_two_calls(acc, fold, 
                     D.gemm_cross_bwd(A, Bt, R, x0, u, act=a_id, want_dx0=False)
 
 
-@pytest.mark.parametrize("m,n,k", [(16384 + 72, 768 + 40, 256), (24576, 512, 320)])
+# (k = 256, 320: whole 64-k blocks -> gemm_pp64_kernel, the 64-k ring of round 6; k = 288: not -> gemm_pp256_kernel)
+@pytest.mark.parametrize("m,n,k", [(16384 + 72, 768 + 40, 256), (24576, 512, 320), (16384 + 72, 768 + 40, 288)])
 def test_fused_cross_backward_every_epilogue_form_against_the_two_call_form_at_ragged_shapes(m, n, k):
     """krs_gemm_cross_bwd's fused ring kernel (EPI 3 .. 8) against the documented two-call form, which
     krs_gemm_set_option(KRS_GEMM_OPT_PIPELINE, 0) forces inside the same entry: m and n that are NOT multiples of the
@@ -558,16 +559,20 @@ def test_ring_gemm_equals_the_two_stage_kernels_bit_for_bit():
 
     try:
         L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(4)), "krs_gemm_set_option")
-        ring = products()
+        ring = products()         # default: the 64-k ring (gemm_pp64_kernel) for the K-contiguous products, K = 1088 and 512
+        L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(5)), "krs_gemm_set_option")
+        ring32 = products()       # the 32-k ring (gemm_pp256_kernel) for all of them
         L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(0)), "krs_gemm_set_option")
         ref = products()
     finally:
         L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(4))
-    for name, a, b in zip(("h", "y", "u", "dx", "dK"), ring, ref):
-        if name == "dK":     # split-K slabs: the split count is a function of the shape alone, but the tile kernels differ
-            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
-        else:
-            assert torch.equal(a, b), name
+    for got in (ring, ring32):
+        for name, a, b in zip(("h", "y", "u", "dx", "dK"), got, ref):
+            if name == "dK":     # split-K slabs: the split count is a function of the shape alone, but the tile kernels differ
+                torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-4)
+            else:
+                assert torch.equal(a, b), name
+    assert torch.equal(ring[4], ring32[4])     # (the weight gradient takes the same kernel under both)
 
 
 @pytest.mark.parametrize("m,n,k,ep", [(8192, 512, 3456, None), (8192, 1024, 3456, "bias_relu"), (4096 + 64, 512 + 40, 2048 + 96, None)])
