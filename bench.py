@@ -986,7 +986,7 @@ def gemm_family_rooflines(a, pr, n, b_local):
         ent["traffic"] = tr
         if tr is not None:
             ent["traffic_source"] = ("profiles/k1_pmc.json `gemm families` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                     "kernel at this shape under scripts/exp/gemm_bench: profiles/r4p_gemm_pmc.txt)")
+                                     "kernel at this shape under scripts/exp/gemm_bench: profiles/archive/r4p_gemm_pmc.txt)")
         out.append(ent)
         agg_fl += flops * calls
         agg_ms += e["ms_total"] / n
@@ -1194,7 +1194,7 @@ def main():
     # The second stream for the cross layers' weight gradients (keras_rs_amd/autograd.py, opt-in) stays OFF here since the
     # elementwise backward moved into the data-gradient products (krs_gemm_cross_bwd): the pass it used to run beside is
     # gone, dK / dU would run beside the next layer's ring GEMMs, and that measures no gain (A/B in one call,
-    # profiles/r4k_wgrad_side_ab.txt: 10.13-10.18 ms off, 10.26 on).  KRS_WGRAD_SIDE=1 switches it on for an A/B.
+    # profiles/archive/r4k_wgrad_side_ab.txt: 10.13-10.18 ms off, 10.26 on).  KRS_WGRAD_SIDE=1 switches it on for an A/B.
     from keras_rs_amd import autograd as krs_autograd
 
     krs_autograd.set_wgrad_side_stream(bool(int(os.environ.get("KRS_WGRAD_SIDE", "0"))))

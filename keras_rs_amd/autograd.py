@@ -33,7 +33,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # OPT-IN since round 4 (`set_wgrad_side_stream(True)` or KRS_WGRAD_SIDE=1), and no longer used by bench.py / the example:
 # with the elementwise backward inside the data-gradient products (krs_gemm_cross_bwd) the pass these GEMMs overlapped
 # with is gone -- beside the next layer's ring GEMMs they measured 10.26 against 10.13-10.18 ms
-# (profiles/r4k_wgrad_side_ab.txt).  Also: a gradient produced on a private stream is only safe when NOTHING but the end-of-backward rejoin reads
+# (profiles/archive/r4k_wgrad_side_ab.txt).  Also: a gradient produced on a private stream is only safe when NOTHING but the end-of-backward rejoin reads
 # it, and a backward function cannot see every reader -- a second gradient contribution to the same weight (a manual
 # L2 term, a weight shared by two layers) is summed by autograd's input buffer on the main stream with nothing ordering
 # it behind this stream.  The owner of the training step can promise that; a library default cannot.  What the

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void embed_bag_fwd_generic(const EmbedFwdParam
 
 // One-hot gather: 16 row loads in flight per lane, sample-major walk (embed_gather_hot1_rows) where the output rows allow it.
 // Round 2 kept four variants behind KRS_EMBED_OPT_HOT1 (8 / 16 loads x feature-major / sample-major walk: 172.7 / 170.1 /
-// 164.8 / 159.3 us at the C3 L = 1 launch, profiles/r2_k1_hot1_variants_and_lds_hotrows.txt); round 5 keeps the winner only.
+// 164.8 / 159.3 us at the C3 L = 1 launch, profiles/archive/r2_k1_hot1_variants_and_lds_hotrows.txt); round 5 keeps the winner only.
 int g_hot_rows = 0;   // krs_embed_set_option(KRS_EMBED_OPT_HOTROWS, rows): 0 = no LDS staging (default), 64, 128
 
 template <typename TT, typename OT, int LPR>

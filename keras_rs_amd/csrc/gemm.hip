@@ -21,7 +21,7 @@
 //                           tail of the main loop; bit-identical to the 128x128 two-stage kernels below, which every
 //                           shape takes under pipeline 0 of krs_gemm_set_option.  (The 256x256 two-stage kernels of
 //                           round 1, gemm_glds256_kernel / gemm_tn_glds256_kernel, were deleted in round 5: 222-230 ->
-//                           204 us and 276 -> 208-220 us against the ring, profiles/r2_gemm_ab.txt.)
+//                           204 us and 276 -> 208-220 us against the ring, profiles/archive/r2_gemm_ab.txt.)
 //   * gemm_glds_kernel      two 32 KB stages filled by LDS-DMA on a 128x128 tile for smaller M / N (K >= 1024);
 //   * gemm_tn_glds_kernel
 //                           bf16 weight gradients (both operands K-strided): tiles DMA'd as they
@@ -889,7 +889,7 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
 //     2kb+1, which retires the two pieces of block kb+1 and leaves the 2*NSTG-5 younger pieces in flight.
 //     A wave's vmcnt covers its own DMA writes; the barrier that follows publishes them.
 // Results are bit-identical to the two-stage kernels (same MFMA chain per accumulator: k ascending).
-// Measured and not kept (profiles/r2_gemm_ab.txt): 128-byte rows with a row-wise walk of the wave's block (the
+// Measured and not kept (profiles/archive/r2_gemm_ab.txt): 128-byte rows with a row-wise walk of the wave's block (the
 // "half-tile" ring of the 8-phase template: 205 us against 207 for h = x U, 342 against 338 for dx); issuing the
 // phase's DMA between the MFMAs of the compute segment instead of beside the fragment reads (212 / 319 us
 // against 205 / 274 for the K-contiguous / K-strided forms); five stages instead of four (equal); for the short-K
@@ -899,7 +899,7 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
 // (Rounds 2-4 carried timing-only build switches in this kernel -- KRS_PP_PROBE: DMA stream alone / LDS reads + MFMA alone /
 //  epilogue alone; KRS_PP_LAYOUT_EXP: operands read as if pre-tiled; KRS_PP_{A,B}_AUX: cache policy of the LDS-DMA loads -- and
 //  two more schedules behind krs_gemm_set_option: a five-stage ring and a prefetch schedule.  What they measured is in
-//  profiles/r2_pp_probe_dma_lds_mfma.txt, r4_gemm_layout_waves_clock_probe.txt, r2_gemm_ab.txt; round 5 removed them from
+//  profiles/archive/r2_pp_probe_dma_lds_mfma.txt, r4_gemm_layout_waves_clock_probe.txt, r2_gemm_ab.txt; round 5 removed them from
 //  the product source: the default cache policy, four stages and the ping-pong schedule are what ships.)
 namespace pp {
 constexpr int PIECE = 16384;
@@ -936,7 +936,7 @@ __device__ __forceinline__ void pp_vmcnt() {
 
 // (Round 4 also built the 128x128 tile on a deep ring -- gemm_ring128_kernel, KRS_GEMM_OPT_PIPELINE = 7 -- for the per-rank
 //  shapes of a strongly-scaled job; it measured equal or slower than gemm_glds_kernel (47.2 against 44.9 us at M = 8192,
-//  profiles/r4_gemm_ring128_b8192.txt: one 128x128 tile per CU already draws the ~40 GB/s per CU of the L2 -> LDS path) and
+//  profiles/archive/r4_gemm_ring128_b8192.txt: one 128x128 tile per CU already draws the ~40 GB/s per CU of the L2 -> LDS path) and
 //  was deleted in round 5.)
 // The steady state's LDS-DMA instructions are issued INSIDE the compute segment, behind its 2nd and 5th MFMA, not in the load
 // segment (round 6: the load segment -- six fragment reads + two DMA instructions at 60-185 cycles each -- was the longer
