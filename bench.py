@@ -916,7 +916,7 @@ def roofline_step(a, hots, b_local, res):
                     "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK,
                     "launch_us": sec * 1e6, "algorithmic_bytes": alg, "unique_rows": u, "traffic": traffic,
                     "traffic_source": None if traffic is None else "profiles/k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                      "passes of this kernel at this shape; Infinity-Cache hits are counted, not excluded)"})
+                                      "passes of this kernel at this shape, read in round 4; Infinity-Cache hits are counted, not excluded)"})
     out += gemm_family_rooflines(a, pr, n, b_local)
     if "gemm_cross_bwd" in pr:
         e = pr["gemm_cross_bwd"]
@@ -927,7 +927,7 @@ def roofline_step(a, hots, b_local, res):
         alg = calls * (7 * b_local * dcols * 2 + (b_local + dcols) * a.projection * 2)
         traffic = None
         if a.batch == 65536 and a.tables == 26 and a.dim == 128 and a.projection == 512 and b_local == a.batch:
-            per_launch = pmc_traffic_key("gemm_pp256_kernel<false, 4, 4, 0> (krs_gemm_cross_bwd, C3 shape)")
+            per_launch = pmc_traffic_key("krs_gemm_cross_bwd (C3 shape)")
             traffic = None if per_launch is None else calls * per_launch
         out.append({"kernel": "krs_gemm_cross_bwd x %d per step (dx = dh U^T + g with the elementwise backward of the layer "
                               "below in its epilogue; NOT in the aggregate above)" % calls,
@@ -935,7 +935,7 @@ def roofline_step(a, hots, b_local, res):
                     "frac": alg / sec / HBM_PEAK, "ms_per_step": sec * 1e3, "algorithmic_bytes": alg,
                     "flops_per_step": e["work_total"] / n, "traffic": traffic,
                     "traffic_source": None if traffic is None else "profiles/k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                      "passes of this kernel at this shape under scripts/exp/gemm_bench, x launches per step)"})
+                                      "passes of this kernel at this shape under scripts/exp/gemm_bench, x launches per step; read in round 6)"})
     for key, label in (("k1", "K1 inside the step (beside the K2 plan on the side stream)"),
                        ("k2_plan", "K2 plan (radix sort + segment list; side stream)")):
         if key in pr:
@@ -986,7 +986,7 @@ def gemm_family_rooflines(a, pr, n, b_local):
         ent["traffic"] = tr
         if tr is not None:
             ent["traffic_source"] = ("profiles/k1_pmc.json `gemm families` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                     "kernel at this shape under scripts/exp/gemm_bench: profiles/archive/r4p_gemm_pmc.txt)")
+                                     "kernel at this shape under scripts/exp/gemm_bench, read in round 6: profiles/r6_gemm_hbm_pmc.txt)")
         out.append(ent)
         agg_fl += flops * calls
         agg_ms += e["ms_total"] / n
@@ -1018,7 +1018,8 @@ def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False, in_step_s=Non
     return {"kernel": kernel, "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic,
             "traffic_source": None if traffic is None else "profiles/k1_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                              "passes of this kernel at this shape (counters cannot be read inside this run)",
+                              "passes of this kernel at this shape, read in round 2 and re-checked in round 4 (counters cannot be "
+                              "read inside this run)",
             "launch_us": k1_s * 1e6,
             "launch_us_source": ("HIP events around the call inside the probe steps (in-step)" if in_step_s else
                                  "HIP events around one launch behind the timed steps (isolated)"),
