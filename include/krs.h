@@ -334,7 +334,13 @@ size_t krs_gemm_workspace_bytes(int64_t m, int64_t n, int64_t k, int a_is_km);
  * with G, dz and dx0 BIT-IDENTICAL to those two calls (dz and dx0 are computed from G as it is stored, after its one
  * rounding) -- without the second pass reading G, x0 and u back and with the streams written by the product's epilogue.
  * Row stride `ld` for x0, u, dz and dx0; workspace: krs_gemm_cross_bwd_workspace_bytes(m, n) when dbias is wanted.
- * bf16 tiles the 256x256 ring kernel covers run fused; every other shape / dtype runs the two calls (needs ldg == ld). */
+ * bf16 tiles the 256x256 ring kernel covers run fused; every other shape / dtype runs the two calls (needs ldg == ld).
+ *
+ * DENSE form (round 6): x0 == NULL -- the layer below is a Dense layer (examples/ml_perf/model.py:214-262), u its saved
+ * output y:  dz = G * act'(y),  dbias = column sums of dz;  R, dx0, u_upper, fold_direct must be absent and g_out may be NULL:
+ * G itself is NOT stored (the raw data gradient of a Dense output has no other reader), so the launch streams y in and dz out
+ * where krs_gemm + krs_dense_act_bwd write G, read G and y and write dz.  dz is bit-identical to those two calls (one
+ * rounding of G, then the derivative). */
 size_t krs_gemm_cross_bwd_workspace_bytes(int64_t m, int64_t n);
 int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, int64_t ldb,
                        const void* r, int64_t ldr, float beta,

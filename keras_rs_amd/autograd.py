@@ -227,6 +227,22 @@ def _fusable_below(up, a, x_dtype, task) -> bool:
                 or low[5].dtype != a.dtype or (up.buf is not None and up.task == task))
 
 
+def _dense_fusable_below(rel, dz, x_dtype, task) -> bool:
+    """May the product `dz @ K^T` run the activation backward of the Dense layer behind relay `rel` in its epilogue?"""
+    if rel is None or rel.lower is None or not FUSE_DENSE_BWD or task == -1 or x_dtype != dz.dtype:
+        return False
+    y_low, act_low, bias_low = rel.lower
+    if act_low == L.ACT_NONE and not bias_low:
+        return False            # (nothing to do below: a plain product)
+    if y_low is not None and (y_low.dtype != dz.dtype or not y_low.is_contiguous()):
+        return False
+    if rel.fused is not None and rel.fused[3] == task:
+        return False            # (another consumer of that output already did it in this pass)
+    out = rel.out_ref() if rel.out_ref is not None else None
+    # (somebody watches the layer's output gradient: hand autograd the real dL/dy)
+    return out is None or not (out.retains_grad or out._backward_hooks)
+
+
 def _dx_product(ctx, dh, dc, direct, dx0, x0c, task, u_own=None):
     """dx = dh U^T + direct.  When x was produced by a cross layer on the same x0 (ctx.relay_up) whose elementwise
     backward can ride in this product's epilogue, it does: that layer's dz / dbias and its term of dL/dx0 (added into
@@ -433,6 +449,27 @@ class CrossLayerFn(torch.autograd.Function):
                 dbias if has_bias else None, None, None, None, None, None)
 
 
+# development switch: 0 = every Dense layer runs its own activation backward (krs_dense_act_bwd), as before round 6
+FUSE_DENSE_BWD = bool(int(__import__("os").environ.get("KRS_FUSE_DENSE_BWD", "1")))
+
+
+class DenseActRelay:
+    """Hand-off between two STACKED Dense layers (examples/ml_perf/model.py:214-262: `x = dense(x)` repeated): the upper
+    layer's data-gradient product dx = dz K^T is the lower layer's dL/dy, and the lower layer's first backward step --
+    dz_low = dL/dy * act'(y_low), dbias_low = column sums -- can ride in that product's epilogue (krs_gemm_cross_bwd, dense
+    form): no [B, units] matrix is written for dL/dy and read back.
+      lower  (y, act, has_bias) of the layer whose output carries this relay -- set by its forward;
+      fused  (dz_low, its version, dbias_low, graph task) -- set by the upper layer's backward, taken by the lower one's.
+    What autograd hands the lower layer is then dz_low itself.  If y had ANOTHER consumer the engine has summed that
+    consumer's gradient into it: the lower backward recognises the tensor it was promised (pointer, shape, version) and
+    otherwise sends the difference through the derivative (linear in the gradient)."""
+
+    __slots__ = ("lower", "fused", "out_ref")
+
+    def __init__(self):
+        self.lower, self.fused, self.out_ref = None, None, None
+
+
 class DenseFn(torch.autograd.Function):
     """y = act(x @ K + b): the Dense layers of the DLRM bottom / top MLPs
     (examples/ml_perf/model.py:214-262) on krs_gemm with the bias + activation epilogue fused.
@@ -440,24 +477,47 @@ class DenseFn(torch.autograd.Function):
     db = column sum, dx = dz K^T."""
 
     @staticmethod
-    def forward(ctx, x, kernel, bias, act, compute_dtype, relay_up=None):
+    def forward(ctx, x, kernel, bias, act, compute_dtype, relay_up=None, dense_up=None, relay_out=None):
         # relay_up: the Dx0Relay of the cross layer that produced x (layers.Dense reads it off its input): this layer's
         # data-gradient product then runs that layer's elementwise backward in its epilogue (krs_gemm_cross_bwd)
+        # dense_up / relay_out: the DenseActRelay of the Dense layer that produced x / of this layer's own output
         xc = x.to(compute_dtype).contiguous()
         kc, kct = D.cast_transpose(kernel, compute_dtype)
         y, _ = D.gemm(xc, kct, b_is_nk=True, bias=bias, act=act)
         ctx.save_for_backward(xc, kc, y if act != L.ACT_NONE else None)
         ctx.meta = (act, bias is not None, x.dtype, kernel.dtype)
         ctx.relay_up = relay_up if ctx.needs_input_grad[0] else None
+        ctx.dense_up = dense_up if ctx.needs_input_grad[0] else None
+        ctx.relay_out = relay_out
+        if relay_out is not None:
+            relay_out.lower = (y if act != L.ACT_NONE else None, act, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, g):
         xc, kc, y = ctx.saved_tensors
         act, has_bias, x_dt, k_dt = ctx.meta
-        g = g.to(xc.dtype)
-        # dz = g * act'(y) and the bias gradient in one pass (krs_dense_act_bwd)
-        dz, db = D.dense_act_bwd(g, y, act, want_dbias=has_bias)
+        task = torch._C._current_graph_task_id()
+        rel, fused = ctx.relay_out, None
+        if rel is not None:
+            fused, rel.fused = rel.fused, None
+            if fused is not None and fused[3] != task:
+                fused = None
+        if fused is not None:
+            # the consumer of y ran this layer's activation backward inside its data-gradient product
+            dz_f, version, db = fused[:3]
+            if g.data_ptr() == dz_f.data_ptr() and g.shape == dz_f.shape and g._version == version and g.dtype == dz_f.dtype:
+                dz = dz_f
+            else:
+                # y had another consumer: its share of dL/dy arrived summed into dz_f and still has to meet act'(y)
+                delta = (g.float() - dz_f.float()).to(dz_f.dtype)
+                rest, _ = D.dense_act_bwd(delta, y, act, want_dbias=False)
+                dz = (dz_f.float() + (delta if rest is None else rest).float()).to(dz_f.dtype)
+                db = D.colsum(dz) if has_bias else None
+        else:
+            g = g.to(xc.dtype)
+            # dz = g * act'(y) and the bias gradient in one pass (krs_dense_act_bwd)
+            dz, db = D.dense_act_bwd(g, y, act, want_dbias=has_bias)
         dz = dz.contiguous()
         dk, _ = D.gemm(xc, dz, a_is_km=True, out_dtype=torch.float32)            # [in, units]
         dx = None
@@ -475,10 +535,18 @@ class DenseFn(torch.autograd.Function):
                 if not defer:
                     up.buf, up.task = dx0, task
                 up.fused = (dx, dx._version, dz_low, db_low, task, defer)
+            elif _dense_fusable_below(ctx.dense_up, dz, x_dt, task):
+                # x is the output of a Dense layer: its activation backward and bias gradient ride in this product's epilogue;
+                # what goes back to autograd is that layer's dz (its backward recognises it)
+                below = ctx.dense_up
+                y_low, act_low, bias_low = below.lower
+                dx, db_low = D.gemm_dense_bwd(dz, kc, y_low if y_low is not None else dz.new_empty((dz.shape[0], kc.shape[0])),
+                                              act_low, want_dbias=bias_low)
+                below.fused = (dx, dx._version, db_low, task)
             else:
                 dx, _ = D.gemm(dz, kc, b_is_nk=True)                               # [B, in]
                 dx = dx.to(x_dt)
-        return dx, dk.to(k_dt), db, None, None, None
+        return dx, dk.to(k_dt), db, None, None, None, None, None
 
 
 class BinaryCrossentropyFn(torch.autograd.Function):

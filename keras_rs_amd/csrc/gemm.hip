@@ -753,9 +753,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_glds_kernel(const GemmParams p
 // the term of the layer ABOVE computed here from its dL/dy (= R, already loaded) and its saved u, so that the top layer of a
 // stack neither writes nor this launch reads a [M, N] matrix for it (that one sum is rounded once instead of twice);
 // 3: no dL/dx0 at all from this launch (the caller hands u to the NEXT launch as its u_upper: a Dense layer above a stack).
-template <int DX0, bool HAS_R>
+// X0 = false: the DENSE form (krs_gemm_cross_bwd with x0 = NULL, round 6) -- the layer below is a Dense layer, dz = G act'(y)
+// with y in the place of u, no x0 stream, no dL/dx0, and G itself is not stored (nobody reads the raw data gradient of a
+// Dense output): two streams (y in, dz out) instead of krs_dense_act_bwd's three behind a stored and re-read G.
+template <int DX0, bool HAS_R, bool X0 = true>
 __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams& p, f32x16 (&acc)[2][2][2], float* stage,
                                                                int64_t wm0, int64_t wn0, int64_t group) {
+  static_assert(X0 || (DX0 == 3 && !HAS_R), "the dense form has no R and no dL/dx0");
   const int lane = threadIdx.x & 63;
   const int frow = lane & 31, fhalf = lane >> 5;
   constexpr int SST = 68;
@@ -774,7 +778,7 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int64_t gmc = min(wm0 + c * 32 + it * 8 + (lane >> 3), p.m - 1);
-      vx02[b][it] = load8_bf16_nt(p.f_x0, gmc * p.f_ld + gnc);
+      if constexpr (X0) vx02[b][it] = load8_bf16_nt(p.f_x0, gmc * p.f_ld + gnc);
       vu2[b][it] = load8_bf16_nt(p.f_u, gmc * p.f_ld + gnc);
     }
   };
@@ -820,12 +824,12 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
       // G as it is stored (one rounding) is what everything below sees
       const uint4 gq = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                                   pack_bf16x2(v[6], v[7]));
-      {
+      if constexpr (X0) {
         const u32x4 gs = {gq.x, gq.y, gq.z, gq.w};
         __builtin_nontemporal_store(gs, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.c) + gm * p.ldc + gn));
       }
       unpack_bf16x8(gq, g);
-      unpack_bf16x8(ex0[it], x0v);
+      if constexpr (X0) unpack_bf16x8(ex0[it], x0v);
       unpack_bf16x8(eu[it], uv);
       if constexpr (DX0 == 1 || DX0 == 2) unpack_bf16x8(ed[it], tv);
       else {
@@ -834,7 +838,7 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float gx0 = g[q] * x0v[q];
+        const float gx0 = X0 ? g[q] * x0v[q] : g[q];
         dz[q] = gx0 * act_grad_from_output(p.f_act, uv[q]);
         db[q] += dz[q];
         const float told = DX0 == 1 ? tv[q] : (DX0 == 2 ? rv[q] * tv[q] : 0.0f);
@@ -878,21 +882,26 @@ __device__ __forceinline__ void gemm_epilogue_wave128_crossbwd(const GemmParams&
 //     K-strided layout 32 k-rows x 256 columns), 2 LDS-DMA instructions per thread each; the pieces live in
 //     a ring of NSTG stages (4 = 128 KB, 5 = all 160 KB of the CU);
 //   * a block is consumed in two PHASES of 16 k (6 ds_read_b128 / 12 transposing reads + 8 MFMA per wave),
-//     each phase = a LOAD segment (fragment reads of this phase, ONE piece of DMA issue) and a COMPUTE
-//     segment (the 8 MFMA), every segment closed by s_barrier;
+//     each phase = a LOAD segment (fragment reads of this phase) and a COMPUTE segment (the 8 MFMA with the
+//     phase's ONE piece of DMA issue -- two instructions per wave -- behind its 2nd and 5th MFMA, round 6),
+//     every segment closed by s_barrier;
 //   * waves 0-3 (rows 0..127 of the tile: one wave per SIMD) and waves 4-7 (rows 128..255: the other wave
 //     of every SIMD) run one segment apart -- waves 4-7 pass one extra barrier first -- so on every SIMD
 //     one wave computes while its partner reads LDS and issues DMA;
 //   * nothing is ever drained: pieces A(j), B(j) are issued in phases 2(j-NSTG)+3 / +4 (a slot is refilled
 //     two phases after the last read of its previous content: that read was retired by the reader's
 //     lgkmcnt(0) one barrier earlier), and the only wait is a COUNTED vmcnt at the end of every odd phase
-//     2kb+1, which retires the two pieces of block kb+1 and leaves the 2*NSTG-5 younger pieces in flight.
+//     2kb+1, which retires the two pieces of block kb+1 and leaves the younger pieces in flight (that phase's
+//     own piece is issued behind the wait, in its compute segment: 2*NSTG-6 pieces = STEADY - 2 instructions).
 //     A wave's vmcnt covers its own DMA writes; the barrier that follows publishes them.
 // Results are bit-identical to the two-stage kernels (same MFMA chain per accumulator: k ascending).
 // Measured and not kept (profiles/archive/r2_gemm_ab.txt): 128-byte rows with a row-wise walk of the wave's block (the
-// "half-tile" ring of the 8-phase template: 205 us against 207 for h = x U, 342 against 338 for dx); issuing the
-// phase's DMA between the MFMAs of the compute segment instead of beside the fragment reads (212 / 319 us
-// against 205 / 274 for the K-contiguous / K-strided forms); five stages instead of four (equal); for the short-K
+// "half-tile" ring of the 8-phase template: 205 us against 207 for h = x U, 342 against 338 for dx -- round 6's
+// gemm_pp64_kernel is that idea on 64-k pieces with the DMA among the MFMAs: 189 us); in ROUND 2 issuing the
+// phase's DMA between the MFMAs of the compute segment instead of beside the fragment reads measured worse (212 / 319 us
+// against 205 / 274 for the K-contiguous / K-strided forms of that day's kernel) -- re-measured in round 6 on today's
+// kernels it is the better place (215 -> 212 us here, 195 -> 189 in gemm_pp64_kernel:
+// profiles/r6_gemm_k64_dma_in_compute_ab.txt); five stages instead of four (equal); for the short-K
 // products with heavy epilogues, 256 x 128 tiles on a three-stage ring at TWO workgroups per CU, so that one's
 // epilogue runs under the other's main loop (467 / 344 us against 450 / 323: 1.5x the operand bytes per flop cost
 // more than the overlap returns).
@@ -1192,8 +1201,9 @@ __global__ __launch_bounds__(512) void gemm_pp256_kernel(const GemmParams p, int
   lds_dma_retired<NPF>();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   if constexpr (EPI >= 3) {   // 3: + R, 4: + R, dx0 accumulates, 5: no R, 6: no R, dx0 accumulates, 7: + R, dx0 = R u_upper + ...,
-                              // 8: no R, no dx0
-    gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : (EPI == 8 ? 3 : 0)), EPI == 3 || EPI == 4 || EPI == 7>(
+                              // 8: no R, no dx0, 9: the dense form (no x0, no R, no dx0, G not stored)
+    gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : ((EPI == 8 || EPI == 9) ? 3 : 0)),
+                                   EPI == 3 || EPI == 4 || EPI == 7, EPI != 9>(
         p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
     return;
   }
@@ -1388,7 +1398,8 @@ __global__ __launch_bounds__(512) void gemm_pp64_kernel(const GemmParams p, int 
   lds_dma_retired<NPF>();
   float* stage_f = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   if constexpr (EPI >= 3) {
-    gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : (EPI == 8 ? 3 : 0)), EPI == 3 || EPI == 4 || EPI == 7>(
+    gemm_epilogue_wave128_crossbwd<(EPI == 4 || EPI == 6) ? 1 : (EPI == 7 ? 2 : ((EPI == 8 || EPI == 9) ? 3 : 0)),
+                                   EPI == 3 || EPI == 4 || EPI == 7, EPI != 9>(
         p, acc, stage_f, m0 + wm * 128, n0 + wn * 64, (m0 >> 8) * 2 + wm);
     return;
   }
@@ -2008,7 +2019,11 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
                                   void* dx0, int64_t ld, int dx0_accumulate, const void* u_upper, int fold_direct,
                                   float* dbias, int64_t m, int64_t n, int64_t k, int act, int dtype, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-  KRS_REQUIRE(a && bt && g_out && x0 && u && dz, "krs_gemm_cross_bwd: null operand");
+  const bool dense_form = x0 == nullptr;    // the layer below is a Dense layer: dz = G act'(u) (u = its saved output), dbias
+  KRS_REQUIRE(a && bt && u && dz && (dense_form || g_out), "krs_gemm_cross_bwd: null operand");
+  KRS_REQUIRE(!dense_form || (!r && !dx0 && !dx0_accumulate && !u_upper && !fold_direct),
+              "krs_gemm_cross_bwd: the dense form (x0 = NULL) takes no R, dx0, u_upper or fold_direct");
+  if (dense_form && !g_out) { g_out = dz; ldg = ld; }    // (never written by the fused form; the two-call form passes through it)
   if (!r) { ldr = n; beta = 0.0f; }
   KRS_REQUIRE(dx0 || (!r && !dx0_accumulate && !u_upper && !fold_direct),
               "krs_gemm_cross_bwd: dx0 = NULL (the term is left to the next launch's u_upper) is the form without R");
@@ -2024,7 +2039,7 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
   const bool fused = dtype == KRS_BF16 && gemm_pipe() != 0 && m >= 256 && n >= 256 && k >= 256 && k % 64 == 0 &&
                      ceil_div(m, 256) * ceil_div(n, 256) >= 192 && n % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
                      ldr % 8 == 0 && ldg % 8 == 0 && ld % 8 == 0 && al16(a) && al16(bt) && (!r || al16(r)) && al16(g_out) &&
-                     al16(x0) && al16(u) && al16(dz) && (!dx0 || al16(dx0)) && (!u_upper || al16(u_upper));
+                     (!x0 || al16(x0)) && al16(u) && al16(dz) && (!dx0 || al16(dx0)) && (!u_upper || al16(u_upper));
   if (!fused) {
     // any other shape / dtype: the two calls this entry stands for
     krs_gemm_epilogue ep;
@@ -2035,6 +2050,8 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
                           false))
       return rc;
     KRS_REQUIRE(ldg == ld, "krs_gemm_cross_bwd: the two-call form needs one row stride for G, x0, u, dz and dx0");
+    if (dense_form)    // G lands in (or is) dz's buffer, the activation derivative is applied in place
+      return krs_dense_act_bwd(g_out, ldg, u, ld, dz, ld, dbias, m, n, act, dtype, workspace, workspace_bytes, stream);
     if (u_upper) {   // the upper layer's term first: dx0 = R * u_upper (its own rounding here), then accumulate
       KRS_REQUIRE(ldr == ld, "krs_gemm_cross_bwd: the two-call form needs R on the common row stride");
       if (int rc = krs_cross_epilogue_bwd(r, u_upper, x0, x0, nullptr, dx0, 0, nullptr, nullptr, m, n, ld, 0.0f, KRS_ACT_NONE,
@@ -2080,7 +2097,8 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
     }                                                                                                  \
     hipLaunchKernelGGL(kern, grid256, dim3(512), pp64::NSLOT * pp64::SLOT, st, p, nt_);                \
   }
-    if (u_upper) KRS_CB64_LAUNCH(7)
+    if (dense_form) KRS_CB64_LAUNCH(9)
+    else if (u_upper) KRS_CB64_LAUNCH(7)
     else if (r) {
       if (dx0_accumulate) KRS_CB64_LAUNCH(4)
       else KRS_CB64_LAUNCH(3)
@@ -2094,7 +2112,8 @@ extern "C" int krs_gemm_cross_bwd(const void* a, int64_t lda, const void* bt, in
     if (dbias) return finish_colsum(p.f_partial, 2 * ceil_div(m, 256), n, dbias, st);
     return KRS_OK;
   }
-  if (u_upper) KRS_CB_LAUNCH(7)
+  if (dense_form) KRS_CB_LAUNCH(9)
+  else if (u_upper) KRS_CB_LAUNCH(7)
   else if (r) {
     if (dx0_accumulate) KRS_CB_LAUNCH(4)
     else KRS_CB_LAUNCH(3)

@@ -189,6 +189,30 @@ def gemm_cross_bwd(a: torch.Tensor, bt: torch.Tensor, r: torch.Tensor, x0: torch
     return g, dz, dx0, dbias
 
 
+def gemm_dense_bwd(a: torch.Tensor, bt: torch.Tensor, y: torch.Tensor, act: int, want_dbias: bool = True):
+    """The dense form of krs_gemm_cross_bwd: dz = (A @ Bt^T) * act'(y) and dbias = column sums of dz in ONE launch -- the
+    data-gradient product of a Dense layer running the activation backward of the Dense layer BELOW it (whose saved output
+    is y) in its epilogue; the raw data gradient is never stored.  a: [M, K], bt: [N, K], y: [M, N].  Returns (dz, dbias)."""
+    a, bt = _rowmajor(a, "gemm_dense_bwd A"), _rowmajor(bt, "gemm_dense_bwd Bt")
+    y = _rowmajor(y, "gemm_dense_bwd y").contiguous()
+    m, k = a.shape
+    n = bt.shape[0]
+    if bt.shape[1] != k or tuple(y.shape) != (m, n) or not (a.dtype == bt.dtype == y.dtype):
+        raise L.KrsError("gemm_dense_bwd: shapes / dtypes do not fit")
+    dz = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    dbias = torch.empty(n, dtype=torch.float32, device=a.device) if want_dbias else None
+    nbytes = int(L.lib().krs_gemm_cross_bwd_workspace_bytes(C.c_int64(m), C.c_int64(n))) if want_dbias else 0
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=a.device) if want_dbias else None
+    with probe.span("gemm_dense_bwd", 2.0 * m * n * k):
+        rc = L.lib().krs_gemm_cross_bwd(
+            L.ptr(a), C.c_int64(a.stride(0)), L.ptr(bt), C.c_int64(bt.stride(0)), None, C.c_int64(n), C.c_float(0.0),
+            None, C.c_int64(n), None, L.ptr(y), L.ptr(dz), None, C.c_int64(n), C.c_int(0), None, C.c_int(0), L.ptr(dbias),
+            C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int(act), C.c_int(L.fdtype(a)), L.ptr(ws), C.c_size_t(nbytes),
+            L.stream_ptr())
+    L.check(rc, "krs_gemm_cross_bwd (dense form)")
+    return dz, dbias
+
+
 def colsum(a: torch.Tensor) -> torch.Tensor:
     a = _rowmajor(a, "colsum")
     out = torch.empty(a.shape[1], dtype=torch.float32, device=a.device)

@@ -12,7 +12,7 @@ from typing import Any
 import torch
 
 from keras_rs_amd import _lib as L
-from keras_rs_amd.autograd import DenseFn
+from keras_rs_amd.autograd import DenseActRelay, DenseFn
 from keras_rs_amd.layers import base
 
 _FUSED_ACTS = {None: L.ACT_NONE, base.linear: L.ACT_NONE, base.relu: L.ACT_RELU,
@@ -52,12 +52,23 @@ class Dense(base.Layer):
         fused = self.activation in _FUSED_ACTS
         # (an input that is the output of a FeatureCross stack carries that layer's relay: the data gradient of this
         #  layer then runs the cross layer's elementwise backward in its epilogue, autograd.DenseFn)
+        # (likewise an input that is the output of another Dense layer carries a DenseActRelay: that layer's activation
+        #  backward and bias gradient then ride in this layer's data-gradient product; this layer's own output gets one)
+        two_d = x.dim() == 2
+        relay_out = DenseActRelay() if (two_d and fused) else None
         y = DenseFn.apply(x.reshape(-1, d), self.kernel, self.bias,
                           _FUSED_ACTS[self.activation] if fused else L.ACT_NONE, self.compute_dtype,
-                          getattr(x, "_krs_dx0_relay", None) if x.dim() == 2 else None)
+                          getattr(x, "_krs_dx0_relay", None) if two_d else None,
+                          getattr(x, "_krs_dense_relay", None) if two_d else None, relay_out)
         if not fused:
             y = self.activation(y)
-        return y.reshape(*lead, self.units)
+        y = y.reshape(*lead, self.units)
+        if relay_out is not None:
+            import weakref
+
+            relay_out.out_ref = weakref.ref(y)
+            y._krs_dense_relay = relay_out
+        return y
 
     def compute_output_shape(self, input_shape):
         return tuple(input_shape[:-1]) + (self.units,)

@@ -1234,6 +1234,104 @@ def test_dense_above_a_cross_stack_whose_top_output_has_a_second_consumer():
         torch.testing.assert_close(u.float(), v.float(), rtol=2.0 ** -6, atol=2.0 ** -7 * scale, msg=lambda m: f"{name}: {m}")
 
 
+@pytest.mark.parametrize("policy,acts", [("mixed_bfloat16", ("relu", "relu", "relu", "sigmoid")), ("float32", ("tanh", "relu", None, "sigmoid"))])
+def test_stacked_dense_layers_run_the_lower_layers_activation_backward_in_the_upper_data_gradient(policy, acts):
+    """Round 6 (review item 5): the data-gradient product dx = dz K^T of a Dense layer on top of another Dense layer runs that
+    layer's dz = dL/dy * act'(y) and bias gradient in its epilogue (krs_gemm_cross_bwd, dense form: dL/dy is never written).
+    Every weight / bias / input gradient of a 4-layer stack (units that take the fused ring kernel in bf16 and the two-call
+    form in fp32 / for the 1-unit layer) against the same stack with the fusion switched off: dz and dx bit for bit -- the
+    derivative is applied to the same once-rounded product --, bias gradients to fp32 summation order."""
+    from keras_rs_amd import autograd as A
+    from keras_rs_amd.layers import base as kl_base
+
+    kl = _layers()
+    g = torch.Generator(device=DEV).manual_seed(41)
+    B, d, units = 16384 + 40, 768, (512, 512, 256, 1)
+    dt = torch.bfloat16 if policy == "mixed_bfloat16" else torch.float32
+    x0 = (torch.randn(B, d, device=DEV, generator=g) * 0.5).to(dt)
+    gy = (torch.randn(B, 1, device=DEV, generator=g) * 0.1).to(dt)
+
+    def run(fuse):
+        old, A.FUSE_DENSE_BWD = A.FUSE_DENSE_BWD, fuse
+        try:
+            mlp = [kl.Dense(u, activation=a, kernel_initializer=kl_base.GlorotUniform(seed=60 + i),
+                            bias_initializer=kl_base.RandomUniform(-0.1, 0.1, seed=70 + i), dtype=policy)
+                   for i, (u, a) in enumerate(zip(units, acts))]
+            x = x0.clone().requires_grad_()
+            h = x
+            for layer in mlp:
+                h = layer(h)
+            h.backward(gy)
+            torch.cuda.synchronize()
+            return [(f"{i}.{n}", q.grad.clone()) for i, layer in enumerate(mlp) for n, q in layer.named_parameters()] + [("x", x.grad.clone())]
+        finally:
+            A.FUSE_DENSE_BWD = old
+
+    a, b = run(True), run(False)
+    for (name, u), (_, v) in zip(a, b):
+        if name.endswith("bias"):
+            torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4 * float(v.abs().max() + 1e-6), msg=lambda m: f"{name}: {m}")
+        else:
+            assert torch.equal(u, v), name
+    # and against float64 autograd of the same stack (the fused path is what ships: this is the parity statement)
+    if policy == "float32":
+        mlp_ref = [kl.Dense(u, activation=a, kernel_initializer=kl_base.GlorotUniform(seed=60 + i),
+                            bias_initializer=kl_base.RandomUniform(-0.1, 0.1, seed=70 + i), dtype=policy)
+                   for i, (u, a) in enumerate(zip(units, acts))]
+        for layer in mlp_ref:
+            layer.build((B, d if layer is mlp_ref[0] else mlp_ref[mlp_ref.index(layer) - 1].units))
+        xr = x0.double().requires_grad_()
+        h = xr
+        for layer, act in zip(mlp_ref, acts):
+            h = h @ layer.kernel.double() + layer.bias.double()
+            h = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, None: lambda t: t}[act](h)
+        h.backward(gy.double())
+        # (fp32 against float64: a pre-activation within rounding of a relu's kink takes the other branch -- a handful of
+        #  elements; everywhere else the two agree to fp32 accuracy)
+        got, ref = dict(a)["x"].double(), xr.grad
+        close = torch.isclose(got, ref, rtol=2e-4, atol=2e-6)
+        assert float(close.double().mean()) > 0.999 and float((got - ref).abs().max()) < 1e-3
+
+
+def test_a_dense_output_with_a_second_consumer_or_a_watcher_still_gets_the_right_gradient():
+    """The upper Dense layer hands autograd the LOWER layer's dz instead of dL/dy.  With a second consumer of that output the
+    engine sums the other gradient into it: the lower backward notices (another tensor) and sends the difference through the
+    derivative.  With retain_grad() on the output nothing is fused and .grad is the real dL/dy."""
+    from keras_rs_amd import autograd as A
+    from keras_rs_amd.layers import base as kl_base
+
+    kl = _layers()
+    g = torch.Generator(device=DEV).manual_seed(43)
+    B, d = 16384, 512
+    x0 = (torch.randn(B, d, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+
+    def run(fuse, watch):
+        old, A.FUSE_DENSE_BWD = A.FUSE_DENSE_BWD, fuse
+        try:
+            lo = kl.Dense(512, activation="sigmoid", kernel_initializer=kl_base.GlorotUniform(seed=81), dtype="mixed_bfloat16")
+            hi = kl.Dense(256, activation="relu", kernel_initializer=kl_base.GlorotUniform(seed=82), dtype="mixed_bfloat16")
+            x = x0.clone().requires_grad_()
+            y = lo(x)
+            if watch:
+                y.retain_grad()
+            loss = hi(y).float().mean() + (0.0 if watch else y.float().pow(2).mean() * 0.5)     # the second consumer
+            loss.backward()
+            torch.cuda.synchronize()
+            out = [(f"{i}.{n}", q.grad.clone()) for i, layer in enumerate((lo, hi)) for n, q in layer.named_parameters()] + [("x", x.grad.clone())]
+            return out + ([("y", y.grad.clone())] if watch else [])
+        finally:
+            A.FUSE_DENSE_BWD = old
+
+    for watch in (False, True):
+        a, b = run(True, watch), run(False, watch)
+        for (name, u), (_, v) in zip(a, b):
+            if watch:
+                assert torch.equal(u, v), name       # nothing was fused: the same launches
+            else:
+                scale = float(v.float().abs().max())
+                torch.testing.assert_close(u.float(), v.float(), rtol=2.0 ** -6, atol=2.0 ** -7 * scale, msg=lambda m: f"{name}: {m}")
+
+
 def test_training_step_leaves_no_cyclic_garbage_that_holds_device_tensors():
     """bench.py times its steps with the cyclic collector off: anything a step leaves in a reference cycle then stays
     allocated (round 4: a recursive closure of the output packing held the 453 MB lookup slab of every step, two fresh
