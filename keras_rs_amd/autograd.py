@@ -231,11 +231,9 @@ def _dense_fusable_below(rel, dz, x_dtype, task) -> bool:
     """May the product `dz @ K^T` run the activation backward of the Dense layer behind relay `rel` in its epilogue?"""
     if rel is None or rel.lower is None or not FUSE_DENSE_BWD or task == -1 or x_dtype != dz.dtype:
         return False
-    y_low, act_low, bias_low = rel.lower
+    act_low, bias_low = rel.lower
     if act_low == L.ACT_NONE and not bias_low:
         return False            # (nothing to do below: a plain product)
-    if y_low is not None and (y_low.dtype != dz.dtype or not y_low.is_contiguous()):
-        return False
     if rel.fused is not None and rel.fused[3] == task:
         return False            # (another consumer of that output already did it in this pass)
     out = rel.out_ref() if rel.out_ref is not None else None
@@ -458,7 +456,9 @@ class DenseActRelay:
     layer's data-gradient product dx = dz K^T is the lower layer's dL/dy, and the lower layer's first backward step --
     dz_low = dL/dy * act'(y_low), dbias_low = column sums -- can ride in that product's epilogue (krs_gemm_cross_bwd, dense
     form): no [B, units] matrix is written for dL/dy and read back.
-      lower  (y, act, has_bias) of the layer whose output carries this relay -- set by its forward;
+      lower  (act, has_bias) of the layer whose output carries this relay -- set by its forward (no tensor: the output
+             holds the relay as an attribute, a reference back would be a cycle that only the cyclic collector frees; the
+             upper layer has that output anyway -- it is its saved input);
       fused  (dz_low, its version, dbias_low, graph task) -- set by the upper layer's backward, taken by the lower one's.
     What autograd hands the lower layer is then dz_low itself.  If y had ANOTHER consumer the engine has summed that
     consumer's gradient into it: the lower backward recognises the tensor it was promised (pointer, shape, version) and
@@ -487,10 +487,11 @@ class DenseFn(torch.autograd.Function):
         ctx.save_for_backward(xc, kc, y if act != L.ACT_NONE else None)
         ctx.meta = (act, bias is not None, x.dtype, kernel.dtype)
         ctx.relay_up = relay_up if ctx.needs_input_grad[0] else None
-        ctx.dense_up = dense_up if ctx.needs_input_grad[0] else None
+        # (the lower layer's saved output is this layer's saved input when no cast / copy came between)
+        ctx.dense_up = dense_up if (ctx.needs_input_grad[0] and xc.data_ptr() == x.data_ptr() and xc.dtype == x.dtype) else None
         ctx.relay_out = relay_out
         if relay_out is not None:
-            relay_out.lower = (y if act != L.ACT_NONE else None, act, bias is not None)
+            relay_out.lower = (act, bias is not None)
         return y
 
     @staticmethod
@@ -539,9 +540,8 @@ class DenseFn(torch.autograd.Function):
                 # x is the output of a Dense layer: its activation backward and bias gradient ride in this product's epilogue;
                 # what goes back to autograd is that layer's dz (its backward recognises it)
                 below = ctx.dense_up
-                y_low, act_low, bias_low = below.lower
-                dx, db_low = D.gemm_dense_bwd(dz, kc, y_low if y_low is not None else dz.new_empty((dz.shape[0], kc.shape[0])),
-                                              act_low, want_dbias=bias_low)
+                act_low, bias_low = below.lower
+                dx, db_low = D.gemm_dense_bwd(dz, kc, xc, act_low, want_dbias=bias_low)     # (xc IS the lower layer's output y)
                 below.fused = (dx, dx._version, db_low, task)
             else:
                 dx, _ = D.gemm(dz, kc, b_is_nk=True)                               # [B, in]
