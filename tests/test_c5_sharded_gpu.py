@@ -39,11 +39,18 @@ def _run(extra, timeout=900):
 
 
 def test_c5_criteo_vocabularies_sharded_eight_ways_parity():
+    import gc
+
     import torch
 
+    # the eight ranks are processes of their own and need ~160 GB between them: hand back what this process's caching
+    # allocator still holds from earlier tests of the session
+    gc.collect()
+    torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info(0)
     if total < 200 * 2 ** 30:
         pytest.skip("C5 needs ~160 GB of HBM for the tables and their accumulators")
+    assert free > 170 * 2 ** 30, f"only {free >> 30} GiB of HBM are free: an earlier test of this session still holds device memory"
     line, full, _ = _run(["--replicate-below", "2048"])
     assert line["n_gpus"] == 8 and full["ranks"] == 8 and "Criteo-1TB scale" in full["config"]["workload"]
     assert "204184588 rows" in full["config"]["workload"] and "power-law" in full["config"]["workload"]
