@@ -647,3 +647,80 @@ def test_cross_backward_with_a_long_k_on_a_small_batch_needs_no_split_k_workspac
                               C.c_int(L.F32), None, None, C.c_size_t(0), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         L.check(rc, "krs_gemm")
         torch.testing.assert_close(out.double(), A.double() @ Bt.double().t(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("m,n,k", [(24576 + 13, 515, 192), (24576, 776, 448), (65536, 512, 128 + 64)])
+def test_the_64k_ring_at_its_edges(m, n, k):
+    """gemm_pp64_kernel (round 6) where its bookkeeping is thinnest: K = 192 = three 64-k blocks (prologue, one tail block with the
+    last piece, one with nothing in flight: the steady loop does not run), K = 448 (odd block count through five slots), an N that
+    is not a multiple of 8 (scalar epilogue stores, clamped DMA rows in the last N tile) and an M with a partial last tile --
+    against float64 on sampled rows and bit for bit against the reference schedule (pipeline 0) and the 32-k ring (pipeline 5),
+    plain and with the bias + ReLU epilogue; run-to-run identical."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd import dense_ops as D
+
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(m + n + k)
+    a = (torch.rand(m, k, device=dev, generator=gen) - 0.5).to(torch.bfloat16)
+    bt = ((torch.rand(n, k, device=dev, generator=gen) - 0.5) * 0.2).to(torch.bfloat16)
+    bias = torch.rand(n, device=dev, generator=gen) - 0.5
+    rows = torch.cat([torch.arange(0, 300, device=dev), torch.arange(m - 300, m, device=dev)])
+    ref = a[rows].double() @ bt.double().t()
+
+    def both():
+        plain, _ = D.gemm(a, bt, b_is_nk=True)
+        act, _ = D.gemm(a, bt, b_is_nk=True, bias=bias, act=L.ACT_RELU)
+        return plain, act
+
+    got = both()
+    again = both()
+    assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
+    torch.testing.assert_close(got[0][rows].double(), ref, rtol=2.0 ** -8 * 1.01, atol=1e-4)
+    torch.testing.assert_close(got[1][rows].double(), torch.relu(ref + bias.double()), rtol=2.0 ** -8 * 1.01, atol=1e-4)
+    try:
+        for pipe in (0, 5):
+            L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(pipe)), "krs_gemm_set_option")
+            other = both()
+            assert torch.equal(got[0], other[0]) and torch.equal(got[1], other[1]), pipe
+    finally:
+        L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(4))
+
+
+def test_the_64k_ring_is_race_free_over_many_launches():
+    """A staged LDS buffer read before its DMA has landed, or restaged before its last read, shows up as RARE wrong tiles that come
+    and go with memory load (cdna_hip_programming.md, 8-phase template notes) -- so the C3 long-K product (54 blocks through the
+    five slots, 512 workgroups in two rounds) and the K = 512 cross form run 150 times each, while a second stream keeps HBM busy,
+    and every output must equal the first launch's bits (which equal the reference schedule's)."""
+    import ctypes as C
+
+    from keras_rs_amd import _lib as L
+    from keras_rs_amd import dense_ops as D
+
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev).manual_seed(77)
+    m, d, p = 65536, 3456, 512
+    x = (torch.rand(m, d, device=dev, generator=gen) - 0.5).to(torch.bfloat16)
+    x0 = (torch.rand(m, d, device=dev, generator=gen) - 0.5).to(torch.bfloat16)
+    ut = ((torch.rand(p, d, device=dev, generator=gen) - 0.5) * 0.1).to(torch.bfloat16)
+    vt = ((torch.rand(d, p, device=dev, generator=gen) - 0.5) * 0.1).to(torch.bfloat16)
+    try:
+        L.check(L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(0)), "krs_gemm_set_option")
+        h_ref, _ = D.gemm(x, ut, b_is_nk=True)
+        y_ref, u_ref = D.gemm(h_ref, vt, b_is_nk=True, x0=x0, x=x, want_u=True)
+    finally:
+        L.lib().krs_gemm_set_option(C.c_int(0), C.c_int(4))
+    noise_src = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    noise_dst = torch.empty_like(noise_src)
+    side = torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    for it in range(150):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                noise_dst.copy_(noise_src)          # HBM traffic beside the product
+        h, _ = D.gemm(x, ut, b_is_nk=True)
+        y, u = D.gemm(h, vt, b_is_nk=True, x0=x0, x=x, want_u=True)
+        bad += (h != h_ref).sum() + (y != y_ref).sum() + (u != u_ref).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0
