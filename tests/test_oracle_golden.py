@@ -205,3 +205,37 @@ def test_adam_and_ftrl_oracle_against_float64_keras_formulas():
         n = n_new
         np.testing.assert_allclose(w, W, rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(acc[1], z, rtol=2e-5, atol=1e-6)
+
+
+def test_adam_oracle_against_an_independent_implementation_torch_sparse_adam():
+    """Adam has no vector in the reference (the arithmetic is jax_tpu_embedding's, absent).  An INDEPENDENT implementation of the
+    same rule exists in this image: torch.optim.SparseAdam is lazy Adam -- only the rows a step touches move, their moments
+    included -- with step_size = lr sqrt(1 - b2^t) / (1 - b1^t) and denominator sqrt(v) + eps, i.e. keras.optimizers.Adam's
+    update_step applied to the touched rows (what config_conversion.py:256-265 asks the SparseCore library for).  Five steps with
+    different touched-row sets, float64 in torch, against the oracle's fp32 arithmetic: weights and both moment planes.  Still not
+    a reference vector ("parity unpinned" stands), but no longer only this repo's own transcription."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    V, D = 23, 7
+    w0 = rng.uniform(-1, 1, (V, D)).astype(np.float32)
+    lr, b1, b2, eps = 0.05, 0.9, 0.999, 1e-7
+    w = w0.copy()
+    acc = np.zeros((2, V, D), np.float32)
+    p = torch.nn.Parameter(torch.from_numpy(w0).double())
+    opt = torch.optim.SparseAdam([p], lr=lr, betas=(b1, b2), eps=eps)
+    for t in range(1, 6):
+        rows = np.sort(rng.choice(V, size=rng.integers(3, 12), replace=False))
+        g = np.zeros((V, D), np.float32)
+        g[rows] = rng.uniform(-1, 1, (len(rows), D)).astype(np.float32)
+        touched = np.zeros(V, np.uint8)
+        touched[rows] = 1
+        corr = np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        ko.apply_optimizer(w, acc, g, touched, lr, "adam", (b1, b2, eps, corr))
+        p.grad = torch.sparse_coo_tensor(torch.from_numpy(rows)[None, :], torch.from_numpy(g[rows]).double(), (V, D))
+        opt.step()
+        st = opt.state[p]
+        np.testing.assert_allclose(w, p.detach().numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(acc[0], st["exp_avg"].numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(acc[1], st["exp_avg_sq"].numpy(), rtol=2e-5, atol=1e-7)
+    assert not np.array_equal(w, w0)
