@@ -220,6 +220,9 @@ def _is_placement_leaf(x) -> bool:
     return isinstance(x, PlacementAndPath)
 
 
+MAX_GROUP_DESCRIPTORS = 512      # = kMaxLdsDesc of csrc/embed_bag_bwd.hip
+
+
 @dataclasses.dataclass
 class _Group:
     """Features of one placement sharing (embedding_dim): one FusedBags, one launch."""
@@ -342,7 +345,32 @@ class DistributedEmbedding(base.Layer):
                 g.table_configs.append(fc.table)
             g.paths.append(path)
             g.table_index.append(idx)
-        self._groups[placement] = list(by_dim.values())
+        # K2's vector apply kernel keeps a launch's feature / table descriptors in LDS, MAX_GROUP_DESCRIPTORS of each; a
+        # wider group would fall to its any-shape kernel (one column per lane, no hot-row path: correct, slow under skew --
+        # ADVICE r5).  Groups are independent launches anyway, so a wider one is split between tables (the features of
+        # one table stay together); each part gets its own slab.
+        groups = []
+        for g in by_dim.values():
+            if len(g.paths) <= MAX_GROUP_DESCRIPTORS and len(g.table_configs) <= MAX_GROUP_DESCRIPTORS:
+                groups.append(g)
+                continue
+            feats_of = [[i for i, t in enumerate(g.table_index) if t == ti] for ti in range(len(g.table_configs))]
+            part = _Group(placement, g.dim, [], [], [])
+            for ti, feats in enumerate(feats_of):
+                if len(feats) > MAX_GROUP_DESCRIPTORS:
+                    raise ValueError(f"Table '{g.table_configs[ti].name}' is shared by {len(feats)} features; a fused launch "
+                                     f"takes at most {MAX_GROUP_DESCRIPTORS} features of one table")
+                if part.paths and (len(part.paths) + len(feats) > MAX_GROUP_DESCRIPTORS
+                                   or len(part.table_configs) + 1 > MAX_GROUP_DESCRIPTORS):
+                    groups.append(part)
+                    part = _Group(placement, g.dim, [], [], [])
+                part.table_configs.append(g.table_configs[ti])
+                for i in feats:
+                    part.paths.append(g.paths[i])
+                    part.table_index.append(len(part.table_configs) - 1)
+            if part.paths:
+                groups.append(part)
+        self._groups[placement] = groups
 
     def _parse_table_stacking(self, table_stacking, feature_configs) -> list:
         """`table_stacking` (base:455-466, jax/distributed_embedding.py:413-453): None / "auto" / a list of table

@@ -1428,3 +1428,40 @@ def test_a_forward_without_a_backward_leaves_no_stale_bookkeeping():
     y.float().sum().backward()
     assert cross.kernel._krs_pending_cross == 0 and not bags._plan_ws_busy
     torch.cuda.synchronize()
+
+
+def test_a_layer_with_more_features_than_one_fused_launch_takes_is_split_into_groups():
+    """K2's vector apply kernel keeps 512 feature / table descriptors of a launch in LDS; a wider group used to
+    fall to the any-shape kernel (no hot-row path).  The layer now splits such a group between tables -- 700 tables of one width
+    here, two of them shared by two features each: two groups, every lookup and every fused SGD update equal to the oracle's,
+    features of a shared table in one group."""
+    from keras_rs_amd.layers import distributed_embedding as de
+    from oracle import krs_oracle as ko
+
+    kl = _layers()
+    rng = np.random.default_rng(5)
+    T, V, D, B = 700, 40, 8, 16
+    tcs = [kl.TableConfig(f"t{t}", V, D, optimizer=kl.SGD(0.5), combiner="sum", placement="sparsecore") for t in range(T)]
+    fcs = {f"f{t}": kl.FeatureConfig(f"f{t}", tcs[t], (B, 2), (B, D)) for t in range(T)}
+    fcs["g0"] = kl.FeatureConfig("g0", tcs[3], (B, 1), (B, D))          # shared tables
+    fcs["g1"] = kl.FeatureConfig("g1", tcs[650], (B, 3), (B, D))
+    emb = kl.DistributedEmbedding(fcs)
+    groups = emb._groups["sparsecore"]
+    assert len(groups) == 2 and all(len(g.paths) <= de.MAX_GROUP_DESCRIPTORS and len(g.table_configs) <= de.MAX_GROUP_DESCRIPTORS for g in groups)
+    assert sum(len(g.paths) for g in groups) == T + 2 and sum(len(g.table_configs) for g in groups) == T
+    where = {p: gi for gi, g in enumerate(groups) for p in g.paths}
+    assert where["g0"] == where["f3"] and where["g1"] == where["f650"]
+    ids = {k: rng.integers(0, V, fc.input_shape).astype(np.int32) for k, fc in fcs.items()}
+    out = emb(ids)
+    tables = {k: v.cpu().numpy().copy() for k, v in emb.get_embedding_tables().items()}
+    gout = {k: rng.uniform(-1, 1, (B, D)).astype(np.float32) for k in fcs}
+    for k, fc in fcs.items():
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), ko.embed_reduce(tables[fc.table.name], ids[k], None, "sum"), rtol=1e-6, atol=1e-6)
+    sum((out[k] * torch.from_numpy(gout[k]).to(DEV)).sum() for k in fcs).backward()
+    after = emb.get_embedding_tables()
+    for t in (0, 3, 350, 511, 512, 650, 699):
+        exp = tables[f"t{t}"].astype(np.float64).copy()
+        for k, fc in fcs.items():
+            if fc.table is tcs[t]:
+                np.add.at(exp, ids[k].reshape(-1), -0.5 * np.repeat(gout[k], ids[k].shape[1], axis=0))
+        np.testing.assert_allclose(after[f"t{t}"].cpu().numpy(), exp, rtol=1e-5, atol=1e-6)
