@@ -23,10 +23,13 @@ With N > 1 the tables are MOD row-sharded over the ranks (C4), B_local = 65,536 
 The K timed steps run with Python's cyclic garbage collector switched off (reference counting still frees every
 tensor): a full collection inside the region starves the GPU for a whole step on a fresh box.
 
-Prints ONE JSON line (rank 0) with `value` = whole-job embedding lookups/s, `ms_per_step` =
-the DCN fwd+bwd step time, a `roofline` object for K1 measured live with HIP events on the
-launch stream, and a `cpu_baseline` object (the oracle timed on this box's host cores on a
-bounded sample of the same workload).
+The LAST stdout line (rank 0) is ONE JSON object below 4 KB (`compact_line`: the driver keeps an ~8 KB tail of stdout + stderr)
+with `value` = whole-job embedding lookups/s, `ms_per_step` = the DCN fwd+bwd step time, a `roofline` object for K1 measured
+live with HIP events on the launch stream (priced at its in-step duration, the isolated launch beside it), `roofline_dominant`
+(the kernel family that costs the step the most time) and a `cpu_baseline` object (the reference's op composition on this
+box's host cores on a bounded sample of the same workload).  Everything else the run measured -- `roofline_step` per kernel
+family, the L = 1 and C2 legs, per-step times, the sharded run's `phases` / `graph_leg` / `parity` -- goes to the side file the
+line names under `detail` (`--detail`, default ./bench_detail.json).
 """
 
 from __future__ import annotations
