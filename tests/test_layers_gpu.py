@@ -1465,3 +1465,33 @@ def test_a_layer_with_more_features_than_one_fused_launch_takes_is_split_into_gr
             if fc.table is tcs[t]:
                 np.add.at(exp, ids[k].reshape(-1), -0.5 * np.repeat(gout[k], ids[k].shape[1], axis=0))
         np.testing.assert_allclose(after[f"t{t}"].cpu().numpy(), exp, rtol=1e-5, atol=1e-6)
+
+
+def test_scheduled_learning_rates_of_many_tables_reach_the_kernels_through_device_memory():
+    """krs_store_f32 carries at most 32 values per launch: 40 tables with their OWN schedules (two launches per update) and SGD,
+    three eager updates -- every table must have moved by its own lr_t(step) * gradient at every step (the rates are written
+    into the descriptor array on the device; a stale or misplaced rate shows as a wrong row)."""
+    kl = _layers()
+    rng = np.random.default_rng(9)
+    T, V, D, B = 40, 30, 8, 12
+    def make_schedule(t):          # (one positional argument: the update count -- jax/config_conversion.py:136-176)
+        return lambda step: (0.5 + 0.01 * t) / (1.0 + step)
+
+    sched = [make_schedule(t) for t in range(T)]
+    tcs = [kl.TableConfig(f"t{t}", V, D, optimizer=kl.SGD(sched[t]), combiner="sum", placement="sparsecore") for t in range(T)]
+    fcs = {f"f{t}": kl.FeatureConfig(f"f{t}", tcs[t], (B, 1), (B, D)) for t in range(T)}
+    emb = kl.DistributedEmbedding(fcs)
+    ids = {k: rng.integers(0, V, (B, 1)).astype(np.int32) for k in fcs}
+    exp = None
+    for step in range(3):
+        out = emb(ids)
+        if exp is None:
+            exp = {k: v.cpu().numpy().astype(np.float64).copy() for k, v in emb.get_embedding_tables().items()}
+        gout = {k: rng.uniform(-1, 1, (B, D)).astype(np.float32) for k in fcs}
+        sum((out[k] * torch.from_numpy(gout[k]).to(DEV)).sum() for k in fcs).backward()
+        for t in range(T):
+            np.add.at(exp[f"t{t}"], ids[f"f{t}"].reshape(-1), -np.float32(sched[t](step)) * gout[f"f{t}"].astype(np.float64))
+        got = emb.get_embedding_tables()
+        for t in (0, 1, 31, 32, 39):
+            np.testing.assert_allclose(got[f"t{t}"].cpu().numpy(), exp[f"t{t}"], rtol=2e-5, atol=2e-6, err_msg=f"step {step} table {t}")
+    assert emb._groups["sparsecore"][0].step == 3
