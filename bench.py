@@ -919,7 +919,7 @@ def roofline_step(a, hots, b_local, res):
                     "achieved": alg / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / sec / HBM_PEAK,
                     "launch_us": sec * 1e6, "algorithmic_bytes": alg, "unique_rows": u, "traffic": traffic,
                     "traffic_source": None if traffic is None else "profiles/k1_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                      "passes of this kernel at this shape, read in round 4; Infinity-Cache hits are counted, not excluded)"})
+                                      "passes of this kernel at this shape, re-read in round 6; Infinity-Cache hits are counted, not excluded)"})
     out += gemm_family_rooflines(a, pr, n, b_local)
     if "gemm_cross_bwd" in pr:
         e = pr["gemm_cross_bwd"]
@@ -1021,8 +1021,8 @@ def k1_roofline(a, hots, b_local, k1_s, kernel, gather_form=False, in_step_s=Non
     return {"kernel": kernel, "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": achieved / HBM_PEAK, "traffic": traffic,
             "traffic_source": None if traffic is None else "profiles/k1_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                              "passes of this kernel at this shape, read in round 2 and re-checked in round 4 (counters cannot be "
-                              "read inside this run)",
+                              "passes of this kernel at this shape, re-read in round 6 (counters cannot be read inside this "
+                              "run)",
             "launch_us": k1_s * 1e6,
             "launch_us_source": ("HIP events around the call inside the probe steps (in-step)" if in_step_s else
                                  "HIP events around one launch behind the timed steps (isolated)"),
